@@ -1,0 +1,697 @@
+/* TEST INFRASTRUCTURE ONLY — see oracle.h.
+ *
+ * Clean-room CPU restatement of the reference's zhpsm matcher
+ * (src/zhpsm/ZHPolar_Match.cpp, PolarParameter.h, ZHPolar_Match.h, point.cpp).
+ * Plain C, FP32 in the reference's source order, with the reference's
+ * float->double promotion points reproduced.  Must be compiled WITHOUT FMA
+ * contraction (-ffp-contract=off), see Makefile.
+ *
+ * Deliberately reproduced quirks:
+ *  - M_PI is 3.141592654 in every zhpsm file       PolarParameter.h:38
+ *  - the median filter is an in-place recurrence   ZHPolar_Match.cpp:1619-1638
+ *  - hwh21 is never accumulated -> D = hwh11*hwh22 ZHPolar_Match.cpp:1067,1102
+ *  - norm_a subtracts m*pi, not m*2pi              ZHPolar_Match.h:77-87
+ *  - ICP partial bubble sort, ref-indexed ix/iy    ZHPolar_Match.cpp:1836-1917
+ */
+#include "oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+/* PolarParameter.h:38-40 */
+#define Z_PI   3.141592654
+#define Z_D2R  (Z_PI / 180.0)
+#define Z_R2D  (180.0 / Z_PI)
+
+/* PolarParameter.h:12-23 */
+#define Z_MIN_RANGE     10.0f
+#define Z_SEG_MAX_DIST  20.0
+#define Z_WEIGHT        (70 * 70)
+#define Z_MAX_ERROR     100
+#define Z_STOP_PSM      0.4
+#define Z_ITER_PSM      30
+#define Z_ITER_ICP      60
+#define Z_STOP_ICP      0.1
+
+/* ------------------------------------------------------------------------ */
+/* parameters: PolarParameter.h:57-67 (ctor), :70-83 (presets)              */
+
+orc_param* orc_param_new(int points, int fov_deg, int max_range, int min_valid,
+                         int window, int fi_min_deg, int fi_max_deg)
+{
+    orc_param* p = (orc_param*)calloc(1, sizeof(orc_param));
+    p->points = points;
+    p->fov_deg = fov_deg;
+    p->max_range = max_range;
+    p->min_valid = min_valid;
+    p->window = window;
+    p->fi_min = (float)(fi_min_deg * Z_D2R);
+    p->fi_max = (float)(fi_max_deg * Z_D2R);
+    p->min_range = (int)Z_MIN_RANGE;
+    p->dfi = (float)((fov_deg * Z_D2R) / (points - 1.0));
+    p->fi = (float*)malloc(sizeof(float) * points);
+    p->si = (float*)malloc(sizeof(float) * points);
+    p->co = (float*)malloc(sizeof(float) * points);
+    orc_tables(p);
+    return p;
+}
+
+orc_param* orc_param_preset(const char* name)
+{
+    if (!strcmp(name, "LMS511")) return orc_param_new(361, 180, 5000, 80, 40, 0, 180);
+    if (!strcmp(name, "LMS211")) return orc_param_new(181, 180, 5000, 40, 20, -90, 90);
+    if (!strcmp(name, "LMS151")) return orc_param_new(541, 270, 5000, 100, 50, -45, 225);
+    return NULL;
+}
+
+void orc_param_free(orc_param* p)
+{
+    if (!p) return;
+    free(p->fi); free(p->si); free(p->co); free(p);
+}
+
+/* pm_init, ZHPolar_Match.cpp:68-78 */
+void orc_tables(orc_param* p)
+{
+    for (int i = 0; i < p->points; ++i) {
+        p->fi[i] = ((float)i) * p->dfi + p->fi_min;
+        p->si[i] = sinf(p->fi[i]);
+        p->co[i] = cosf(p->fi[i]);
+    }
+}
+
+void orc_param_set_fimin_maxrange(orc_param* p, float fi_min, int max_range)
+{
+    p->fi_min = fi_min;
+    p->max_range = max_range;
+    orc_tables(p);
+}
+
+/* ------------------------------------------------------------------------ */
+/* preprocessing                                                            */
+
+/* pm_median_filter, ZHPolar_Match.cpp:1610-1639: 5 taps, edges clamped,
+ * written back into the array being read (so taps left of i are already
+ * filtered). */
+void orc_median(const orc_param* p, float* r)
+{
+    const int n = p->points;
+    for (int i = 0; i < n; ++i) {
+        float w[5];
+        for (int t = 0; t < 5; ++t) {
+            int j = i - 2 + t;
+            if (j < 0) j = 0;
+            if (j > n - 1) j = n - 1;
+            w[t] = r[j];
+        }
+        /* full bubble sort of the 5 taps (:1629-1636) */
+        for (int hi = 4; hi > 0; --hi)
+            for (int k = 0; k < hi; ++k)
+                if (w[k] > w[k + 1]) { float s = w[k]; w[k] = w[k + 1]; w[k + 1] = s; }
+        r[i] = w[2];
+    }
+}
+
+/* pm_find_far_points, :1583-1590 */
+void orc_far(const orc_param* p, const float* r, int* bad)
+{
+    for (int i = 0; i < p->points; ++i)
+        if (r[i] > (float)p->max_range) bad[i] |= ORC_RANGE;
+}
+
+/* pm_segment_scan, :1495-1576.  State machine over (current id, run length). */
+void orc_segment(const orc_param* p, const float* r, const int* bad, int* seg)
+{
+    const float lim = (float)Z_SEG_MAX_DIST;
+    const int n = p->points;
+    int id = 1, run;
+    if (fabsf(r[0] - r[1]) < lim) { seg[0] = id; seg[1] = id; run = 2; }
+    else                          { seg[0] = 0;  seg[1] = id; run = 1; }
+
+    for (int i = 2; i < n; ++i) {
+        int brk = 0;
+        if (bad[i]) {
+            brk = 1;
+            seg[i] = 0;
+        } else {
+            float ex = (float)(r[i] - (2.0 * r[i - 1] - r[i - 2]));   /* :1530, double inside */
+            if (fabsf(r[i] - r[i - 1]) < lim ||
+                (seg[i - 1] == seg[i - 2] && fabsf(ex) < lim)) {
+                run++;
+                seg[i] = id;
+            } else {
+                brk = 1;
+            }
+        }
+        if (!brk) continue;
+        if (run == 1) {
+            float ex = (float)(r[i] - (2.0 * r[i - 1] - r[i - 2]));   /* :1549 */
+            if (seg[i - 2] == 0 && bad[i] == 0 && bad[i - 1] == 0 && bad[i - 2] == 0 &&
+                fabsf(ex) < lim) {
+                seg[i] = id; seg[i - 1] = id; seg[i - 2] = id;
+                run = 3;
+            } else {
+                seg[i - 1] = 0;
+                seg[i] = id;
+                run = 1;
+            }
+        } else {
+            id++;
+            seg[i] = id;
+            run = 1;
+        }
+    }
+}
+
+/* pm_preprocessScan, :861-866 */
+void orc_preprocess(const orc_param* p, float* r, int* bad, int* seg)
+{
+    orc_median(p, r);
+    orc_far(p, r, bad);
+    orc_segment(p, r, bad, seg);
+}
+
+/* ------------------------------------------------------------------------ */
+/* pm_scan_project, :1356-1479                                              */
+
+void orc_scan_project(const orc_param* p, const float* r, const int* bad, const int* seg,
+                      const float pose[3], float* new_r, int* new_bad)
+{
+    const int n = p->points;
+    float* pr = (float*)malloc(sizeof(float) * n);   /* range in the ref frame */
+    float* pf = (float*)malloc(sizeof(float) * n);   /* bearing in the ref frame */
+
+    for (int i = 0; i < n; ++i) {                     /* :1366-1378 */
+        float d = pose[2] + p->fi[i];
+        float x = r[i] * cosf(d) + pose[0];
+        float y = r[i] * sinf(d) + pose[1];
+        pr[i] = sqrtf(x * x + y * y);
+        float a = atan2f(y, x);
+        if (x < 0 && y < 0) a = (float)(a + 2.0 * Z_PI);
+        pf[i] = a;
+        new_r[i] = 10000;
+        new_bad[i] = ORC_EMPTY;
+    }
+
+    for (int i = 1; i < n; ++i) {                     /* :1390-1465 */
+        if (!(seg[i] != 0 && seg[i] == seg[i - 1] && !bad[i] && !bad[i - 1])) continue;
+        if ((double)fabsf(pf[i] - pf[i - 1]) >= Z_PI) continue;         /* :1406 */
+
+        int occ;
+        float a0, a1, r0, r1;
+        if (pf[i] > pf[i - 1]) { occ = 0; a0 = pf[i - 1]; a1 = pf[i]; r0 = pr[i - 1]; r1 = pr[i]; }
+        else                   { occ = 1; a0 = pf[i]; a1 = pf[i - 1]; r0 = pr[i]; r1 = pr[i - 1]; }
+        int j0 = (int)ceil((double)((a0 - p->fi_min) / p->dfi));        /* :1415/:1427 */
+        int j1 = (int)floor((double)((a1 - p->fi_min) / p->dfi));       /* :1416/:1428 */
+
+        for (int j = j0; j <= j1; ++j) {
+            float ri = (r1 - r0) / (a1 - a0) * (((float)j * p->dfi + p->fi_min) - a0) + r0;   /* :1439 */
+            if (j >= 0 && j < n && new_r[j] > ri) {
+                new_r[j] = ri;
+                new_bad[j] &= ~ORC_EMPTY;
+                if (occ) new_bad[j] |= ORC_OCCLUDED; else new_bad[j] &= ~ORC_OCCLUDED;
+                new_bad[j] |= bad[i];
+                new_bad[j] |= bad[i - 1];
+            }
+        }
+    }
+    free(pr); free(pf);
+}
+
+/* ------------------------------------------------------------------------ */
+/* pm_orientation_search, :1152-1261                                        */
+
+int orc_orientation_search(const orc_param* p, const float* ref_r, const int* ref_bad,
+                           const float* new_r, const int* new_bad, float* dth_out)
+{
+    const int n = p->points, W = p->window;
+    const int K = 2 * W + 1;
+    float* err = (float*)malloc(sizeof(float) * K);
+    const float BIG = 10000;
+
+    for (int k = 0; k < K; ++k) {
+        int di = k - W;
+        int lo = di <= 0 ? -di : 0;
+        int hi = di <= 0 ? n : n - di;
+        float e = 0, cnt = 0;
+        for (int i = lo; i < hi; ++i) {
+            float delta = fabsf(new_r[i] - ref_r[i + di]);
+            if (!new_bad[i] && !ref_bad[i + di]) { e += delta; cnt++; }   /* generic branch :1193-1199 */
+        }
+        err[k] = cnt > 0 ? e / cnt : BIG;
+    }
+
+    float emin = (float)(BIG * 10.0);
+    int imin = -1;
+    for (int k = 0; k < K; ++k)
+        if (err[k] < emin) { emin = err[k]; imin = k; }
+    if (imin < 0 || err[imin] >= BIG) { free(err); return ORC_NO_ORIENT; }   /* :1236-1240 */
+
+    float dth = (float)(imin - W) * p->dfi;                                  /* :1241 */
+    if (imin >= 1 && imin < K - 1) {                                         /* :1244-1254 */
+        float D = (float)((err[imin - 1] + err[imin + 1]) - 2.0 * err[imin]);
+        float d = BIG;
+        if ((double)fabsf(D) > 0.01 && err[imin - 1] > err[imin] && err[imin + 1] > err[imin])
+            d = (float)((err[imin - 1] - err[imin + 1]) / D / 2.0);
+        if (fabsf(d) < 1.0) dth += d * p->dfi;
+    }
+    free(err);
+    *dth_out = dth;
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* pm_translation_estimation, :1015-1131                                    */
+
+int orc_translation_estimation(const orc_param* p, const float* ref_r, const int* ref_bad,
+                               const float* new_r, const int* new_bad, float C,
+                               float* dx, float* dy, float* avg_err)
+{
+    const int n = p->points;
+    float hw1 = 0, hw2 = 0, h11 = 0, h12 = 0, h21 = 0, h22 = 0, abs_err = 0;
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        float dr = ref_r[i] - new_r[i];
+        abs_err += fabsf(dr);
+        if (ref_bad[i] == 0 && new_bad[i] == 0 && new_r[i] < (float)p->max_range &&
+            new_r[i] > Z_MIN_RANGE && fabsf(dr) < (float)Z_MAX_ERROR) {
+            float w = C / (dr * dr + C);
+            cnt++;
+            float c = p->co[i], s = p->si[i];
+            float wc = c * w, ws = s * w;
+            hw1 += wc * dr;
+            hw2 += ws * dr;
+            h11 += wc * c;
+            h12 += wc * s;
+            h22 += ws * s;
+        }
+    }
+    if (cnt < p->min_valid) return ORC_FEW_POINTS;                 /* :1089-1096 */
+    float D = h11 * h22 - h12 * h21;                               /* h21 stays 0, :1102 */
+    if ((double)D < 0.001) return ORC_SINGULAR;                    /* :1103-1107 */
+    float i11 = h22 / D, i12 = -h12 / D, i21 = -h12 / D, i22 = h11 / D;
+    *dx = i11 * hw1 + i12 * hw2;
+    *dy = i21 * hw1 + i22 * hw2;
+    *avg_err = abs_err / cnt;
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* shared: pose of the current scan expressed in the reference scan's frame */
+/* :916-927 / :1289-1298 / :1693-1704 (LASER_Y = 0)                         */
+
+static void rel_pose(const float rp[3], const float ap[3], float out[3])
+{
+    const float LY = 0;
+    float rx = rp[0], ry = rp[1], rth = rp[2], ax = ap[0], ay = ap[1], ath = ap[2];
+    out[0] = sinf(rth - ath) * LY + cosf(rth) * ax + sinf(rth) * ay - sinf(rth) * ry - rx * cosf(rth);
+    out[1] = cosf(rth - ath) * LY - sinf(rth) * ax + cosf(rth) * ay - cosf(rth) * ry + rx * sinf(rth) - LY;
+    out[2] = ath - rth;
+}
+
+/* norm_a, ZHPolar_Match.h:77-87 (sic: subtracts m*pi) */
+static float norm_a(float a)
+{
+    int m = (int)(a / (2.0 * Z_PI));
+    a = (float)(a - (float)m * Z_PI);
+    if (a < (-Z_PI)) a = (float)(a + 2.0 * Z_PI);
+    if (a >= Z_PI) a = (float)(a - 2.0 * Z_PI);
+    return a;
+}
+
+/* ------------------------------------------------------------------------ */
+/* pm_psm, :890-1003                                                        */
+
+static int psm_core(const orc_param* p,
+                    const float* ref_r, const int* ref_bad, const float ref_pose[3],
+                    const float* act_r, const int* act_bad, const int* act_seg, const float act_pose[3],
+                    float pose_out[3], float* ret, int* iters_out)
+{
+    const int n = p->points;
+    float* new_r = (float*)malloc(sizeof(float) * n);
+    int* new_bad = (int*)malloc(sizeof(int) * n);
+    float cur[3];
+    rel_pose(ref_pose, act_pose, cur);
+    float ax = cur[0], ay = cur[1], ath = cur[2];
+    float C = Z_WEIGHT;
+    float dx = 0, dy = 0, dth = 0, avg = 100000000.0f;
+    int small = 0, status = ORC_OK;
+    /* On a throw the reference leaves lsa untouched (only written at :1000). */
+    pose_out[0] = act_pose[0]; pose_out[1] = act_pose[1]; pose_out[2] = act_pose[2];
+
+    int iter = -1;
+    while (++iter < Z_ITER_PSM && small < 3) {
+        if ((double)(fabsf(dx) + fabsf(dy) + fabsf(dth)) < Z_STOP_PSM) small++; else small = 0;
+        cur[0] = ax; cur[1] = ay; cur[2] = ath;
+        orc_scan_project(p, act_r, act_bad, act_seg, cur, new_r, new_bad);
+        if (iter % 2 == 0) {
+            status = orc_orientation_search(p, ref_r, ref_bad, new_r, new_bad, &dth);
+            if (status) break;
+            ath += dth;
+            continue;
+        }
+        /* `if (iter == PM_CHANGE_WEIGHT_ITER) C = C/50` (:973) can never fire:
+         * 10 is even and takes the branch above. */
+        status = orc_translation_estimation(p, ref_r, ref_bad, new_r, new_bad, C, &dx, &dy, &avg);
+        if (status) break;
+        ax += dx;
+        ay += dy;
+    }
+    free(new_r); free(new_bad);
+    if (iters_out) *iters_out = iter;
+    if (status) return status;
+    pose_out[0] = ax; pose_out[1] = ay; pose_out[2] = ath;
+    *ret = avg;
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* point_line_distance, :2036-2056                                          */
+
+static float seg_foot(float x1, float y1, float x2, float y2, float x3, float y3,
+                      float* fx, float* fy)
+{
+    float ax = x2 - x1, ay = y2 - y1;
+    float len = sqrtf(ax * ax + ay * ay);
+    if ((double)len < 0.0001) return -1;
+    float t = -(-ax * x3 + ay * y1 + ax * x1 - ay * y3) / (ax * ax + ay * ay);
+    if (t < 0 || t > 1) return -1;
+    *fx = x1 + t * ax;
+    *fy = y1 + t * ay;
+    return sqrtf((x3 - *fx) * (x3 - *fx) + (y3 - *fy) * (y3 - *fy));
+}
+
+/* pm_icp, :1653-2021 */
+static int icp_core(const orc_param* p,
+                    const float* ref_r, const int* ref_bad, const float ref_pose[3],
+                    const float* act_r, const int* act_bad, const int* act_seg, const float act_pose[3],
+                    float pose_out[3], float* ret, int* iters_out)
+{
+    const int n = p->points, W = p->window;
+    float* buf = (float*)malloc(sizeof(float) * n * 14);
+    int* ibuf = (int*)malloc(sizeof(int) * n * 3);
+    float *new_r = buf, *nx = buf + n, *ny = buf + 2 * n, *dist = buf + 3 * n,
+          *qx = buf + 4 * n, *qy = buf + 5 * n, *rx_ = buf + 6 * n, *ry_ = buf + 7 * n,
+          *cx = buf + 8 * n, *cy = buf + 9 * n,
+          *thisx = buf + 10 * n, *thisy = buf + 11 * n, *thatx = buf + 12 * n,
+          *thaty = buf + 13 * n;
+    int *new_bad = ibuf, *mi = ibuf + n, *mj = ibuf + 2 * n;
+
+    float cur[3];
+    rel_pose(ref_pose, act_pose, cur);
+    float ax = cur[0], ay = cur[1], ath = cur[2];
+    for (int i = 0; i < n; ++i) {                 /* :1708-1715 */
+        rx_[i] = ref_r[i] * p->co[i]; ry_[i] = ref_r[i] * p->si[i];
+        cx[i] = act_r[i] * p->co[i];  cy[i] = act_r[i] * p->si[i];
+    }
+    float dx = 0, dy = 0, dth = 0, abs_err = 0;
+    int small = 0, status = ORC_OK, n_tail = 0;
+    pose_out[0] = act_pose[0]; pose_out[1] = act_pose[1]; pose_out[2] = act_pose[2];
+
+    int iter = -1;
+    while (++iter < Z_ITER_ICP && small < 3) {
+        if ((fabsf(dx) + fabsf(dy) + fabsf(dth) * Z_R2D) < Z_STOP_ICP) small++; else small = 0;  /* :1728 */
+
+        cur[0] = ax; cur[1] = ay; cur[2] = ath;
+        orc_scan_project(p, act_r, act_bad, act_seg, cur, new_r, new_bad);   /* flags only */
+
+        float co = cosf(ath), si = sinf(ath);
+        for (int i = 0; i < n; ++i) {             /* :1755-1758 */
+            nx[i] = cx[i] * co - cy[i] * si + ax;
+            ny[i] = cx[i] * si + cy[i] * co + ay;
+        }
+
+        /* correspondence search, :1785-1822 */
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            if (new_bad[i]) continue;
+            int lo = i - W; if (lo < 0) lo = 0;
+            int hi = i + W; if (hi > n) hi = n;
+            float best = 1000000;
+            int bj = -1;
+            for (int j = lo; j < hi; ++j) {
+                if (ref_bad[j]) continue;
+                float ex = nx[i] - rx_[j], ey = ny[i] - ry_[j];
+                float d = ex * ex + ey * ey;
+                if (d < best) { best = d; bj = j; }
+            }
+            if (bj >= 0 && sqrtf(best) < (float)Z_MAX_ERROR) {
+                mi[m] = i; mj[m] = bj; dist[m] = sqrtf(best); m++;
+            }
+        }
+        if (m < p->min_valid) { status = ORC_FEW_POINTS; break; }           /* :1825-1832 */
+
+        /* partial bubble sort: worst 20 % to the tail, :1836-1857 */
+        int drop = (int)((double)m * 0.2);
+        n_tail = drop;
+        for (int pass = 0; pass < drop; ++pass)
+            for (int j = 1; j < m - pass; ++j)
+                if (dist[j] < dist[j - 1]) {
+                    int t;
+                    float f;
+                    t = mi[j]; mi[j] = mi[j - 1]; mi[j - 1] = t;
+                    t = mj[j]; mj[j] = mj[j - 1]; mj[j - 1] = t;
+                    f = dist[j]; dist[j] = dist[j - 1]; dist[j - 1] = f;
+                }
+
+        /* interpolate reference side, :1867-1926; qx/qy are indexed by REF index */
+        int keep = m - drop;
+        for (int k = 0; k < keep; ++k) {
+            int i = mi[k], j = mj[k];
+            float d1 = -1, d2 = -1, f1x = 0, f1y = 0, f2x = 0, f2y = 0;
+            if (j > 0)     d1 = seg_foot(rx_[j - 1], ry_[j - 1], rx_[j], ry_[j], nx[i], ny[i], &f1x, &f1y);
+            if (j < n - 1) d2 = seg_foot(rx_[j], ry_[j], rx_[j + 1], ry_[j + 1], nx[i], ny[i], &f2x, &f2y);
+            qx[j] = rx_[j]; qy[j] = ry_[j];
+            float d0 = sqrtf((rx_[j] - nx[i]) * (rx_[j] - nx[i]) + (ry_[j] - ny[i]) * (ry_[j] - ny[i]));
+            if (d1 > 0 && d1 < d0) { qx[j] = f1x; qy[j] = f1y; d0 = d1; }
+            if (d2 > 0 && d2 < d0) { qx[j] = f2x; qy[j] = f2y; }
+            thisx[k] = nx[i]; thisy[k] = ny[i];
+            thatx[k] = qx[j]; thaty[k] = qy[j];
+        }
+
+        /* closed-form rigid fit, :1936-1991 */
+        float mpx = 0, mpy = 0, mqx = 0, mqy = 0;
+        abs_err = 0;
+        for (int k = 0; k < keep; ++k) {
+            mpx += nx[mi[k]]; mpy += ny[mi[k]];
+            mqx += qx[mj[k]]; mqy += qy[mj[k]];
+        }
+        mpx /= keep; mpy /= keep; mqx /= keep; mqy /= keep;
+        float sxx = 0, sxy = 0, syx = 0, syy = 0;
+        for (int k = 0; k < keep; ++k) {
+            sxx += (nx[mi[k]] - mpx) * (qx[mj[k]] - mqx);
+            sxy += (nx[mi[k]] - mpx) * (qy[mj[k]] - mqy);
+            syx += (ny[mi[k]] - mpy) * (qx[mj[k]] - mqx);
+            syy += (ny[mi[k]] - mpy) * (qy[mj[k]] - mqy);
+        }
+        dth = atan2f(sxy - syx, sxx + syy);
+        dx = mqx - ax - (cosf(dth) * (mpx - ax) - sinf(dth) * (mpy - ay));
+        dy = mqy - ay - (sinf(dth) * (mpx - ax) + cosf(dth) * (mpy - ay));
+        ax += dx;
+        ay += dy;
+        ath += dth;
+        ath = norm_a(ath);
+    }
+
+    if (!status) {
+        /* :2015-2020: mean residual of the first (0.2 n) recorded pairs */
+        for (int k = 0; k < n_tail; ++k)
+            abs_err += sqrtf((thisx[k] - thatx[k]) * (thisx[k] - thatx[k]) +
+                             (thisy[k] - thaty[k]) * (thisy[k] - thaty[k]));
+        *ret = abs_err / n_tail;
+        pose_out[0] = ax; pose_out[1] = ay; pose_out[2] = ath;
+    }
+    if (iters_out) *iters_out = iter;
+    free(buf); free(ibuf);
+    return status;
+}
+
+int orc_match(const orc_param* p, int which,
+              const float* ref_r, const int* ref_bad, const float ref_pose[3],
+              const float* act_r, const int* act_bad, const int* act_seg, const float act_pose[3],
+              float pose_out[3], float* ret, int* iters_out)
+{
+    if (which == 0)
+        return psm_core(p, ref_r, ref_bad, ref_pose, act_r, act_bad, act_seg, act_pose, pose_out, ret, iters_out);
+    return icp_core(p, ref_r, ref_bad, ref_pose, act_r, act_bad, act_seg, act_pose, pose_out, ret, iters_out);
+}
+
+/* ------------------------------------------------------------------------ */
+/* pm_error_index2, :1279-1339                                              */
+
+void orc_error_index2(const orc_param* p,
+                      const float* ref_r, const int* ref_bad, const float ref_pose[3],
+                      const float* act_r, const int* act_bad, const int* act_seg, const float act_pose[3],
+                      float exy[2], int* n_assoc)
+{
+    const int n = p->points;
+    float* new_r = (float*)malloc(sizeof(float) * n);
+    int* new_bad = (int*)malloc(sizeof(int) * n);
+    float cur[3];
+    rel_pose(ref_pose, act_pose, cur);
+    orc_scan_project(p, act_r, act_bad, act_seg, cur, new_r, new_bad);
+    float sx = 0, sy = 0;
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        float delta = (float)(fabsf(new_r[i] - ref_r[i]) * 0.01);
+        if (!new_bad[i] && !ref_bad[i] && (double)delta < Z_MAX_ERROR / 2.0 && delta < 1) {
+            float a = delta * p->co[i], b = delta * p->si[i];
+            sx += a * a;
+            sy += b * b;
+            cnt++;
+        }
+    }
+    /* the reference returns uninitialised values when cnt == 0; NaN here */
+    exy[0] = cnt > 0 ? sx / cnt : NAN;
+    exy[1] = cnt > 0 ? sy / cnt : NAN;
+    if (n_assoc) *n_assoc = cnt;
+    free(new_r); free(new_bad);
+}
+
+/* ------------------------------------------------------------------------ */
+/* FMatch, :81-121                                                          */
+
+void orc_fmatch(const orc_param* p, float* ref_r, int* ref_bad, int* ref_seg,
+                float* act_r, int* act_bad, int* act_seg, int bFirst,
+                float pose_out[3], float ret_pair[2])
+{
+    const float zero[3] = {0, 0, 0};
+    float ret;
+    if (bFirst) orc_preprocess(p, ref_r, ref_bad, ref_seg);
+    orc_preprocess(p, act_r, act_bad, act_seg);
+    int st = icp_core(p, ref_r, ref_bad, zero, act_r, act_bad, act_seg, zero, pose_out, &ret, NULL);
+    if (st == ORC_OK) {
+        orc_error_index2(p, ref_r, ref_bad, zero, act_r, act_bad, act_seg, pose_out, ret_pair, NULL);
+        return;
+    }
+    /* the retry at :110-118 sees identical inputs and throws again */
+    ret_pair[0] = -1.0f; ret_pair[1] = -1.0f;
+}
+
+/* ------------------------------------------------------------------------ */
+
+int orc_match_batch(const orc_param* p, int which, int B,
+                    const float* r, const int* bad, const int* seg,
+                    const int* ref_idx, const int* act_idx,
+                    float* pose_out, int* status_out)
+{
+    const float zero[3] = {0, 0, 0};
+    const int n = p->points;
+    int ok = 0;
+    for (int b = 0; b < B; ++b) {
+        float ret = 0;
+        size_t ro = (size_t)ref_idx[b] * n, ao = (size_t)act_idx[b] * n;
+        int st = orc_match(p, which, r + ro, bad + ro, zero, r + ao, bad + ao, seg + ao, zero,
+                           pose_out + 3 * b, &ret, NULL);
+        if (status_out) status_out[b] = st;
+        ok += st == ORC_OK;
+    }
+    return ok;
+}
+
+/* ------------------------------------------------------------------------ */
+/* readCarmon, :172-284.  strtok/atof semantics kept; `line` buffer 8192.   */
+
+int orc_read_carmen(orc_param* p, const char* filename, const char* tag_in,
+                    float** r_out, float** x_out, float** y_out, int** bad_out, float** pose_out)
+{
+    FILE* f = fopen(filename, "r");
+    if (!f) return 0;
+    const int n = p->points;
+    int cap = 256, S = 0;
+    float* R = (float*)malloc(sizeof(float) * cap * n);
+    float* X = (float*)malloc(sizeof(float) * cap * n);
+    float* Y = (float*)malloc(sizeof(float) * cap * n);
+    int* Bd = (int*)malloc(sizeof(int) * cap * n);
+    float* P = (float*)malloc(sizeof(float) * cap * 3);
+    float* sr = (float*)calloc(n, sizeof(float));   /* the reused `ls` scan */
+    float* sx = (float*)calloc(n, sizeof(float));
+    float* sy = (float*)calloc(n, sizeof(float));
+    int* sb = (int*)calloc(n, sizeof(int));
+    float pose[3] = {0, 0, 0};
+
+    /* "LMS..." tags mark the in-house pose-less format (:204-211) */
+    int ours = strncmp(tag_in, "LMS", 3) == 0;
+    char line[8192];
+    int first = 1, fail = 0;
+    while (fgets(line, sizeof line, f)) {
+        size_t L = strlen(line);
+        if (L && line[L - 1] == '\n') line[--L] = 0;
+        else if (L == sizeof line - 1) break;       /* getline failbit on overlong line */
+        char* tok = strtok(line, " ");
+        if (!tok) continue;
+        if (strcmp(tok, tag_in) != 0) continue;      /* :214-216 */
+        /* laserType */ strtok(NULL, " ");
+        double start = atof(strtok(NULL, " "));
+        double fov = atof(strtok(NULL, " "));
+        /* resolution */ strtok(NULL, " ");
+        double maxRange = atof(strtok(NULL, " "));
+        /* accuracy */ strtok(NULL, " ");
+        /* remissionMode */ strtok(NULL, " ");
+        int np = atoi(strtok(NULL, " "));
+        if (np == 0) continue;
+        if (first) {                                 /* :227-235 */
+            first = 0;
+            p->fi_min = (float)start;
+            p->fi_max = (float)(start + fov * Z_D2R);
+            orc_tables(p);
+            if (maxRange * 100 != p->max_range) p->max_range = (int)(maxRange * 100);
+        }
+        if (np != n - 1 && np != n) { fail = 1; break; }     /* :238-248 */
+        for (int i = 0; i < np; ++i) {               /* :250-259 */
+            sr[i] = (float)(atof(strtok(NULL, " ")) * 100.0);
+            sx[i] = sr[i] * p->co[i];
+            sy[i] = sr[i] * p->si[i];
+            sb[i] = 0;
+            if (sr[i] < Z_MIN_RANGE) sr[i] = (float)(p->max_range + 1);
+        }
+        if (!ours) {                                 /* :262-270 */
+            strtok(NULL, " ");
+            pose[0] = (float)atof(strtok(NULL, " "));
+            pose[1] = (float)atof(strtok(NULL, " "));
+            pose[2] = (float)atof(strtok(NULL, " "));
+        }
+        if (np == n - 1) { sr[np] = (float)(p->max_range + 1); sb[np] = 0; }   /* :276-279 */
+        if (S == cap) {
+            cap *= 2;
+            R = (float*)realloc(R, sizeof(float) * cap * n);
+            X = (float*)realloc(X, sizeof(float) * cap * n);
+            Y = (float*)realloc(Y, sizeof(float) * cap * n);
+            Bd = (int*)realloc(Bd, sizeof(int) * cap * n);
+            P = (float*)realloc(P, sizeof(float) * cap * 3);
+        }
+        memcpy(R + (size_t)S * n, sr, sizeof(float) * n);
+        memcpy(X + (size_t)S * n, sx, sizeof(float) * n);
+        memcpy(Y + (size_t)S * n, sy, sizeof(float) * n);
+        memcpy(Bd + (size_t)S * n, sb, sizeof(int) * n);
+        memcpy(P + (size_t)S * 3, pose, sizeof pose);
+        S++;
+    }
+    fclose(f);
+    free(sr); free(sx); free(sy); free(sb);
+    if (fail || S == 0) { free(R); free(X); free(Y); free(Bd); free(P); return 0; }
+    *r_out = R; *x_out = X; *y_out = Y; *bad_out = Bd; *pose_out = P;
+    return S;
+}
+
+void orc_free(void* ptr) { free(ptr); }
+
+/* ------------------------------------------------------------------------ */
+/* OrientedPoint2D::oplus / ominus, src/zhpsm/point.cpp:31-69 (double)      */
+
+void orc_oplus(const double a[3], const double b[3], double out[3])
+{
+    double c = cos(a[2]), s = sin(a[2]);
+    out[0] = a[0] + b[0] * c - b[1] * s;
+    out[1] = a[1] + b[0] * s + b[1] * c;
+    out[2] = a[2] + b[2];
+}
+
+void orc_ominus(const double a[3], const double b[3], double out[3])
+{
+    double c = cos(a[2]), s = sin(a[2]);
+    out[0] = (b[0] - a[0]) * c + (b[1] - a[1]) * s;
+    out[1] = -(b[0] - a[0]) * s + (b[1] - a[1]) * c;
+    out[2] = b[2] - a[2];
+}
