@@ -1,0 +1,187 @@
+/* lsa_core.h — C ABI of the MI355X scan-matching / grid-mapping core.
+ *
+ * This is the drop-in boundary.  The reference has no FFI: its
+ * callers link the C++ classes of libzhpsm / libzhicp / libzhcsm / libdrawmap.
+ * Those classes are re-provided in laser_slam_amd/host/ as thin adapters over
+ * the functions below; each entry point names the reference interface it
+ * replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++/torch types cross this boundary.
+ *  - `d_` parameters are DEVICE pointers (hipMalloc / torch CUDA tensors),
+ *    `h_` parameters are HOST pointers.
+ *  - scan sets are SoA, row-major [S][N]: ranges f32 [cm], flags u8, segments u16.
+ *  - every function returns LSA_OK (0) or a negative LSA_E_* code; per-pair
+ *    matcher outcomes are reported in a status array (LSA_ST_*), mirroring the
+ *    `throw int` sites of the reference (ZHPolar_Match.cpp:1095,1106,1239,1831).
+ *  - a context owns one HIP stream + scratch; contexts are independent, so one
+ *    context per host thread is re-entrant (the reference's matchers are used
+ *    one-instance-per-thread, src/slam/threadLocal1.cpp:144).
+ *  - there is NO CPU fallback: without a HIP device every call fails with
+ *    LSA_E_NODEVICE.
+ */
+#ifndef LSA_CORE_H
+#define LSA_CORE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSA_OK            0
+#define LSA_E_NODEVICE   -1
+#define LSA_E_HIP        -2
+#define LSA_E_ARG        -3
+#define LSA_E_NOMEM      -4
+#define LSA_E_IO         -5
+
+/* per-pair matcher status */
+#define LSA_ST_OK          0
+#define LSA_ST_FEW_POINTS  1   /* `throw 1`, ZHPolar_Match.cpp:1095 / :1831 */
+#define LSA_ST_SINGULAR    2   /* `throw 1`, ZHPolar_Match.cpp:1106 */
+#define LSA_ST_NO_ORIENT   3   /* `throw 1`, ZHPolar_Match.cpp:1239 */
+
+/* measurement flags, src/zhpsm/PolarParameter.h:5-9 */
+#define LSA_BAD_RANGE     1
+#define LSA_BAD_MOVING    2
+#define LSA_BAD_MIXED     4
+#define LSA_BAD_OCCLUDED  8
+#define LSA_BAD_EMPTY     16
+
+#define LSA_MATCH_PSM 0        /* CPolarMatch::pm_psm  ZHPolar_Match.cpp:890  */
+#define LSA_MATCH_ICP 1        /* CPolarMatch::pm_icp  ZHPolar_Match.cpp:1653 */
+
+/* Laser parameter block == struct _PARAM, src/zhpsm/PolarParameter.h:42-67. */
+typedef struct lsa_laser_param {
+    int32_t points;       /* pm_l_points */
+    int32_t fov_deg;      /* pm_fov */
+    int32_t max_range;    /* pm_max_range [cm] */
+    int32_t min_range;    /* pm_min_range [cm] */
+    int32_t min_valid;    /* pm_min_valid_points */
+    int32_t window;       /* pm_scan_window */
+    float   fi_min;       /* pm_fi_min [rad] */
+    float   fi_max;       /* pm_fi_max [rad] */
+    float   dfi;          /* pm_dfi [rad] */
+} lsa_laser_param;
+
+typedef struct lsa_ctx lsa_ctx;
+typedef struct lsa_grid lsa_grid;
+
+/* ---- library / device ---------------------------------------------------- */
+const char* lsa_version(void);
+int lsa_device_count(void);
+const char* lsa_last_error(void);
+
+/* ---- parameters: Base_PARAM ctor + presets (PolarParameter.h:57-83),
+ *      getParam (ZHPolar_Match.cpp:15-27), pm_init (ZHPolar_Match.cpp:68-78) -- */
+int lsa_param_make(lsa_laser_param* out, int points, int fov_deg, int max_range_cm,
+                   int min_valid, int window, int fi_min_deg, int fi_max_deg);
+int lsa_param_preset(lsa_laser_param* out, const char* laser_name);
+/* host bearing tables pm_fi / pm_si / pm_co, bit-identical to pm_init */
+int lsa_param_tables(const lsa_laser_param* p, float* h_fi, float* h_si, float* h_co);
+
+/* ---- context -------------------------------------------------------------- */
+int lsa_ctx_create(lsa_ctx** out, int device, const lsa_laser_param* p);
+/* callers write m_pParam fields and call pm_init() (tcp_slam/clientFrontend.cpp:575-582);
+ * the adapter forwards that here. */
+int lsa_ctx_set_param(lsa_ctx* c, const lsa_laser_param* p);
+int lsa_ctx_get_param(const lsa_ctx* c, lsa_laser_param* out);
+/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = own stream */
+int lsa_ctx_set_stream(lsa_ctx* c, void* hip_stream);
+void* lsa_ctx_get_stream(const lsa_ctx* c);
+int lsa_ctx_sync(lsa_ctx* c);
+void lsa_ctx_destroy(lsa_ctx* c);
+
+/* ---- device memory helpers (for C/C++ hosts without their own allocator) --- */
+int lsa_malloc(void** d_ptr, uint64_t bytes);
+int lsa_free(void* d_ptr);
+int lsa_memcpy_h2d(lsa_ctx* c, void* d_dst, const void* h_src, uint64_t bytes);
+int lsa_memcpy_d2h(lsa_ctx* c, void* h_dst, const void* d_src, uint64_t bytes);
+int lsa_memset(lsa_ctx* c, void* d_dst, int value, uint64_t bytes);
+
+/* ---- CARMEN reader: CPolarMatch::readCarmon, ZHPolar_Match.cpp:172-284 ------
+ * Host-side text parsing into SoA host arrays (malloc'd, free with lsa_host_free).
+ * May update p->fi_min / fi_max / max_range exactly as the reference does.
+ * tag = "ROBOTLASER1" (readFlirt) or the "LMS..." name of the pose-less format. */
+int lsa_carmen_read(lsa_laser_param* p, const char* filename, const char* tag,
+                    int* n_scans, float** h_r, float** h_x, float** h_y,
+                    int32_t** h_bad, float** h_pose);
+void lsa_host_free(void* h_ptr);
+
+/* ---- preprocessing: pm_preprocessScan = median + far + segment,
+ *      ZHPolar_Match.cpp:861-866, 1495-1639 ---------------------------------- */
+int lsa_preprocess_batch(lsa_ctx* c, int n_scans, float* d_r /*in/out*/,
+                         uint8_t* d_bad /*in/out*/, uint16_t* d_seg /*out*/);
+
+/* ---- batched matcher: pm_psm / pm_icp (+ optional pm_error_index2,
+ *      ZHPolar_Match.cpp:1279) -------------------------------------------------
+ * Pair b matches current scan act_idx[b] against reference scan ref_idx[b] of
+ * the same preprocessed scan set.  d_init_pose: [B][6] = ref (x,y,th), act
+ * (x,y,th) in cm/rad, or NULL for all-zero (what FMatch uses, :97-99).
+ * Outputs (any may be NULL except d_pose_out): pose [B][3] = lsa->rx,ry,th;
+ * ret [B] = matcher return value; err_xy [B][2] + n_assoc [B] = pm_error_index2 at
+ * the result; status [B]; iters [B]. */
+int lsa_match_batch(lsa_ctx* c, int which, int n_pairs,
+                    const float* d_r, const uint8_t* d_bad, const uint16_t* d_seg,
+                    const int32_t* d_ref_idx, const int32_t* d_act_idx,
+                    const float* d_init_pose,
+                    float* d_pose_out, float* d_ret, float* d_err_xy, int32_t* d_n_assoc,
+                    int32_t* d_status, int32_t* d_iters);
+
+/* pm_error_index2 (ZHPolar_Match.cpp:1279-1339) for B pairs at the poses in
+ * d_init_pose [B][6] (NULL = origin). */
+int lsa_error_index2_batch(lsa_ctx* c, int n_pairs, const float* d_r, const uint8_t* d_bad,
+                           const uint16_t* d_seg, const int32_t* d_ref_idx, const int32_t* d_act_idx,
+                           const float* d_init_pose, float* d_err_xy, int32_t* d_n_assoc);
+
+/* Stage-level entry points (public methods of CPolarMatch callers may use):
+ * pm_scan_project :1356, pm_orientation_search :1152, pm_translation_estimation :1015.
+ * One wave per scan; d_pose [S][3]; new_bad as u8. */
+int lsa_scan_project_batch(lsa_ctx* c, int n_scans, const float* d_r, const uint8_t* d_bad,
+                           const uint16_t* d_seg, const float* d_pose,
+                           float* d_new_r, uint8_t* d_new_bad);
+
+/* ---- single-pair host convenience (B = 1 of the above, host pointers, int flags
+ *      as in struct _PMScan, PolarParameter.h:105-184) --------------------------
+ * FMatch semantics (ZHPolar_Match.cpp:81-121): preprocess act (and ref when
+ * first != 0) in place, zero poses, pm_icp, pm_error_index2.  ret_pair follows the
+ * reference: (sx2, sy2) on success, (-1,-1) on failure. */
+int lsa_fmatch_host(lsa_ctx* c, float* h_ref_r, int32_t* h_ref_bad, int32_t* h_ref_seg,
+                    float* h_act_r, int32_t* h_act_bad, int32_t* h_act_seg, int first,
+                    float h_pose_out[3], float h_ret_pair[2]);
+int lsa_preprocess_host(lsa_ctx* c, float* h_r, int32_t* h_bad, int32_t* h_seg);
+int lsa_match_host(lsa_ctx* c, int which,
+                   const float* h_ref_r, const int32_t* h_ref_bad, const float h_ref_pose[3],
+                   const float* h_act_r, const int32_t* h_act_bad, const int32_t* h_act_seg,
+                   const float h_act_pose[3],
+                   float h_pose_out[3], float* h_ret, int32_t* status);
+int lsa_error_index2_host(lsa_ctx* c,
+                          const float* h_ref_r, const int32_t* h_ref_bad, const float h_ref_pose[3],
+                          const float* h_act_r, const int32_t* h_act_bad, const int32_t* h_act_seg,
+                          const float h_act_pose[3], float h_exy[2], int32_t* n_assoc);
+
+/* ---- counting grid: CPMap, src/drawmap/PMap.{h,cpp} + grid_line, line.cpp ---
+ * Counts are kept as u32 on the device and mirrored to float on download
+ * (the reference stores float counts; identical while < 2^24). */
+int lsa_grid_create(lsa_grid** out, lsa_ctx* c, int size_x, int size_y, int center_x, int center_y,
+                    float off_x, float off_y, double resolution);   /* initializeMap :16-41 */
+void lsa_grid_destroy(lsa_grid* g);
+int lsa_grid_clear(lsa_grid* g);
+/* updateMap :46-91 for n_scans scans of n_beams endpoints each (global metres):
+ * d_gx,d_gy [S][n_beams]; d_robot_xy [S][2]; d_n_valid [S] (beams used per scan) or NULL. */
+int lsa_grid_update_batch(lsa_grid* g, int n_scans, int n_beams, const float* d_gx, const float* d_gy,
+                          const float* d_robot_xy, const int32_t* d_n_valid);
+int lsa_grid_update_host(lsa_grid* g, const float* h_gx, const float* h_gy, int n, float rx, float ry);
+int lsa_grid_compute_prob(lsa_grid* g);                         /* computeProbsOfMap :119-136 */
+/* layer 0 = hit, 1 = sum, 2 = prob; row-major [x][y] floats */
+int lsa_grid_download(lsa_grid* g, int layer, float* h_out);
+int lsa_grid_device_ptrs(lsa_grid* g, uint32_t** d_hit, uint32_t** d_sum, float** d_prob);
+/* getPointCloud :138-149: returns count via *n; copies at most cap points, [x][y] order */
+int lsa_grid_cloud(lsa_grid* g, float prob_thre, float* h_x, float* h_y, int cap, int* n);
+int lsa_grid_cell(const lsa_grid* g, float px, float py, int* ix, int* iy);   /* mapPosfromPoint :100-117 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSA_CORE_H */

@@ -1,0 +1,298 @@
+"""ctypes binding of the C ABI (include/lsa_core.h) for tests and bench.py.
+
+This is plumbing: every compute call goes straight into liblsa_core.so (HIP).
+There is no Python or CPU implementation behind it — if the library is missing
+or no GPU is present, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "liblsa_core.so")
+
+MATCH_PSM, MATCH_ICP = 0, 1
+ST_OK, ST_FEW_POINTS, ST_SINGULAR, ST_NO_ORIENT = 0, 1, 2, 3
+
+vp = C.c_void_p
+
+
+class LaserParam(C.Structure):
+    _fields_ = [("points", C.c_int32), ("fov_deg", C.c_int32), ("max_range", C.c_int32),
+                ("min_range", C.c_int32), ("min_valid", C.c_int32), ("window", C.c_int32),
+                ("fi_min", C.c_float), ("fi_max", C.c_float), ("dfi", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class LsaError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load liblsa_core.so (raises if it has not been built: no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LsaError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.lsa_version.restype = C.c_char_p
+    L.lsa_last_error.restype = C.c_char_p
+    L.lsa_ctx_get_stream.restype = vp
+    L.lsa_ctx_get_stream.argtypes = [vp]
+    L.lsa_ctx_destroy.argtypes = [vp]
+    L.lsa_ctx_destroy.restype = None
+    L.lsa_grid_destroy.argtypes = [vp]
+    L.lsa_grid_destroy.restype = None
+    L.lsa_host_free.argtypes = [vp]
+    L.lsa_host_free.restype = None
+    L.lsa_param_make.argtypes = [C.POINTER(LaserParam)] + [C.c_int] * 7
+    L.lsa_param_preset.argtypes = [C.POINTER(LaserParam), C.c_char_p]
+    L.lsa_param_tables.argtypes = [C.POINTER(LaserParam), vp, vp, vp]
+    L.lsa_ctx_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(LaserParam)]
+    L.lsa_ctx_set_param.argtypes = [vp, C.POINTER(LaserParam)]
+    L.lsa_ctx_get_param.argtypes = [vp, C.POINTER(LaserParam)]
+    L.lsa_ctx_set_stream.argtypes = [vp, vp]
+    L.lsa_ctx_sync.argtypes = [vp]
+    L.lsa_malloc.argtypes = [C.POINTER(vp), C.c_uint64]
+    L.lsa_free.argtypes = [vp]
+    L.lsa_memcpy_h2d.argtypes = [vp, vp, vp, C.c_uint64]
+    L.lsa_memcpy_d2h.argtypes = [vp, vp, vp, C.c_uint64]
+    L.lsa_memset.argtypes = [vp, vp, C.c_int, C.c_uint64]
+    L.lsa_carmen_read.argtypes = [C.POINTER(LaserParam), C.c_char_p, C.c_char_p, C.POINTER(C.c_int)] + [C.POINTER(vp)] * 5
+    L.lsa_preprocess_batch.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.lsa_match_batch.argtypes = [vp, C.c_int, C.c_int] + [vp] * 12
+    L.lsa_error_index2_batch.argtypes = [vp, C.c_int] + [vp] * 8
+    L.lsa_scan_project_batch.argtypes = [vp, C.c_int] + [vp] * 6
+    L.lsa_fmatch_host.argtypes = [vp] + [vp] * 6 + [C.c_int, vp, vp]
+    L.lsa_preprocess_host.argtypes = [vp, vp, vp, vp]
+    L.lsa_match_host.argtypes = [vp, C.c_int] + [vp] * 10
+    L.lsa_error_index2_host.argtypes = [vp] + [vp] * 9
+    L.lsa_grid_create.argtypes = [C.POINTER(vp), vp] + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_double]
+    L.lsa_grid_clear.argtypes = [vp]
+    L.lsa_grid_update_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.lsa_grid_update_host.argtypes = [vp, vp, vp, C.c_int, C.c_float, C.c_float]
+    L.lsa_grid_compute_prob.argtypes = [vp]
+    L.lsa_grid_download.argtypes = [vp, C.c_int, vp]
+    L.lsa_grid_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.lsa_grid_cloud.argtypes = [vp, C.c_float, vp, vp, C.c_int, C.POINTER(C.c_int)]
+    L.lsa_grid_cell.argtypes = [vp, C.c_float, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise LsaError("%s failed (%d): %s" % (what or "lsa call", rc, lib().lsa_last_error().decode()))
+
+
+def _hp(a):
+    """host numpy array -> void*"""
+    return None if a is None else a.ctypes.data_as(vp)
+
+
+def _dp(t):
+    """device pointer: int, None, or anything with .data_ptr() (torch tensor)"""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return vp(t)
+    return vp(t.data_ptr())
+
+
+def param_preset(name):
+    p = LaserParam()
+    check(lib().lsa_param_preset(C.byref(p), name.encode()), "lsa_param_preset")
+    return p
+
+
+def param_make(points, fov_deg, max_range, min_valid, window, fi_min_deg, fi_max_deg):
+    p = LaserParam()
+    check(lib().lsa_param_make(C.byref(p), points, fov_deg, max_range, min_valid, window, fi_min_deg, fi_max_deg),
+          "lsa_param_make")
+    return p
+
+
+def param_tables(p):
+    n = p.points
+    fi, si, co = (np.zeros(n, np.float32) for _ in range(3))
+    check(lib().lsa_param_tables(C.byref(p), _hp(fi), _hp(si), _hp(co)), "lsa_param_tables")
+    return fi, si, co
+
+
+def carmen_read(p, filename, tag="ROBOTLASER1"):
+    """Returns (r, x, y, bad, pose) host arrays; updates p in place like readCarmon."""
+    n_scans = C.c_int(0)
+    ptrs = [vp() for _ in range(5)]
+    check(lib().lsa_carmen_read(C.byref(p), filename.encode(), tag.encode(), C.byref(n_scans),
+                                *[C.byref(q) for q in ptrs]), "lsa_carmen_read")
+    S, n = n_scans.value, p.points
+    outs = []
+    for q, (ct, dt, w) in zip(ptrs, [(C.c_float, np.float32, n)] * 3 + [(C.c_int32, np.int32, n), (C.c_float, np.float32, 3)]):
+        a = np.ctypeslib.as_array(C.cast(q, C.POINTER(ct)), (S, w)).astype(dt, copy=True)
+        lib().lsa_host_free(q)
+        outs.append(a)
+    return tuple(outs)
+
+
+class Context:
+    """One HIP stream + scratch bound to a laser parameter block."""
+
+    def __init__(self, param, device=0):
+        self.L = lib()
+        self.h = vp()
+        self.param = param
+        check(self.L.lsa_ctx_create(C.byref(self.h), device, C.byref(param)), "lsa_ctx_create")
+
+    def close(self):
+        if self.h:
+            self.L.lsa_ctx_destroy(self.h)
+            self.h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n(self):
+        return self.param.points
+
+    def set_param(self, param):
+        check(self.L.lsa_ctx_set_param(self.h, C.byref(param)), "lsa_ctx_set_param")
+        self.param = param
+
+    def set_stream(self, stream_ptr):
+        check(self.L.lsa_ctx_set_stream(self.h, vp(stream_ptr) if stream_ptr else None), "lsa_ctx_set_stream")
+
+    def stream(self):
+        return self.L.lsa_ctx_get_stream(self.h)
+
+    def sync(self):
+        check(self.L.lsa_ctx_sync(self.h), "lsa_ctx_sync")
+
+    # ---- device-pointer (batched) API: arguments are torch CUDA tensors or raw ints
+    def preprocess_batch(self, S, d_r, d_bad, d_seg):
+        check(self.L.lsa_preprocess_batch(self.h, S, _dp(d_r), _dp(d_bad), _dp(d_seg)), "lsa_preprocess_batch")
+
+    def match_batch(self, which, B, d_r, d_bad, d_seg, d_ref_idx, d_act_idx, d_pose_out, d_init_pose=None,
+                    d_ret=None, d_err_xy=None, d_n_assoc=None, d_status=None, d_iters=None):
+        check(self.L.lsa_match_batch(self.h, which, B, _dp(d_r), _dp(d_bad), _dp(d_seg), _dp(d_ref_idx),
+                                     _dp(d_act_idx), _dp(d_init_pose), _dp(d_pose_out), _dp(d_ret),
+                                     _dp(d_err_xy), _dp(d_n_assoc), _dp(d_status), _dp(d_iters)), "lsa_match_batch")
+
+    def error_index2_batch(self, B, d_r, d_bad, d_seg, d_ref_idx, d_act_idx, d_init_pose, d_err_xy, d_n_assoc=None):
+        check(self.L.lsa_error_index2_batch(self.h, B, _dp(d_r), _dp(d_bad), _dp(d_seg), _dp(d_ref_idx),
+                                            _dp(d_act_idx), _dp(d_init_pose), _dp(d_err_xy), _dp(d_n_assoc)),
+              "lsa_error_index2_batch")
+
+    def scan_project_batch(self, S, d_r, d_bad, d_seg, d_pose, d_new_r, d_new_bad):
+        check(self.L.lsa_scan_project_batch(self.h, S, _dp(d_r), _dp(d_bad), _dp(d_seg), _dp(d_pose),
+                                            _dp(d_new_r), _dp(d_new_bad)), "lsa_scan_project_batch")
+
+    # ---- single-pair host API (numpy in/out, int flags like struct _PMScan)
+    def preprocess_host(self, r, bad=None):
+        r = np.ascontiguousarray(r, np.float32).copy()
+        bad = np.zeros(self.n, np.int32) if bad is None else np.ascontiguousarray(bad, np.int32).copy()
+        seg = np.zeros(self.n, np.int32)
+        check(self.L.lsa_preprocess_host(self.h, _hp(r), _hp(bad), _hp(seg)), "lsa_preprocess_host")
+        return r, bad, seg
+
+    def match_host(self, which, ref, act, ref_pose=None, act_pose=None):
+        rp = None if ref_pose is None else np.ascontiguousarray(ref_pose, np.float32)
+        ap = None if act_pose is None else np.ascontiguousarray(act_pose, np.float32)
+        pose = np.zeros(3, np.float32)
+        ret = C.c_float(0)
+        st = C.c_int32(0)
+        check(self.L.lsa_match_host(self.h, which, _hp(ref[0]), _hp(ref[1]), _hp(rp),
+                                    _hp(act[0]), _hp(act[1]), _hp(act[2]), _hp(ap), _hp(pose),
+                                    C.cast(C.byref(ret), vp), C.cast(C.byref(st), vp)), "lsa_match_host")
+        return st.value, pose, ret.value
+
+    def error_index2_host(self, ref, act, ref_pose, act_pose):
+        rp = np.ascontiguousarray(ref_pose, np.float32)
+        ap = np.ascontiguousarray(act_pose, np.float32)
+        exy = np.zeros(2, np.float32)
+        na = C.c_int32(0)
+        check(self.L.lsa_error_index2_host(self.h, _hp(ref[0]), _hp(ref[1]), _hp(rp), _hp(act[0]), _hp(act[1]),
+                                           _hp(act[2]), _hp(ap), _hp(exy), C.cast(C.byref(na), vp)),
+              "lsa_error_index2_host")
+        return exy, na.value
+
+    def fmatch_host(self, ref_raw, act_raw, first):
+        ref = [np.ascontiguousarray(a).copy() for a in ref_raw]
+        act = [np.ascontiguousarray(a).copy() for a in act_raw]
+        pose = np.zeros(3, np.float32)
+        pair = np.zeros(2, np.float32)
+        check(self.L.lsa_fmatch_host(self.h, _hp(ref[0]), _hp(ref[1]), _hp(ref[2]), _hp(act[0]), _hp(act[1]),
+                                     _hp(act[2]), int(bool(first)), _hp(pose), _hp(pair)), "lsa_fmatch_host")
+        return pose, pair, ref, act
+
+
+class Grid:
+    """CPMap counting grid resident in HBM."""
+
+    def __init__(self, ctx, sx, sy, cx, cy, offx, offy, res):
+        self.L = lib()
+        self.ctx = ctx
+        self.shape = (sx, sy)
+        self.h = vp()
+        check(self.L.lsa_grid_create(C.byref(self.h), ctx.h, sx, sy, cx, cy, offx, offy, res), "lsa_grid_create")
+
+    def close(self):
+        if self.h:
+            self.L.lsa_grid_destroy(self.h)
+            self.h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self):
+        check(self.L.lsa_grid_clear(self.h), "lsa_grid_clear")
+
+    def update_batch(self, S, n_beams, d_gx, d_gy, d_robot_xy, d_n_valid=None):
+        check(self.L.lsa_grid_update_batch(self.h, S, n_beams, _dp(d_gx), _dp(d_gy), _dp(d_robot_xy), _dp(d_n_valid)),
+              "lsa_grid_update_batch")
+
+    def update_host(self, gx, gy, rx, ry):
+        gx = np.ascontiguousarray(gx, np.float32)
+        gy = np.ascontiguousarray(gy, np.float32)
+        check(self.L.lsa_grid_update_host(self.h, _hp(gx), _hp(gy), len(gx), rx, ry), "lsa_grid_update_host")
+
+    def compute_prob(self):
+        check(self.L.lsa_grid_compute_prob(self.h), "lsa_grid_compute_prob")
+
+    def download(self, layer):
+        out = np.zeros(self.shape, np.float32)
+        check(self.L.lsa_grid_download(self.h, layer, _hp(out)), "lsa_grid_download")
+        return out
+
+    def layers(self):
+        return self.download(0), self.download(1), self.download(2)
+
+    def device_ptrs(self):
+        a, b, c = vp(), vp(), vp()
+        check(self.L.lsa_grid_device_ptrs(self.h, C.byref(a), C.byref(b), C.byref(c)), "lsa_grid_device_ptrs")
+        return a.value, b.value, c.value
+
+    def cloud(self, thre, cap=1 << 22):
+        x = np.zeros(cap, np.float32)
+        y = np.zeros(cap, np.float32)
+        n = C.c_int(0)
+        check(self.L.lsa_grid_cloud(self.h, thre, _hp(x), _hp(y), cap, C.byref(n)), "lsa_grid_cloud")
+        return x[:min(n.value, cap)], y[:min(n.value, cap)]
+
+    def cell(self, px, py):
+        ix, iy = C.c_int(0), C.c_int(0)
+        check(self.L.lsa_grid_cell(self.h, px, py, C.byref(ix), C.byref(iy)), "lsa_grid_cell")
+        return ix.value, iy.value

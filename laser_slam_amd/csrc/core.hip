@@ -1,0 +1,608 @@
+// C ABI of the MI355X scan-matching / grid-mapping core (include/lsa_core.h):
+// context, parameter block, launch wrappers and the single-pair host helpers.
+// No CPU fallback lives here: without a HIP device every entry point fails.
+#include "../../include/lsa_core.h"
+#include "lsa_device.h"
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "match_kernels.hip"
+#include "grid_kernels.hip"
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                     \
+    do {                                                                  \
+        hipError_t e__ = (expr);                                          \
+        if (e__ != hipSuccess) return fail(LSA_E_HIP, #expr, e__);        \
+    } while (0)
+
+struct lsa_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    lsa_laser_param p{};
+    float* d_tab = nullptr;      // fi | si | co, 3*N floats
+    // staging for the single-pair host helpers (2 scans)
+    float* d_r = nullptr;
+    uint8_t* d_bad = nullptr;
+    uint16_t* d_seg = nullptr;
+    int* d_idx = nullptr;        // ref_idx, act_idx
+    float* d_small = nullptr;    // init pose[6] | pose[3] | ret | exy[2]
+    int* d_ismall = nullptr;     // n_assoc | status | iters
+    int staged_n = 0;
+};
+
+static lsa::DevParam dev_param(const lsa_ctx* c)
+{
+    lsa::DevParam P;
+    P.n = c->p.points; P.max_range = c->p.max_range; P.min_valid = c->p.min_valid; P.window = c->p.window;
+    P.fi_min = c->p.fi_min; P.dfi = c->p.dfi;
+    P.fi = c->d_tab; P.si = c->d_tab + c->p.points; P.co = c->d_tab + 2 * c->p.points;
+    return P;
+}
+
+static int icp_lds(int n) { int Np = (n + 63) & ~63; return 42 * Np + 2048; }
+static int psm_lds(int n) { int Np = (n + 63) & ~63; return 35 * Np; }
+static int pre_lds(int n) { int Np = (n + 63) & ~63; return 12 * Np; }
+
+static int check_param(const lsa_laser_param* p)
+{
+    if (!p) return fail(LSA_E_ARG, "null laser parameter block");
+    if (p->points < 8 || p->points > 1280) return fail(LSA_E_ARG, "points must be in [8,1280]");
+    if (p->window < 1 || 2 * p->window + 1 > ((p->points + 63) & ~63))
+        return fail(LSA_E_ARG, "scan window must satisfy 2W+1 <= points (rounded up to 64)");
+    if ((int)(p->points * 0.2) > 256) return fail(LSA_E_ARG, "trim pool supports at most 256 dropped pairs");
+    if (!(p->dfi > 0)) return fail(LSA_E_ARG, "dfi must be positive");
+    return LSA_OK;
+}
+
+extern "C" {
+
+const char* lsa_version(void) { return "laser_slam_amd 0.1 (gfx950)"; }
+
+const char* lsa_last_error(void) { return g_err.c_str(); }
+
+int lsa_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- parameters (host) ----------------------------------------------------
+// Base_PARAM ctor, src/zhpsm/PolarParameter.h:57-67 (M_PI = 3.141592654 there)
+int lsa_param_make(lsa_laser_param* out, int points, int fov_deg, int max_range_cm,
+                   int min_valid, int window, int fi_min_deg, int fi_max_deg)
+{
+    if (!out) return fail(LSA_E_ARG, "null output");
+    out->points = points;
+    out->fov_deg = fov_deg;
+    out->max_range = max_range_cm;
+    out->min_range = (int)LSA_MIN_RANGE;
+    out->min_valid = min_valid;
+    out->window = window;
+    out->fi_min = (float)(fi_min_deg * LSA_ZD2R);
+    out->fi_max = (float)(fi_max_deg * LSA_ZD2R);
+    out->dfi = (float)((fov_deg * LSA_ZD2R) / (points - 1.0));
+    return LSA_OK;
+}
+
+// presets, PolarParameter.h:70-83 and getParam, ZHPolar_Match.cpp:15-27
+int lsa_param_preset(lsa_laser_param* out, const char* name)
+{
+    if (!out || !name) return fail(LSA_E_ARG, "null argument");
+    if (!strcmp(name, "LMS511")) return lsa_param_make(out, 361, 180, 5000, 80, 40, 0, 180);
+    if (!strcmp(name, "LMS211")) return lsa_param_make(out, 181, 180, 5000, 40, 20, -90, 90);
+    if (!strcmp(name, "LMS151")) return lsa_param_make(out, 541, 270, 5000, 100, 50, -45, 225);
+    return fail(LSA_E_ARG, "unknown laser preset");
+}
+
+// pm_init, ZHPolar_Match.cpp:68-78
+int lsa_param_tables(const lsa_laser_param* p, float* fi, float* si, float* co)
+{
+    if (!p || !fi || !si || !co) return fail(LSA_E_ARG, "null argument");
+    for (int i = 0; i < p->points; ++i) {
+        fi[i] = ((float)i) * p->dfi + p->fi_min;
+        si[i] = lsa::sinf_(fi[i]);
+        co[i] = lsa::cosf_(fi[i]);
+    }
+    return LSA_OK;
+}
+
+// ---- context ----------------------------------------------------------------
+static int upload_tables(lsa_ctx* c)
+{
+    const int n = c->p.points;
+    std::vector<float> t(3 * (size_t)n);
+    lsa_param_tables(&c->p, t.data(), t.data() + n, t.data() + 2 * n);
+    if (c->d_tab) { HIP_TRY(hipFree(c->d_tab)); c->d_tab = nullptr; }
+    HIP_TRY(hipMalloc((void**)&c->d_tab, sizeof(float) * 3 * n));
+    HIP_TRY(hipMemcpy(c->d_tab, t.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice));
+    return LSA_OK;
+}
+
+static int ensure_staging(lsa_ctx* c)
+{
+    const int n = c->p.points;
+    if (c->staged_n == n) return LSA_OK;
+    if (c->d_r) { hipFree(c->d_r); hipFree(c->d_bad); hipFree(c->d_seg); hipFree(c->d_idx); hipFree(c->d_small); hipFree(c->d_ismall); }
+    HIP_TRY(hipMalloc((void**)&c->d_r, sizeof(float) * 2 * n));
+    HIP_TRY(hipMalloc((void**)&c->d_bad, 2 * n));
+    HIP_TRY(hipMalloc((void**)&c->d_seg, sizeof(uint16_t) * 2 * n));
+    HIP_TRY(hipMalloc((void**)&c->d_idx, sizeof(int) * 2));
+    HIP_TRY(hipMalloc((void**)&c->d_small, sizeof(float) * 16));
+    HIP_TRY(hipMalloc((void**)&c->d_ismall, sizeof(int) * 4));
+    const int idx[2] = {0, 1};
+    HIP_TRY(hipMemcpy(c->d_idx, idx, sizeof idx, hipMemcpyHostToDevice));
+    c->staged_n = n;
+    return LSA_OK;
+}
+
+int lsa_ctx_create(lsa_ctx** out, int device, const lsa_laser_param* p)
+{
+    if (!out) return fail(LSA_E_ARG, "null output");
+    int rc = check_param(p);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(LSA_E_NODEVICE, "no HIP device: this library has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(LSA_E_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    lsa_ctx* c = new lsa_ctx;
+    c->device = device;
+    c->p = *p;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(LSA_E_HIP, "hipStreamCreate", e); }
+    rc = upload_tables(c);
+    if (rc) { hipStreamDestroy(c->stream); delete c; return rc; }
+    *out = c;
+    return LSA_OK;
+}
+
+int lsa_ctx_set_param(lsa_ctx* c, const lsa_laser_param* p)
+{
+    if (!c) return fail(LSA_E_ARG, "null context");
+    int rc = check_param(p);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->p = *p;
+    return upload_tables(c);
+}
+
+int lsa_ctx_get_param(const lsa_ctx* c, lsa_laser_param* out)
+{
+    if (!c || !out) return fail(LSA_E_ARG, "null argument");
+    *out = c->p;
+    return LSA_OK;
+}
+
+int lsa_ctx_set_stream(lsa_ctx* c, void* s)
+{
+    if (!c) return fail(LSA_E_ARG, "null context");
+    if (c->own_stream && c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+    if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
+    else {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return LSA_OK;
+}
+
+void* lsa_ctx_get_stream(const lsa_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int lsa_ctx_sync(lsa_ctx* c)
+{
+    if (!c) return fail(LSA_E_ARG, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LSA_OK;
+}
+
+void lsa_ctx_destroy(lsa_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    hipFree(c->d_tab);
+    if (c->d_r) { hipFree(c->d_r); hipFree(c->d_bad); hipFree(c->d_seg); hipFree(c->d_idx); hipFree(c->d_small); hipFree(c->d_ismall); }
+    delete c;
+}
+
+// ---- memory helpers ---------------------------------------------------------
+int lsa_malloc(void** d, uint64_t bytes)
+{
+    if (!d) return fail(LSA_E_ARG, "null output");
+    hipError_t e = hipMalloc(d, bytes ? bytes : 1);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? LSA_E_NOMEM : LSA_E_HIP, "hipMalloc", e);
+    return LSA_OK;
+}
+int lsa_free(void* d) { HIP_TRY(hipFree(d)); return LSA_OK; }
+int lsa_memcpy_h2d(lsa_ctx* c, void* d, const void* h, uint64_t bytes)
+{
+    if (!c) return fail(LSA_E_ARG, "null context");
+    HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LSA_OK;
+}
+int lsa_memcpy_d2h(lsa_ctx* c, void* h, const void* d, uint64_t bytes)
+{
+    if (!c) return fail(LSA_E_ARG, "null context");
+    HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LSA_OK;
+}
+int lsa_memset(lsa_ctx* c, void* d, int v, uint64_t bytes)
+{
+    if (!c) return fail(LSA_E_ARG, "null context");
+    HIP_TRY(hipMemsetAsync(d, v, bytes, c->stream));
+    return LSA_OK;
+}
+
+// ---- launches ---------------------------------------------------------------
+int lsa_preprocess_batch(lsa_ctx* c, int S, float* d_r, uint8_t* d_bad, uint16_t* d_seg)
+{
+    if (!c || !d_r || !d_bad || !d_seg) return fail(LSA_E_ARG, "null argument");
+    if (S <= 0) return LSA_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(lsa::preprocess_kernel, dim3(S), dim3(64), pre_lds(c->p.points), c->stream,
+                       dev_param(c), S, d_r, d_bad, d_seg);
+    HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+
+int lsa_match_batch(lsa_ctx* c, int which, int B,
+                    const float* d_r, const uint8_t* d_bad, const uint16_t* d_seg,
+                    const int32_t* d_ref_idx, const int32_t* d_act_idx, const float* d_init_pose,
+                    float* d_pose_out, float* d_ret, float* d_err_xy, int32_t* d_n_assoc,
+                    int32_t* d_status, int32_t* d_iters)
+{
+    if (!c || !d_r || !d_bad || !d_seg || !d_ref_idx || !d_act_idx || !d_pose_out)
+        return fail(LSA_E_ARG, "null argument");
+    if (which != LSA_MATCH_PSM && which != LSA_MATCH_ICP) return fail(LSA_E_ARG, "unknown matcher");
+    if (B <= 0) return LSA_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const lsa::DevParam P = dev_param(c);
+    if (which == LSA_MATCH_ICP)
+        hipLaunchKernelGGL(lsa::icp_kernel, dim3(B), dim3(64), icp_lds(P.n), c->stream, P, B, d_r, d_bad, d_seg,
+                           d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters);
+    else
+        hipLaunchKernelGGL(lsa::psm_kernel, dim3(B), dim3(64), psm_lds(P.n), c->stream, P, B, d_r, d_bad, d_seg,
+                           d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters);
+    HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+
+int lsa_scan_project_batch(lsa_ctx* c, int S, const float* d_r, const uint8_t* d_bad, const uint16_t* d_seg,
+                           const float* d_pose, float* d_new_r, uint8_t* d_new_bad)
+{
+    if (!c || !d_r || !d_bad || !d_seg || !d_pose || !d_new_r || !d_new_bad) return fail(LSA_E_ARG, "null argument");
+    if (S <= 0) return LSA_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(lsa::project_kernel, dim3(S), dim3(64), psm_lds(c->p.points), c->stream,
+                       dev_param(c), S, d_r, d_bad, d_seg, d_pose, d_new_r, d_new_bad);
+    HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+
+// ---- single-pair host helpers -------------------------------------------------
+static int stage_scan(lsa_ctx* c, int slot, const float* r, const int32_t* bad, const int32_t* seg)
+{
+    const int n = c->p.points;
+    std::vector<uint8_t> b8(n);
+    std::vector<uint16_t> s16(n);
+    for (int i = 0; i < n; ++i) { b8[i] = bad ? (uint8_t)bad[i] : 0; s16[i] = seg ? (uint16_t)seg[i] : 0; }
+    HIP_TRY(hipMemcpyAsync(c->d_r + slot * n, r, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_bad + slot * n, b8.data(), n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_seg + slot * n, s16.data(), sizeof(uint16_t) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LSA_OK;
+}
+
+static int unstage_scan(lsa_ctx* c, int slot, float* r, int32_t* bad, int32_t* seg)
+{
+    const int n = c->p.points;
+    std::vector<uint8_t> b8(n);
+    std::vector<uint16_t> s16(n);
+    HIP_TRY(hipMemcpyAsync(r, c->d_r + slot * n, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(b8.data(), c->d_bad + slot * n, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(s16.data(), c->d_seg + slot * n, sizeof(uint16_t) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i) { if (bad) bad[i] = b8[i]; if (seg) seg[i] = s16[i]; }
+    return LSA_OK;
+}
+
+int lsa_preprocess_host(lsa_ctx* c, float* r, int32_t* bad, int32_t* seg)
+{
+    if (!c || !r || !bad || !seg) return fail(LSA_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_staging(c); if (rc) return rc;
+    rc = stage_scan(c, 0, r, bad, nullptr); if (rc) return rc;
+    rc = lsa_preprocess_batch(c, 1, c->d_r, c->d_bad, c->d_seg); if (rc) return rc;
+    return unstage_scan(c, 0, r, bad, seg);
+}
+
+static int run_pair(lsa_ctx* c, int which, const float* ref_pose, const float* act_pose, bool want_err,
+                    float pose_out[3], float* ret, float exy[2], int32_t* n_assoc, int32_t* status)
+{
+    float init[6] = {0, 0, 0, 0, 0, 0};
+    const bool has_init = ref_pose || act_pose;
+    if (ref_pose) memcpy(init, ref_pose, 12);
+    if (act_pose) memcpy(init + 3, act_pose, 12);
+    if (has_init) HIP_TRY(hipMemcpyAsync(c->d_small, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    int rc = lsa_match_batch(c, which, 1, c->d_r, c->d_bad, c->d_seg, c->d_idx, c->d_idx + 1,
+                             has_init ? c->d_small : nullptr, c->d_small + 6, c->d_small + 9,
+                             want_err ? c->d_small + 10 : nullptr, want_err ? c->d_ismall : nullptr,
+                             c->d_ismall + 1, c->d_ismall + 2);
+    if (rc) return rc;
+    float fs[16]; int is[4];
+    HIP_TRY(hipMemcpyAsync(fs, c->d_small, sizeof fs, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(is, c->d_ismall, sizeof is, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(pose_out, fs + 6, 12);
+    if (ret) *ret = fs[9];
+    if (exy) { exy[0] = fs[10]; exy[1] = fs[11]; }
+    if (n_assoc) *n_assoc = is[0];
+    if (status) *status = is[1];
+    return LSA_OK;
+}
+
+int lsa_match_host(lsa_ctx* c, int which,
+                   const float* ref_r, const int32_t* ref_bad, const float ref_pose[3],
+                   const float* act_r, const int32_t* act_bad, const int32_t* act_seg, const float act_pose[3],
+                   float pose_out[3], float* ret, int32_t* status)
+{
+    if (!c || !ref_r || !act_r || !pose_out) return fail(LSA_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_staging(c); if (rc) return rc;
+    rc = stage_scan(c, 0, ref_r, ref_bad, nullptr); if (rc) return rc;
+    rc = stage_scan(c, 1, act_r, act_bad, act_seg); if (rc) return rc;
+    return run_pair(c, which, ref_pose, act_pose, false, pose_out, ret, nullptr, nullptr, status);
+}
+
+int lsa_error_index2_batch(lsa_ctx* c, int B, const float* d_r, const uint8_t* d_bad, const uint16_t* d_seg,
+                           const int32_t* d_ref_idx, const int32_t* d_act_idx, const float* d_init_pose,
+                           float* d_err_xy, int32_t* d_n_assoc)
+{
+    if (!c || !d_r || !d_bad || !d_seg || !d_ref_idx || !d_act_idx || !d_err_xy) return fail(LSA_E_ARG, "null argument");
+    if (B <= 0) return LSA_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(lsa::error_index_kernel, dim3(B), dim3(64), psm_lds(c->p.points), c->stream,
+                       dev_param(c), B, d_r, d_bad, d_seg, d_ref_idx, d_act_idx, d_init_pose, d_err_xy, d_n_assoc);
+    HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+
+// pm_error_index2 for one host pair (B = 1 of the above)
+int lsa_error_index2_host(lsa_ctx* c,
+                          const float* ref_r, const int32_t* ref_bad, const float ref_pose[3],
+                          const float* act_r, const int32_t* act_bad, const int32_t* act_seg,
+                          const float act_pose[3], float exy[2], int32_t* n_assoc)
+{
+    if (!c || !ref_r || !act_r || !exy) return fail(LSA_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_staging(c); if (rc) return rc;
+    rc = stage_scan(c, 0, ref_r, ref_bad, nullptr); if (rc) return rc;
+    rc = stage_scan(c, 1, act_r, act_bad, act_seg); if (rc) return rc;
+    float init[6] = {0, 0, 0, 0, 0, 0};
+    if (ref_pose) memcpy(init, ref_pose, 12);
+    if (act_pose) memcpy(init + 3, act_pose, 12);
+    HIP_TRY(hipMemcpyAsync(c->d_small, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    rc = lsa_error_index2_batch(c, 1, c->d_r, c->d_bad, c->d_seg, c->d_idx, c->d_idx + 1, c->d_small,
+                                c->d_small + 10, c->d_ismall);
+    if (rc) return rc;
+    int na = 0;
+    HIP_TRY(hipMemcpyAsync(exy, c->d_small + 10, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&na, c->d_ismall, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n_assoc) *n_assoc = na;
+    return LSA_OK;
+}
+
+// CPolarMatch::FMatch, ZHPolar_Match.cpp:81-121
+int lsa_fmatch_host(lsa_ctx* c, float* ref_r, int32_t* ref_bad, int32_t* ref_seg,
+                    float* act_r, int32_t* act_bad, int32_t* act_seg, int first,
+                    float pose_out[3], float ret_pair[2])
+{
+    if (!c || !ref_r || !ref_bad || !ref_seg || !act_r || !act_bad || !act_seg || !pose_out || !ret_pair)
+        return fail(LSA_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_staging(c); if (rc) return rc;
+    const int n = c->p.points;
+    rc = stage_scan(c, 0, ref_r, ref_bad, ref_seg); if (rc) return rc;
+    rc = stage_scan(c, 1, act_r, act_bad, act_seg); if (rc) return rc;
+    if (first) { rc = lsa_preprocess_batch(c, 1, c->d_r, c->d_bad, c->d_seg); if (rc) return rc; }
+    rc = lsa_preprocess_batch(c, 1, c->d_r + n, c->d_bad + n, c->d_seg + n); if (rc) return rc;
+    int32_t status = 0, na = 0;
+    float ret = 0, exy[2] = {0, 0};
+    rc = run_pair(c, LSA_MATCH_ICP, nullptr, nullptr, true, pose_out, &ret, exy, &na, &status);
+    if (rc) return rc;
+    if (first) { rc = unstage_scan(c, 0, ref_r, ref_bad, ref_seg); if (rc) return rc; }
+    rc = unstage_scan(c, 1, act_r, act_bad, act_seg); if (rc) return rc;
+    if (status == LSA_ST_OK) { ret_pair[0] = exy[0]; ret_pair[1] = exy[1]; }
+    else { ret_pair[0] = -1.0f; ret_pair[1] = -1.0f; }   // the retry at :110-118 sees the same inputs
+    return LSA_OK;
+}
+
+
+// ---- counting grid ------------------------------------------------------------
+struct lsa_grid {
+    lsa_ctx* c = nullptr;
+    lsa::GridParam G{};
+    uint32_t* d_hit = nullptr;
+    uint32_t* d_sum = nullptr;
+    float* d_prob = nullptr;
+    float* d_tmp = nullptr;      // float mirror for downloads / cloud output
+    int* d_rows = nullptr;       // per-row counts + total
+    // staging for lsa_grid_update_host
+    float* d_pts = nullptr;
+    int pts_cap = 0;
+    size_t cells = 0;
+};
+
+int lsa_grid_create(lsa_grid** out, lsa_ctx* c, int sx, int sy, int cx, int cy, float offx, float offy, double res)
+{
+    if (!out || !c) return fail(LSA_E_ARG, "null argument");
+    if (sx <= 0 || sy <= 0 || !(res > 0)) return fail(LSA_E_ARG, "bad grid geometry");
+    HIP_TRY(hipSetDevice(c->device));
+    lsa_grid* g = new lsa_grid;
+    g->c = c;
+    g->G.size_x = sx; g->G.size_y = sy; g->G.center_x = cx; g->G.center_y = cy;
+    g->G.off_x = offx; g->G.off_y = offy; g->G.res = res;
+    g->cells = (size_t)sx * sy;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&g->d_hit, g->cells * 4)) != hipSuccess ||
+        (e = hipMalloc((void**)&g->d_sum, g->cells * 4)) != hipSuccess ||
+        (e = hipMalloc((void**)&g->d_prob, g->cells * 4)) != hipSuccess ||
+        (e = hipMalloc((void**)&g->d_tmp, g->cells * 4)) != hipSuccess ||
+        (e = hipMalloc((void**)&g->d_rows, sizeof(int) * (sx + 1))) != hipSuccess) {
+        lsa_grid_destroy(g);
+        return fail(LSA_E_NOMEM, "hipMalloc(grid)", e);
+    }
+    *out = g;
+    return lsa_grid_clear(g);
+}
+
+void lsa_grid_destroy(lsa_grid* g)
+{
+    if (!g) return;
+    hipSetDevice(g->c->device);
+    hipStreamSynchronize(g->c->stream);
+    hipFree(g->d_hit); hipFree(g->d_sum); hipFree(g->d_prob); hipFree(g->d_tmp); hipFree(g->d_rows); hipFree(g->d_pts);
+    delete g;
+}
+
+int lsa_grid_clear(lsa_grid* g)
+{
+    if (!g) return fail(LSA_E_ARG, "null grid");
+    HIP_TRY(hipMemsetAsync(g->d_hit, 0, g->cells * 4, g->c->stream));
+    HIP_TRY(hipMemsetAsync(g->d_sum, 0, g->cells * 4, g->c->stream));
+    HIP_TRY(hipMemsetAsync(g->d_prob, 0, g->cells * 4, g->c->stream));
+    return LSA_OK;
+}
+
+static int blocks_for(size_t work, int block, int cap = 256 * 16)
+{
+    size_t b = (work + block - 1) / block;
+    if (b > (size_t)cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+int lsa_grid_update_batch(lsa_grid* g, int S, int n_beams, const float* d_gx, const float* d_gy,
+                          const float* d_robot_xy, const int32_t* d_n_valid)
+{
+    if (!g || !d_gx || !d_gy || !d_robot_xy) return fail(LSA_E_ARG, "null argument");
+    if (S <= 0 || n_beams <= 0) return LSA_OK;
+    HIP_TRY(hipSetDevice(g->c->device));
+    hipLaunchKernelGGL(lsa::grid_update_kernel, dim3(blocks_for((size_t)S * n_beams, 256)), dim3(256), 0,
+                       g->c->stream, g->G, S, n_beams, d_gx, d_gy, d_robot_xy, d_n_valid, g->d_hit, g->d_sum);
+    HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+
+int lsa_grid_update_host(lsa_grid* g, const float* gx, const float* gy, int n, float rx, float ry)
+{
+    if (!g || (n > 0 && (!gx || !gy))) return fail(LSA_E_ARG, "null argument");
+    if (n < 0) return lsa_grid_compute_prob(g);          // updateMap(n<0) == finish, PMap.cpp:54-60
+    if (n == 0) return LSA_OK;
+    HIP_TRY(hipSetDevice(g->c->device));
+    if (g->pts_cap < n) {
+        if (g->d_pts) hipFree(g->d_pts);
+        HIP_TRY(hipMalloc((void**)&g->d_pts, sizeof(float) * (2 * (size_t)n + 2)));
+        g->pts_cap = n;
+    }
+    hipStream_t st = g->c->stream;
+    const float rxy[2] = {rx, ry};
+    HIP_TRY(hipMemcpyAsync(g->d_pts, gx, sizeof(float) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(g->d_pts + g->pts_cap, gy, sizeof(float) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(g->d_pts + 2 * (size_t)g->pts_cap, rxy, sizeof rxy, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));      // rxy is a stack temporary
+    return lsa_grid_update_batch(g, 1, n, g->d_pts, g->d_pts + g->pts_cap, g->d_pts + 2 * (size_t)g->pts_cap, nullptr);
+}
+
+int lsa_grid_compute_prob(lsa_grid* g)
+{
+    if (!g) return fail(LSA_E_ARG, "null grid");
+    HIP_TRY(hipSetDevice(g->c->device));
+    hipLaunchKernelGGL(lsa::grid_prob_kernel, dim3(blocks_for(g->cells, 256)), dim3(256), 0, g->c->stream,
+                       g->cells, g->d_hit, g->d_sum, g->d_prob);
+    HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+
+int lsa_grid_download(lsa_grid* g, int layer, float* h_out)
+{
+    if (!g || !h_out || layer < 0 || layer > 2) return fail(LSA_E_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(g->c->device));
+    const float* src = g->d_prob;
+    if (layer < 2) {
+        hipLaunchKernelGGL(lsa::grid_to_float_kernel, dim3(blocks_for(g->cells, 256)), dim3(256), 0, g->c->stream,
+                           g->cells, layer == 0 ? g->d_hit : g->d_sum, g->d_tmp);
+        HIP_TRY(hipGetLastError());
+        src = g->d_tmp;
+    }
+    HIP_TRY(hipMemcpyAsync(h_out, src, g->cells * 4, hipMemcpyDeviceToHost, g->c->stream));
+    HIP_TRY(hipStreamSynchronize(g->c->stream));
+    return LSA_OK;
+}
+
+int lsa_grid_device_ptrs(lsa_grid* g, uint32_t** hit, uint32_t** sum, float** prob)
+{
+    if (!g) return fail(LSA_E_ARG, "null grid");
+    if (hit) *hit = g->d_hit;
+    if (sum) *sum = g->d_sum;
+    if (prob) *prob = g->d_prob;
+    return LSA_OK;
+}
+
+int lsa_grid_cloud(lsa_grid* g, float thre, float* h_x, float* h_y, int cap, int* n)
+{
+    if (!g || !n || cap < 0 || (cap > 0 && (!h_x || !h_y))) return fail(LSA_E_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(g->c->device));
+    hipStream_t st = g->c->stream;
+    const int sx = g->G.size_x;
+    const int wave_blocks = (sx * 64 + 255) / 256;
+    hipLaunchKernelGGL(lsa::cloud_count_kernel, dim3(wave_blocks), dim3(256), 0, st, g->G, g->d_prob, thre, g->d_rows);
+    hipLaunchKernelGGL(lsa::cloud_scan_kernel, dim3(1), dim3(1024), 0, st, sx, g->d_rows, g->d_rows + sx);
+    HIP_TRY(hipGetLastError());
+    int total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, g->d_rows + sx, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *n = total;
+    int take = total < cap ? total : cap;
+    if ((size_t)take * 2 > g->cells) take = (int)(g->cells / 2);
+    if (take > 0) {
+        hipLaunchKernelGGL(lsa::cloud_emit_kernel, dim3(wave_blocks), dim3(256), 0, st, g->G, g->d_prob, thre,
+                           g->d_rows, take, g->d_tmp, g->d_tmp + take);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_x, g->d_tmp, sizeof(float) * take, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_y, g->d_tmp + take, sizeof(float) * take, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return LSA_OK;
+}
+
+int lsa_grid_cell(const lsa_grid* g, float px, float py, int* ix, int* iy)
+{
+    if (!g || !ix || !iy) return fail(LSA_E_ARG, "null argument");
+    *ix = lsa::grid_cell1(px, g->G.off_x, g->G.center_x, g->G.res);
+    *iy = lsa::grid_cell1(py, g->G.off_y, g->G.center_y, g->G.res);
+    return LSA_OK;
+}
+
+} // extern "C"

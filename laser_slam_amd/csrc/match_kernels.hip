@@ -1,0 +1,787 @@
+// Batched scan matching on gfx950: one 64-lane wavefront per scan pair.
+//
+// Restates (bit-faithfully, FP32 in source order, -ffp-contract=off) the
+// reference's zhpsm matcher:
+//   pm_scan_project            src/zhpsm/ZHPolar_Match.cpp:1356-1479
+//   pm_orientation_search      :1152-1261
+//   pm_translation_estimation  :1015-1131
+//   pm_psm                     :890-1003
+//   pm_icp                     :1653-2021   (+ point_line_distance :2036-2056)
+//   pm_error_index2            :1279-1339
+//   pm_median_filter / pm_find_far_points / pm_segment_scan  :1495-1639
+//
+// Why these are not "shuffle-tree" reductions: the matchers iterate through hard
+// gates, and SURVEY.md §7 measured that last-bit perturbations (FMA contraction
+// alone) move 30-44 % of pairs past 1e-4 m / 1e-4 rad.  Every floating-point sum
+// below is therefore accumulated in the reference's index order by a single lane
+// (several independent sums run side by side in different lanes), while all
+// order-free work (trigonometry, nearest-neighbour search, interpolation,
+// compaction) is spread over the 64 lanes.
+//
+// Data layout: scans are SoA in HBM ([S][N] f32 ranges, u8 flags, u16 segments);
+// a wave streams its two scans in with coalesced loads and keeps everything else
+// in LDS (reference scan x/y, projected scan, atomic-min keys, match list).
+#include "lsa_device.h"
+#include "../../include/lsa_core.h"
+
+namespace lsa {
+
+// ---------------------------------------------------------------------------
+// LDS carve-up (byte offsets, Np = N rounded up to 64).  Regions are reused
+// across the phases of an iteration.
+//
+//  ICP (42 Np + 2 KiB)                         PSM (35 Np)
+//   [ 0, 8) ref_xy float2 (ref_r at the end)    [ 0, 4) ref_r
+//   [ 8,12) act_r                               [ 4, 8) act_r
+//   [12,20) pr,pf -> q (ix,iy) float2           [ 8,16) pr,pf      -> terms 0,1
+//   [20,28) keys -> NN result -> match list     [16,24) keys       -> terms 2,3
+//   [28,36) nxy float2                          [24,28) new_r      -> |dr|
+//   [36,40) owner u32                           [28,32) err[2W+1]  -> term 4
+//   [40,41) ref_bad  [41,42) pair_ok            [32,33) ref_bad [33,34) pair_ok [34,35) new_bad
+//   [42Np, +2 KiB) trim pool
+// ---------------------------------------------------------------------------
+
+struct Lds {
+    float2* ref_xy;
+    float* ref_r;
+    float* act_r;
+    float* pr;
+    float* pf;
+    float2* q;
+    unsigned long long* key;
+    float2* nxy;
+    float* new_r;
+    float* err;
+    uint32_t* owner;
+    uint8_t* ref_bad;
+    uint8_t* pair_ok;
+    uint8_t* new_bad;
+    float* pool_d;
+    uint32_t* pool_ij;
+};
+
+__device__ __forceinline__ Lds carve_icp(char* base, int Np)
+{
+    Lds L = {};
+    L.ref_xy = (float2*)base;
+    L.ref_r = (float*)base;
+    L.act_r = (float*)(base + 8 * Np);
+    L.pr = (float*)(base + 12 * Np);
+    L.pf = (float*)(base + 16 * Np);
+    L.q = (float2*)(base + 12 * Np);
+    L.key = (unsigned long long*)(base + 20 * Np);
+    L.nxy = (float2*)(base + 28 * Np);
+    L.owner = (uint32_t*)(base + 36 * Np);
+    L.ref_bad = (uint8_t*)(base + 40 * Np);
+    L.pair_ok = (uint8_t*)(base + 41 * Np);
+    L.pool_d = (float*)(base + 42 * Np);
+    L.pool_ij = (uint32_t*)(base + 42 * Np + 1024);
+    return L;
+}
+
+__device__ __forceinline__ Lds carve_psm(char* base, int Np)
+{
+    Lds L = {};
+    L.ref_r = (float*)base;
+    L.act_r = (float*)(base + 4 * Np);
+    L.pr = (float*)(base + 8 * Np);
+    L.pf = (float*)(base + 12 * Np);
+    L.key = (unsigned long long*)(base + 16 * Np);
+    L.new_r = (float*)(base + 24 * Np);
+    L.err = (float*)(base + 28 * Np);
+    L.ref_bad = (uint8_t*)(base + 32 * Np);
+    L.pair_ok = (uint8_t*)(base + 33 * Np);
+    L.new_bad = (uint8_t*)(base + 34 * Np);
+    return L;
+}
+
+constexpr unsigned long long KEY_INIT = 0xFFFFFFFFFFFFFFFFull;
+
+// key = ordered(range) << 32 | beam << 1 | occluded.  Smallest key = smallest
+// interpolated range, earliest beam among exact ties (the reference overwrites
+// only on strict '>', ZHPolar_Match.cpp:1443, so the first writer of the minimum wins).
+__device__ __forceinline__ unsigned long long make_key(float ri, int i, int occ)
+{
+    return ((unsigned long long)f_ord(ri) << 32) | (unsigned long long)((i << 1) | occ);
+}
+__device__ __forceinline__ float key_r(unsigned long long k) { return k == KEY_INIT ? 10000.0f : ord_f((uint32_t)(k >> 32)); }
+__device__ __forceinline__ int key_bad(unsigned long long k) { return k == KEY_INIT ? LSA_BAD_EMPTY : ((int)(k & 1) ? 8 : 0); }
+
+// ---------------------------------------------------------------------------
+// pm_scan_project (:1356-1479).  Pass 1 is per beam; pass 2 is a scatter-min of
+// the interpolated ranges onto the reference bearings, done with 64-bit LDS
+// atomic-min keys so that its outcome equals the sequential loop's.
+__device__ void scan_project(const DevParam& P, const Lds& L, float ax, float ay, float ath)
+{
+    const int N = P.n, lane = lane_id();
+    for (int i = lane; i < N; i += WAVE) {
+        float d = ath + P.fi[i];
+        float rr = L.act_r[i];
+        float x = rr * cosf_(d) + ax;
+        float y = rr * sinf_(d) + ay;
+        L.pr[i] = sqrtf(x * x + y * y);
+        float a = atan2f_(y, x);
+        if (x < 0 && y < 0) a = (float)((double)a + 2.0 * LSA_ZPI);
+        L.pf[i] = a;
+        L.key[i] = KEY_INIT;
+    }
+    __syncthreads();
+    for (int i = lane; i < N; i += WAVE) {
+        if (!L.pair_ok[i]) continue;
+        float fc = L.pf[i], fp = L.pf[i - 1];
+        if ((double)fabsf_(fc - fp) >= LSA_ZPI) continue;
+        float a0, a1, r0, r1;
+        int occ;
+        if (fc > fp) { occ = 0; a0 = fp; a1 = fc; r0 = L.pr[i - 1]; r1 = L.pr[i]; }
+        else         { occ = 1; a0 = fc; a1 = fp; r0 = L.pr[i]; r1 = L.pr[i - 1]; }
+        int j0 = (int)ceil((double)((a0 - P.fi_min) / P.dfi));
+        int j1 = (int)floor((double)((a1 - P.fi_min) / P.dfi));
+        if (j0 < 0) j0 = 0;                 // out-of-range bearings are never written (:1443)
+        if (j1 > N - 1) j1 = N - 1;
+        for (int j = j0; j <= j1; ++j) {
+            float ri = (r1 - r0) / (a1 - a0) * (((float)j * P.dfi + P.fi_min) - a0) + r0;
+            if (ri < 10000.0f) atomicMin(&L.key[j], make_key(ri, i, occ));
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// current-scan pose in the reference frame (:916-927, LASER_Y = 0)
+__device__ __forceinline__ void rel_pose(const float* ip, float& ax, float& ay, float& ath)
+{
+    if (ip == nullptr) { ax = 0; ay = 0; ath = 0; return; }
+    const float LY = 0;
+    float rx = ip[0], ry = ip[1], rth = ip[2], x = ip[3], y = ip[4], th = ip[5];
+    ax = sinf_(rth - th) * LY + cosf_(rth) * x + sinf_(rth) * y - sinf_(rth) * ry - rx * cosf_(rth);
+    ay = cosf_(rth - th) * LY - sinf_(rth) * x + cosf_(rth) * y - cosf_(rth) * ry + rx * sinf_(rth) - LY;
+    ath = th - rth;
+}
+
+// norm_a, ZHPolar_Match.h:77-87 (sic)
+__device__ __forceinline__ float norm_a(float a)
+{
+    int m = (int)((double)a / (2.0 * LSA_ZPI));
+    a = (float)((double)a - (double)(float)m * LSA_ZPI);
+    if ((double)a < -LSA_ZPI) a = (float)((double)a + 2.0 * LSA_ZPI);
+    if ((double)a >= LSA_ZPI) a = (float)((double)a - 2.0 * LSA_ZPI);
+    return a;
+}
+
+// point_line_distance, :2036-2056
+__device__ __forceinline__ float seg_foot(float x1, float y1, float x2, float y2, float x3, float y3,
+                                          float& fx, float& fy)
+{
+    float ax = x2 - x1, ay = y2 - y1;
+    float len = sqrtf(ax * ax + ay * ay);
+    if ((double)len < 0.0001) return -1.0f;
+    float t = -(-ax * x3 + ay * y1 + ax * x1 - ay * y3) / (ax * ax + ay * ay);
+    if (t < 0 || t > 1) return -1.0f;
+    fx = x1 + t * ax;
+    fy = y1 + t * ay;
+    return sqrtf((x3 - fx) * (x3 - fx) + (y3 - fy) * (y3 - fy));
+}
+
+// candidate reference-side point for the pair (cur i -> ref j), :1883-1917
+__device__ __forceinline__ float2 interp_candidate(const Lds& L, int N, int i, int j)
+{
+    float2 p = L.nxy[i];
+    float2 rj = L.ref_xy[j];
+    float d1 = -1.0f, d2 = -1.0f, f1x = 0, f1y = 0, f2x = 0, f2y = 0;
+    if (j > 0) { float2 a = L.ref_xy[j - 1]; d1 = seg_foot(a.x, a.y, rj.x, rj.y, p.x, p.y, f1x, f1y); }
+    if (j < N - 1) { float2 b = L.ref_xy[j + 1]; d2 = seg_foot(rj.x, rj.y, b.x, b.y, p.x, p.y, f2x, f2y); }
+    float2 out = rj;
+    float d0 = sqrtf((rj.x - p.x) * (rj.x - p.x) + (rj.y - p.y) * (rj.y - p.y));
+    if (d1 > 0 && d1 < d0) { out.x = f1x; out.y = f1y; d0 = d1; }
+    if (d2 > 0 && d2 < d0) { out.x = f2x; out.y = f2y; }
+    return out;
+}
+
+struct Rec { float d; uint32_t ij; };   // match record: distance, cur beam | ref beam << 16
+
+__device__ __forceinline__ Rec ld_rec(const unsigned long long* p)
+{
+    unsigned long long v = *p;
+    Rec r; r.d = u2f((uint32_t)v); r.ij = (uint32_t)(v >> 32);
+    return r;
+}
+__device__ __forceinline__ void st_rec(unsigned long long* p, Rec r)
+{
+    *p = (unsigned long long)f2u(r.d) | ((unsigned long long)r.ij << 32);
+}
+
+// ---------------------------------------------------------------------------
+// The partial bubble sort of :1836-1857 (`drop` passes, strict '<' swaps) is a
+// pipeline of `drop` stages that each carry their running maximum; its first
+// n-drop outputs are: out[t-drop] = min(pool U {a[t]}) where pool holds the `drop`
+// largest records seen so far, ties ordered by arrival.  The pool is kept sorted
+// (descending) in LDS; each step is a wave-parallel insert.  Only the kept prefix
+// is produced (the dropped tail is never read by the reference either).
+__device__ void trim_worst(const Lds& L, int n, int drop)
+{
+    const int lane = lane_id();
+    int psize = 0;
+    for (int t = 0; t < n; ++t) {
+        Rec x = ld_rec(&L.key[t]);
+        // p = number of pool records with d > x.d (a prefix of the sorted pool)
+        int p = 0;
+        float old_d[4]; uint32_t old_ij[4];
+        #pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            int s = lane + 64 * s4;
+            bool in = s < psize;
+            float pd = in ? L.pool_d[s] : 0.0f;
+            p += __popcll(__ballot(in && pd > x.d));
+            // value that would move into slot s on a right shift
+            old_d[s4] = (s >= 1 && s - 1 < psize) ? L.pool_d[s - 1] : 0.0f;
+            old_ij[s4] = (s >= 1 && s - 1 < psize) ? L.pool_ij[s - 1] : 0u;
+        }
+        if (psize >= drop && p == drop) {          // smaller than the whole pool: passes straight through
+            if (lane == 0) st_rec(&L.key[t - drop], x);
+            continue;
+        }
+        if (psize >= drop) {
+            if (lane == 0) { Rec e; e.d = L.pool_d[drop - 1]; e.ij = L.pool_ij[drop - 1]; st_rec(&L.key[t - drop], e); }
+        }
+        int new_size = psize < drop ? psize + 1 : drop;
+        #pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            int s = lane + 64 * s4;
+            if (s > p && s < new_size) { L.pool_d[s] = old_d[s4]; L.pool_ij[s] = old_ij[s4]; }
+            if (s == p) { L.pool_d[s] = x.d; L.pool_ij[s] = x.ij; }
+        }
+        psize = new_size;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// pm_error_index2 tail (:1311-1338) on the projection currently held in L.key.
+// Ordered sums by lanes 0 (x) and 1 (y).
+__device__ void error_index2_tail(const DevParam& P, const Lds& L, float* exy, int* n_assoc)
+{
+    const int N = P.n, lane = lane_id();
+    float acc = 0.0f;
+    int cnt = 0;
+    if (lane < 2) {
+        const float* tab = lane == 0 ? P.co : P.si;
+        for (int i = 0; i < N; ++i) {
+            unsigned long long k = L.key[i];
+            float rr = L.ref_r[i];
+            float delta = (float)((double)fabsf_(key_r(k) - rr) * 0.01);
+            if (key_bad(k) == 0 && L.ref_bad[i] == 0 && (double)delta < 50.0 && delta < 1.0f) {
+                float a = delta * tab[i];
+                acc += a * a;
+                cnt++;
+            }
+        }
+        float v = cnt > 0 ? acc / (float)cnt : u2f(0x7fc00000u);
+        if (exy) exy[lane] = v;
+        if (lane == 0 && n_assoc) *n_assoc = cnt;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// ICP kernel
+__global__ __launch_bounds__(64) void icp_kernel(
+    DevParam P, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
+    const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
+    const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
+    float* __restrict__ err_xy, int* __restrict__ n_assoc, int* __restrict__ status_out, int* __restrict__ iters_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = P.n, Np = (N + 63) & ~63, W = P.window, lane = lane_id();
+    const Lds L = carve_icp(smem, Np);
+
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const size_t ro = (size_t)ref_idx[b] * N, ao = (size_t)act_idx[b] * N;
+        __syncthreads();
+        for (int i = lane; i < N; i += WAVE) {
+            float rr = g_r[ro + i];
+            L.ref_xy[i] = make_float2(rr * P.co[i], rr * P.si[i]);      // :1710-1711
+            L.ref_bad[i] = g_bad[ro + i];
+            L.act_r[i] = g_r[ao + i];
+            uint8_t ok = 0;
+            if (i >= 1) {
+                uint16_t s1 = g_seg[ao + i], s0 = g_seg[ao + i - 1];
+                ok = (s1 != 0 && s1 == s0 && g_bad[ao + i] == 0 && g_bad[ao + i - 1] == 0) ? 1 : 0;   // :1396
+            }
+            L.pair_ok[i] = ok;
+            L.owner[i] = 0;
+        }
+        float ax, ay, ath;
+        rel_pose(init_pose ? init_pose + 6 * (size_t)b : nullptr, ax, ay, ath);
+        const float ax0 = init_pose ? init_pose[6 * (size_t)b + 3] : 0.0f;
+        const float ay0 = init_pose ? init_pose[6 * (size_t)b + 4] : 0.0f;
+        const float ath0 = init_pose ? init_pose[6 * (size_t)b + 5] : 0.0f;
+        float dx = 0, dy = 0, dth = 0;
+        int small = 0, status = LSA_ST_OK, n = 0, drop = 0, keep = 0;
+        __syncthreads();
+
+        int iter = -1;
+        while (++iter < LSA_ITER_ICP && small < 3) {
+            if (((double)(fabsf_(dx) + fabsf_(dy)) + (double)fabsf_(dth) * LSA_ZR2D) < LSA_STOP_ICP) small++;
+            else small = 0;                                                     // :1728
+
+            scan_project(P, L, ax, ay, ath);                                    // flags only, :1750
+
+            const float co = cosf_(ath), si = sinf_(ath);                       // :1753-1758
+            for (int i = lane; i < N; i += WAVE) {
+                float rr = L.act_r[i];
+                float cx = rr * P.co[i], cy = rr * P.si[i];                     // act.x/act.y, :1713-1714
+                L.nxy[i] = make_float2(cx * co - cy * si + ax, cx * si + cy * co + ay);
+            }
+            __syncthreads();
+
+            // nearest reference point inside [i-W, i+W), :1785-1810
+            for (int base = 0; base < N; base += WAVE) {
+                const int i = base + lane;
+                const bool live = i < N && key_bad(L.key[i < N ? i : 0]) == 0;
+                float best = 1000000.0f;
+                int bj = -1;
+                float2 p = L.nxy[i < N ? i : 0];
+                for (int o = -W; o < W; ++o) {
+                    int j = i + o;
+                    if (live && j >= 0 && j < N && L.ref_bad[j] == 0) {
+                        float2 rj = L.ref_xy[j];
+                        float ex = p.x - rj.x, ey = p.y - rj.y;
+                        float d = ex * ex + ey * ey;
+                        if (d < best) { best = d; bj = j; }
+                    }
+                }
+                if (i < N) {
+                    Rec r;
+                    float sd = sqrtf(best);
+                    r.d = (live && bj >= 0 && sd < LSA_MAX_ERROR) ? sd : -1.0f;   // :1811
+                    r.ij = (uint32_t)i | ((uint32_t)(bj < 0 ? 0 : bj) << 16);
+                    st_rec(&L.key[i], r);
+                }
+            }
+            __syncthreads();
+            // compaction in beam order (in place: destination index <= source index)
+            n = 0;
+            for (int base = 0; base < N; base += WAVE) {
+                const int i = base + lane;
+                Rec r; r.d = -1.0f; r.ij = 0;
+                if (i < N) r = ld_rec(&L.key[i]);
+                const bool ok = r.d >= 0.0f;
+                const unsigned long long mask = __ballot(ok);
+                if (ok) st_rec(&L.key[n + prefix_popc(mask)], r);
+                n += __popcll(mask);
+            }
+            __syncthreads();
+            if (n < P.min_valid) { status = LSA_ST_FEW_POINTS; break; }        // :1825-1832
+
+            drop = (int)((double)n * 0.2);                                      // :1836
+            keep = n - drop;
+            trim_worst(L, n, drop);
+            __syncthreads();
+
+            // reference-side interpolation, :1867-1926.  ix/iy are indexed by the
+            // reference beam and later pairs overwrite earlier ones: the pair with
+            // the largest list position owns the slot.
+            for (int k = lane; k < keep; k += WAVE) {
+                Rec r = ld_rec(&L.key[k]);
+                atomicMax(&L.owner[r.ij >> 16], (uint32_t)(k + 1));
+            }
+            __syncthreads();
+            for (int k = lane; k < keep; k += WAVE) {
+                Rec r = ld_rec(&L.key[k]);
+                const int i = r.ij & 0xffff, j = r.ij >> 16;
+                if (L.owner[j] == (uint32_t)(k + 1)) L.q[j] = interp_candidate(L, N, i, j);
+            }
+            __syncthreads();
+
+            // closed-form rigid fit, :1936-1986.  Four ordered sums side by side:
+            // lane 0: sum nx, lane 1: sum ny, lane 2: sum ix, lane 3: sum iy.
+            float mean = 0.0f;
+            if (lane < 4) {
+                const float* basep = lane < 2 ? (const float*)L.nxy : (const float*)L.q;
+                const int comp = lane & 1;
+                for (int k = 0; k < keep; ++k) {
+                    uint32_t ij = (uint32_t)(L.key[k] >> 32);
+                    int idx = lane < 2 ? (int)(ij & 0xffff) : (int)(ij >> 16);
+                    mean += basep[2 * idx + comp];
+                }
+                mean /= (float)keep;
+            }
+            const float mpx = __shfl(mean, 0), mpy = __shfl(mean, 1), mqx = __shfl(mean, 2), mqy = __shfl(mean, 3);
+            float cov = 0.0f;
+            if (lane < 4) {
+                // lane 0: sxx (nx,ix)  lane 1: sxy (nx,iy)  lane 2: syx (ny,ix)  lane 3: syy (ny,iy)
+                const int pc = lane >> 1, qc = lane & 1;
+                const float mp = pc ? mpy : mpx, mq = qc ? mqy : mqx;
+                const float* np_ = (const float*)L.nxy;
+                const float* qp_ = (const float*)L.q;
+                for (int k = 0; k < keep; ++k) {
+                    uint32_t ij = (uint32_t)(L.key[k] >> 32);
+                    float pv = np_[2 * (int)(ij & 0xffff) + pc], qv = qp_[2 * (int)(ij >> 16) + qc];
+                    cov += (pv - mp) * (qv - mq);
+                }
+            }
+            const float sxx = __shfl(cov, 0), sxy = __shfl(cov, 1), syx = __shfl(cov, 2), syy = __shfl(cov, 3);
+            dth = atan2f_(sxy - syx, sxx + syy);                                // :1984
+            dx = mqx - ax - (cosf_(dth) * (mpx - ax) - sinf_(dth) * (mpy - ay));
+            dy = mqy - ay - (sinf_(dth) * (mpx - ax) + cosf_(dth) * (mpy - ay));
+            ax += dx;
+            ay += dy;
+            ath += dth;
+            ath = norm_a(ath);
+
+            // release the owner slots for the next iteration
+            for (int k = lane; k < keep; k += WAVE) L.owner[(uint32_t)(L.key[k] >> 32) >> 16] = 0;
+            __syncthreads();
+        }
+
+        // :2012-2020.  The returned value averages the residuals of the first `drop`
+        // kept pairs of the last iteration, each against its own candidate point.
+        float ret = 0.0f;
+        if (status == LSA_ST_OK) {
+            if (lane == 0) {
+                float acc = 0.0f;
+                for (int k = 0; k < drop; ++k) {
+                    Rec r = ld_rec(&L.key[k]);
+                    const int i = r.ij & 0xffff, j = r.ij >> 16;
+                    float2 c = interp_candidate(L, N, i, j);
+                    float2 p = L.nxy[i];
+                    acc += sqrtf((p.x - c.x) * (p.x - c.x) + (p.y - c.y) * (p.y - c.y));
+                }
+                ret = acc / (float)drop;
+            }
+        }
+        if (lane == 0) {
+            const bool ok = status == LSA_ST_OK;
+            pose_out[3 * (size_t)b + 0] = ok ? ax : ax0;       // lsa untouched on throw
+            pose_out[3 * (size_t)b + 1] = ok ? ay : ay0;
+            pose_out[3 * (size_t)b + 2] = ok ? ath : ath0;
+            if (ret_out) ret_out[b] = ret;
+            if (status_out) status_out[b] = status;
+            if (iters_out) iters_out[b] = iter;
+        }
+        if (err_xy) {
+            __syncthreads();
+            if (status == LSA_ST_OK) {
+                // pm_error_index2 at the result (FMatch, :105): ref at the origin, cur at (ax,ay,ath)
+                for (int i = lane; i < N; i += WAVE) L.ref_r[i] = g_r[ro + i];   // ref_xy no longer needed
+                __syncthreads();
+                float ex, ey, eth;
+                if (init_pose) {
+                    float ip[6] = {init_pose[6 * (size_t)b], init_pose[6 * (size_t)b + 1], init_pose[6 * (size_t)b + 2], ax, ay, ath};
+                    rel_pose(ip, ex, ey, eth);
+                } else { ex = ax; ey = ay; eth = ath; }
+                scan_project(P, L, ex, ey, eth);
+                error_index2_tail(P, L, err_xy + 2 * (size_t)b, n_assoc ? n_assoc + b : nullptr);
+            } else if (lane < 2) {
+                err_xy[2 * (size_t)b + lane] = -1.0f;
+                if (lane == 0 && n_assoc) n_assoc[b] = 0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// PSM kernel.
+//   orientation search (:1152-1261): lane k accumulates the shift di = k - W in
+//   beam order (each lane owns whole shifts, so the order is the reference's);
+//   translation estimation (:1015-1131): the six ordered sums run in lanes 0..5.
+__global__ __launch_bounds__(64) void psm_kernel(
+    DevParam P, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
+    const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
+    const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
+    float* __restrict__ err_xy, int* __restrict__ n_assoc, int* __restrict__ status_out, int* __restrict__ iters_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = P.n, Np = (N + 63) & ~63, W = P.window, lane = lane_id();
+    const Lds L = carve_psm(smem, Np);
+    const int K = 2 * W + 1;                 // K <= Np is checked by the launcher
+    float* err = L.err;
+    // translation terms reuse the projection scratch (dead once new_r/new_bad are unpacked)
+    float* const term0 = L.pr; float* const term1 = L.pf;
+    float* const term2 = (float*)L.key; float* const term3 = (float*)L.key + Np;
+    float* const term4 = L.err; float* const term5 = L.new_r;
+
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const size_t ro = (size_t)ref_idx[b] * N, ao = (size_t)act_idx[b] * N;
+        __syncthreads();
+        for (int i = lane; i < N; i += WAVE) {
+            L.ref_r[i] = g_r[ro + i];
+            L.ref_bad[i] = g_bad[ro + i];
+            L.act_r[i] = g_r[ao + i];
+            uint8_t ok = 0;
+            if (i >= 1) {
+                uint16_t s1 = g_seg[ao + i], s0 = g_seg[ao + i - 1];
+                ok = (s1 != 0 && s1 == s0 && g_bad[ao + i] == 0 && g_bad[ao + i - 1] == 0) ? 1 : 0;
+            }
+            L.pair_ok[i] = ok;
+        }
+        float ax, ay, ath;
+        rel_pose(init_pose ? init_pose + 6 * (size_t)b : nullptr, ax, ay, ath);
+        const float ax0 = init_pose ? init_pose[6 * (size_t)b + 3] : 0.0f;
+        const float ay0 = init_pose ? init_pose[6 * (size_t)b + 4] : 0.0f;
+        const float ath0 = init_pose ? init_pose[6 * (size_t)b + 5] : 0.0f;
+        const float C = LSA_WEIGHT;
+        float dx = 0, dy = 0, dth = 0, avg = 100000000.0f;
+        int small = 0, status = LSA_ST_OK;
+        __syncthreads();
+
+        int iter = -1;
+        while (++iter < LSA_ITER_PSM && small < 3) {
+            if ((double)(fabsf_(dx) + fabsf_(dy) + fabsf_(dth)) < LSA_STOP_PSM) small++; else small = 0;   // :933
+
+            scan_project(P, L, ax, ay, ath);
+            // unpack the keys into new_r / new_bad (A region is free again)
+            for (int i = lane; i < N; i += WAVE) {
+                unsigned long long k = L.key[i];
+                L.new_r[i] = key_r(k);
+                L.new_bad[i] = (uint8_t)key_bad(k);
+            }
+            __syncthreads();
+
+            if ((iter & 1) == 0) {
+                // ---- orientation search ----
+                for (int k = lane; k < K; k += WAVE) {
+                    const int di = k - W;
+                    const int lo = di <= 0 ? -di : 0, hi = di <= 0 ? N : N - di;
+                    float e = 0.0f, cnt = 0.0f;
+                    for (int i = lo; i < hi; ++i) {
+                        float delta = fabsf_(L.new_r[i] - L.ref_r[i + di]);
+                        if (L.new_bad[i] == 0 && L.ref_bad[i + di] == 0) { e += delta; cnt += 1.0f; }
+                    }
+                    err[k] = cnt > 0.0f ? e / cnt : 10000.0f;
+                }
+                __syncthreads();
+                // first strict minimum (:1225-1234): wave arg-min on (err, k)
+                float bm = 100000.0f;
+                int bk = -1;
+                for (int k = lane; k < K; k += WAVE) {
+                    float e = err[k];
+                    if (e < bm) { bm = e; bk = k; }
+                }
+                for (int off = 32; off >= 1; off >>= 1) {
+                    float om = __shfl_xor(bm, off);
+                    int ok = __shfl_xor(bk, off);
+                    bool take = (ok >= 0) && (bk < 0 || om < bm || (om == bm && ok < bk));
+                    if (take) { bm = om; bk = ok; }
+                }
+                const int imin = bk;
+                if (imin < 0 || err[imin] >= 10000.0f) { status = LSA_ST_NO_ORIENT; break; }   // :1236-1240
+                dth = (float)(imin - W) * P.dfi;                                             // :1241
+                if (imin >= 1 && imin < K - 1) {
+                    const float em = err[imin - 1], e0 = err[imin], ep = err[imin + 1];
+                    float D = (float)((double)(em + ep) - 2.0 * (double)e0);
+                    float d = 10000.0f;
+                    if ((double)fabsf_(D) > 0.01 && em > e0 && ep > e0) d = (float)((double)((em - ep) / D) / 2.0);
+                    if (fabsf_(d) < 1.0f) dth += d * P.dfi;
+                }
+                ath += dth;
+                __syncthreads();
+                continue;
+            }
+
+            // ---- translation estimation ----
+            // per-beam terms in parallel (zero when the beam is gated out: adding
+            // +0.0f leaves an ordered FP32 sum unchanged), then six ordered sums.
+            int cnt = 0;
+            for (int base = 0; base < N; base += WAVE) {
+                const int i = base + lane;
+                bool ok = false;
+                if (i < N) {
+                    float nr = L.new_r[i];
+                    float dr = L.ref_r[i] - nr;
+                    ok = L.ref_bad[i] == 0 && L.new_bad[i] == 0 && nr < (float)P.max_range &&
+                         nr > LSA_MIN_RANGE && fabsf_(dr) < LSA_MAX_ERROR;                 // :1034
+                    float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+                    if (ok) {
+                        float w = C / (dr * dr + C);
+                        float c = P.co[i], s = P.si[i];
+                        float wc = c * w, ws = s * w;
+                        t0 = wc * dr; t1 = ws * dr; t2 = wc * c; t3 = wc * s; t4 = ws * s;
+                    }
+                    term0[i] = t0; term1[i] = t1; term2[i] = t2;
+                    term3[i] = t3; term4[i] = t4; term5[i] = fabsf_(dr);
+                }
+                cnt += __popcll(__ballot(ok));
+            }
+            __syncthreads();
+            float acc = 0.0f;
+            if (lane < 6) {
+                const float* tp = lane == 0 ? term0 : lane == 1 ? term1 : lane == 2 ? term2
+                                : lane == 3 ? term3 : lane == 4 ? term4 : term5;
+                for (int i = 0; i < N; ++i) acc += tp[i];
+            }
+            const float hw1 = __shfl(acc, 0), hw2 = __shfl(acc, 1), h11 = __shfl(acc, 2),
+                        h12 = __shfl(acc, 3), h22 = __shfl(acc, 4), abs_err = __shfl(acc, 5);
+            __syncthreads();
+            if (cnt < P.min_valid) { status = LSA_ST_FEW_POINTS; break; }                  // :1089
+            const float D = h11 * h22 - h12 * 0.0f;                                         // :1102 (hwh21 == 0)
+            if ((double)D < 0.001) { status = LSA_ST_SINGULAR; break; }                    // :1103
+            const float i11 = h22 / D, i12 = -h12 / D, i21 = -h12 / D, i22 = h11 / D;
+            dx = i11 * hw1 + i12 * hw2;
+            dy = i21 * hw1 + i22 * hw2;
+            avg = abs_err / (float)cnt;
+            ax += dx;
+            ay += dy;
+        }
+
+        if (lane == 0) {
+            const bool ok = status == LSA_ST_OK;
+            pose_out[3 * (size_t)b + 0] = ok ? ax : ax0;
+            pose_out[3 * (size_t)b + 1] = ok ? ay : ay0;
+            pose_out[3 * (size_t)b + 2] = ok ? ath : ath0;
+            if (ret_out) ret_out[b] = ok ? avg : 0.0f;
+            if (status_out) status_out[b] = status;
+            if (iters_out) iters_out[b] = iter;
+        }
+        if (err_xy) {
+            __syncthreads();
+            if (status == LSA_ST_OK) {
+                float ex, ey, eth;
+                if (init_pose) {
+                    float ip[6] = {init_pose[6 * (size_t)b], init_pose[6 * (size_t)b + 1], init_pose[6 * (size_t)b + 2], ax, ay, ath};
+                    rel_pose(ip, ex, ey, eth);
+                } else { ex = ax; ey = ay; eth = ath; }
+                scan_project(P, L, ex, ey, eth);
+                error_index2_tail(P, L, err_xy + 2 * (size_t)b, n_assoc ? n_assoc + b : nullptr);
+            } else if (lane < 2) {
+                err_xy[2 * (size_t)b + lane] = -1.0f;
+                if (lane == 0 && n_assoc) n_assoc[b] = 0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Stand-alone pm_error_index2 (:1279-1339), one wave per pair, at the poses given
+// in init_pose [B][6] (NULL = both at the origin).
+__global__ __launch_bounds__(64) void error_index_kernel(
+    DevParam P, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
+    const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
+    const float* __restrict__ init_pose, float* __restrict__ err_xy, int* __restrict__ n_assoc)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = P.n, Np = (N + 63) & ~63, lane = lane_id();
+    const Lds L = carve_psm(smem, Np);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const size_t ro = (size_t)ref_idx[b] * N, ao = (size_t)act_idx[b] * N;
+        __syncthreads();
+        for (int i = lane; i < N; i += WAVE) {
+            L.ref_r[i] = g_r[ro + i];
+            L.ref_bad[i] = g_bad[ro + i];
+            L.act_r[i] = g_r[ao + i];
+            uint8_t ok = 0;
+            if (i >= 1) {
+                uint16_t s1 = g_seg[ao + i], s0 = g_seg[ao + i - 1];
+                ok = (s1 != 0 && s1 == s0 && g_bad[ao + i] == 0 && g_bad[ao + i - 1] == 0) ? 1 : 0;
+            }
+            L.pair_ok[i] = ok;
+        }
+        float ax, ay, ath;
+        rel_pose(init_pose ? init_pose + 6 * (size_t)b : nullptr, ax, ay, ath);
+        __syncthreads();
+        scan_project(P, L, ax, ay, ath);
+        error_index2_tail(P, L, err_xy + 2 * (size_t)b, n_assoc ? n_assoc + b : nullptr);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Stand-alone projection (public pm_scan_project), one wave per scan.
+__global__ __launch_bounds__(64) void project_kernel(
+    DevParam P, int S, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
+    const uint16_t* __restrict__ g_seg, const float* __restrict__ pose,
+    float* __restrict__ new_r, uint8_t* __restrict__ new_bad)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = P.n, Np = (N + 63) & ~63, lane = lane_id();
+    const Lds L = carve_psm(smem, Np);
+    for (int s = blockIdx.x; s < S; s += gridDim.x) {
+        const size_t so = (size_t)s * N;
+        __syncthreads();
+        for (int i = lane; i < N; i += WAVE) {
+            L.act_r[i] = g_r[so + i];
+            uint8_t ok = 0;
+            if (i >= 1) {
+                uint16_t s1 = g_seg[so + i], s0 = g_seg[so + i - 1];
+                ok = (s1 != 0 && s1 == s0 && g_bad[so + i] == 0 && g_bad[so + i - 1] == 0) ? 1 : 0;
+            }
+            L.pair_ok[i] = ok;
+        }
+        __syncthreads();
+        scan_project(P, L, pose[3 * s], pose[3 * s + 1], pose[3 * s + 2]);
+        for (int i = lane; i < N; i += WAVE) {
+            unsigned long long k = L.key[i];
+            new_r[so + i] = key_r(k);
+            new_bad[so + i] = (uint8_t)key_bad(k);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// pm_preprocessScan (:861-866): median (:1610) -> far (:1583) -> segment (:1495).
+// The median filter writes back into the array it reads and the segmentation is
+// a run-length state machine: both are recurrences along the beam index, so one
+// lane walks the scan (staged in LDS); the far test is per beam.
+__global__ __launch_bounds__(64) void preprocess_kernel(
+    DevParam P, int S, float* __restrict__ g_r, uint8_t* __restrict__ g_bad, uint16_t* __restrict__ g_seg)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = P.n, Np = (N + 63) & ~63, lane = lane_id();
+    float* r = (float*)smem;
+    int* bad = (int*)(smem + 4 * Np);
+    int* seg = (int*)(smem + 8 * Np);
+    for (int s = blockIdx.x; s < S; s += gridDim.x) {
+        const size_t so = (size_t)s * N;
+        __syncthreads();
+        for (int i = lane; i < N; i += WAVE) { r[i] = g_r[so + i]; bad[i] = g_bad[so + i]; seg[i] = 0; }
+        __syncthreads();
+        if (lane == 0) {
+            for (int i = 0; i < N; ++i) {
+                float w[5];
+                #pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    int j = i - 2 + t;
+                    j = j < 0 ? 0 : (j > N - 1 ? N - 1 : j);
+                    w[t] = r[j];
+                }
+                #pragma unroll
+                for (int hi = 4; hi > 0; --hi)
+                    #pragma unroll
+                    for (int k = 0; k < hi; ++k)
+                        if (w[k] > w[k + 1]) { float sw = w[k]; w[k] = w[k + 1]; w[k + 1] = sw; }
+                r[i] = w[2];
+            }
+        }
+        __syncthreads();
+        for (int i = lane; i < N; i += WAVE)
+            if (r[i] > (float)P.max_range) bad[i] |= 1;
+        __syncthreads();
+        if (lane == 0) {
+            const float lim = LSA_SEG_MAX_DIST;
+            int id = 1, run;
+            if (fabsf_(r[0] - r[1]) < lim) { seg[0] = id; seg[1] = id; run = 2; }
+            else                           { seg[0] = 0;  seg[1] = id; run = 1; }
+            for (int i = 2; i < N; ++i) {
+                bool brk = false;
+                if (bad[i]) { brk = true; seg[i] = 0; }
+                else {
+                    float ex = (float)((double)r[i] - (2.0 * (double)r[i - 1] - (double)r[i - 2]));
+                    if (fabsf_(r[i] - r[i - 1]) < lim || (seg[i - 1] == seg[i - 2] && fabsf_(ex) < lim)) { run++; seg[i] = id; }
+                    else brk = true;
+                }
+                if (!brk) continue;
+                if (run == 1) {
+                    float ex = (float)((double)r[i] - (2.0 * (double)r[i - 1] - (double)r[i - 2]));
+                    if (seg[i - 2] == 0 && bad[i] == 0 && bad[i - 1] == 0 && bad[i - 2] == 0 && fabsf_(ex) < lim) {
+                        seg[i] = id; seg[i - 1] = id; seg[i - 2] = id; run = 3;
+                    } else { seg[i - 1] = 0; seg[i] = id; run = 1; }
+                } else { id++; seg[i] = id; run = 1; }
+            }
+        }
+        __syncthreads();
+        for (int i = lane; i < N; i += WAVE) {
+            g_r[so + i] = r[i];
+            g_bad[so + i] = (uint8_t)bad[i];
+            g_seg[so + i] = (uint16_t)seg[i];
+        }
+    }
+}
+
+} // namespace lsa

@@ -1,0 +1,266 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors and the
+CPU oracle on identical inputs.  Bars: bit-exact for flags / segments / indices /
+grid counts; poses within 1e-4 m (= 1e-2 cm in the matcher's cm units) and
+1e-4 rad as north_star states — in practice the kernels reproduce the reference
+bit for bit and the tests report how many pairs are bit-identical."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, SETS, golden_param, load, same_bits
+
+pytestmark = pytest.mark.gpu
+
+TOL_CM = 1e-2     # 1e-4 m
+TOL_RAD = 1e-4
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def make_ctx(name, g):
+    from laser_slam_amd import capi, synth
+    laser = SETS[name][0]
+    p = capi.param_preset(laser) if laser else capi.param_make(**{k: v for k, v in synth.SYN1081.items()})
+    gp = golden_param(g)
+    p.fi_min = float(np.float32(gp["fi_min"]))
+    p.fi_max = float(np.float32(gp["fi_max"]))
+    p.max_range = int(gp["max_range"])
+    return capi.Context(p), p
+
+
+def dev(torch, a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a).astype(dtype)).cuda()
+
+
+def run_match(torch, ctx, which, r, bad, seg, ref_idx, act_idx, init=None, want_err=True):
+    from laser_slam_amd import capi  # noqa: F401
+    B = len(ref_idx)
+    d_r = dev(torch, r, np.float32); d_bad = dev(torch, bad, np.uint8); d_seg = dev(torch, seg, np.int16)
+    d_ri = dev(torch, ref_idx, np.int32); d_ai = dev(torch, act_idx, np.int32)
+    d_init = None if init is None else dev(torch, init, np.float32)
+    pose = torch.zeros(B, 3, dtype=torch.float32, device="cuda")
+    ret = torch.zeros(B, dtype=torch.float32, device="cuda")
+    exy = torch.zeros(B, 2, dtype=torch.float32, device="cuda") if want_err else None
+    na = torch.zeros(B, dtype=torch.int32, device="cuda") if want_err else None
+    st = torch.zeros(B, dtype=torch.int32, device="cuda")
+    it = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ctx.match_batch(which, B, d_r, d_bad, d_seg, d_ri, d_ai, pose, d_init, ret, exy, na, st, it)
+    ctx.sync()
+    out = dict(pose=pose.cpu().numpy(), ret=ret.cpu().numpy(), status=st.cpu().numpy(), iters=it.cpu().numpy())
+    if want_err:
+        out.update(exy=exy.cpu().numpy(), nassoc=na.cpu().numpy())
+    return out
+
+
+def pose_close(a, b):
+    return (np.abs(a[:, :2] - b[:, :2]).max(axis=1) <= TOL_CM) & (np.abs(a[:, 2] - b[:, 2]) <= TOL_RAD)
+
+
+@pytest.mark.parametrize("name", list(SETS))
+def test_tables_match_reference(name, torch_mod):
+    from laser_slam_amd import capi
+    g = load(name)
+    ctx, p = make_ctx(name, g)
+    if "tab_fi" in g:
+        fi, si, co = capi.param_tables(p)
+        assert same_bits(fi, g["tab_fi"]) and same_bits(si, g["tab_si"]) and same_bits(co, g["tab_co"])
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", list(SETS))
+def test_preprocess(name, torch_mod):
+    torch = torch_mod
+    g = load(name)
+    ctx, _ = make_ctx(name, g)
+    S = g["raw_r"].shape[0]
+    d_r = dev(torch, g["raw_r"], np.float32); d_bad = dev(torch, g["raw_bad"], np.uint8)
+    d_seg = torch.zeros(g["raw_r"].shape, dtype=torch.int16, device="cuda")
+    ctx.preprocess_batch(S, d_r, d_bad, d_seg)
+    ctx.sync()
+    assert same_bits(d_r.cpu().numpy(), g["pre_r"])
+    assert np.array_equal(d_bad.cpu().numpy().astype(np.int32), g["pre_bad"])
+    assert np.array_equal(d_seg.cpu().numpy().astype(np.int32), g["pre_seg"])
+    # host single-scan entry point
+    r, bad, seg = ctx.preprocess_host(g["raw_r"][1], g["raw_bad"][1])
+    assert same_bits(r, g["pre_r"][1]) and np.array_equal(bad, g["pre_bad"][1]) and np.array_equal(seg, g["pre_seg"][1])
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", list(SETS))
+def test_scan_project(name, torch_mod):
+    torch = torch_mod
+    g = load(name)
+    ctx, _ = make_ctx(name, g)
+    idx = g["stage_idx"]
+    d_r = dev(torch, g["pre_r"][idx], np.float32); d_bad = dev(torch, g["pre_bad"][idx], np.uint8)
+    d_seg = dev(torch, g["pre_seg"][idx], np.int16); d_pose = dev(torch, g["stage_pose"], np.float32)
+    nr = torch.zeros(d_r.shape, dtype=torch.float32, device="cuda")
+    nb = torch.zeros(d_r.shape, dtype=torch.uint8, device="cuda")
+    ctx.scan_project_batch(len(idx), d_r, d_bad, d_seg, d_pose, nr, nb)
+    ctx.sync()
+    assert same_bits(nr.cpu().numpy(), g["stage_new_r"])
+    assert np.array_equal(nb.cpu().numpy().astype(np.int32), g["stage_new_bad"])
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", list(SETS))
+@pytest.mark.parametrize("which", [0, 1])
+def test_match_vs_golden(name, which, torch_mod):
+    torch = torch_mod
+    g = load(name)
+    ctx, _ = make_ctx(name, g)
+    nm = "psm" if which == 0 else "icp"
+    S = g["pre_r"].shape[0]
+    ref_idx = np.arange(S - 1); act_idx = ref_idx + 1
+    out = run_match(torch, ctx, which, g["pre_r"], g["pre_bad"], g["pre_seg"], ref_idx, act_idx)
+    assert np.array_equal(out["status"] != 0, g[nm + "_status"] != 0)
+    ok = g[nm + "_status"] == 0
+    close = pose_close(out["pose"], g[nm + "_pose"])
+    exact = np.array([same_bits(out["pose"][b], g[nm + "_pose"][b]) for b in range(S - 1)])
+    print("%s %s: %d/%d pairs bit-identical, %d within tolerance" % (name, nm, exact.sum(), S - 1, close.sum()))
+    assert close.all(), np.nonzero(~close)[0]
+    assert exact.all(), np.nonzero(~exact)[0]          # the design target is bit-faithful FP32
+    assert same_bits(out["ret"][ok], g[nm + "_ret"][ok])
+    assert np.array_equal(out["nassoc"][ok], g[nm + "_nassoc"][ok])
+    has = ok & (g[nm + "_nassoc"] > 0)
+    assert same_bits(out["exy"][has], g[nm + "_exy"][has])
+    # failed pairs report (-1,-1) like FMatch
+    assert np.all(out["exy"][~ok] == -1.0)
+    # non-zero initial poses
+    K = g["init_pose"].shape[0]
+    out = run_match(torch, ctx, which, g["pre_r"], g["pre_bad"], g["pre_seg"], ref_idx[:K], act_idx[:K],
+                    init=g["init_pose"], want_err=False)
+    assert np.array_equal(out["status"] != 0, g[nm + "_init_status"] != 0)
+    assert same_bits(out["pose"], g[nm + "_init_pose_out"])
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["mit", "syn1081"])
+def test_match_vs_oracle_shuffled_pairs(name, torch_mod):
+    """Pairs that are NOT consecutive (harder, more failures) against the CPU oracle."""
+    torch = torch_mod
+    from oracle_lib import SYN1081, Oracle
+    g = load(name)
+    ctx, p = make_ctx(name, g)
+    laser = SETS[name][0]
+    o = Oracle(laser) if laser else Oracle(**SYN1081)
+    o.set_fimin_maxrange(np.float32(p.fi_min), p.max_range)
+    S = g["pre_r"].shape[0]
+    rng = np.random.default_rng(7)
+    B = 48
+    ref_idx = rng.integers(0, S, B); act_idx = np.clip(ref_idx + rng.integers(-4, 5, B), 0, S - 1)
+    r = np.ascontiguousarray(g["pre_r"]); bad = np.ascontiguousarray(g["pre_bad"]); seg = np.ascontiguousarray(g["pre_seg"])
+    for which in (0, 1):
+        out = run_match(torch, ctx, which, r, bad, seg, ref_idx, act_idx, want_err=False)
+        pose_o, st_o = o.match_batch(which, r, bad, seg, ref_idx, act_idx)
+        assert np.array_equal(out["status"], st_o)
+        assert same_bits(out["pose"], pose_o)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["mit", "intel", "syn1081"])
+def test_fmatch_chain_host_api(name, torch_mod):
+    g = load(name)
+    ctx, _ = make_ctx(name, g)
+    n = g["raw_r"].shape[1]
+    cur = [g["raw_r"][0].copy(), g["raw_bad"][0].copy(), np.zeros(n, np.int32)]
+    B = min(20, g["fmatch_pose"].shape[0])
+    for b in range(B):
+        act = [g["raw_r"][b + 1].copy(), g["raw_bad"][b + 1].copy(), np.zeros(n, np.int32)]
+        pose, pair, r2, a2 = ctx.fmatch_host(cur, act, b == 0)
+        assert same_bits(pose, g["fmatch_pose"][b]), b
+        assert same_bits(pair, g["fmatch_pair"][b]), (b, pair, g["fmatch_pair"][b])
+        assert same_bits(a2[0], g["pre_r"][b + 1]) and np.array_equal(a2[2], g["pre_seg"][b + 1])
+        cur = a2
+    # single-pair host matcher + error index
+    ref = (g["pre_r"][0], g["pre_bad"][0], g["pre_seg"][0]); act = (g["pre_r"][1], g["pre_bad"][1], g["pre_seg"][1])
+    for which, nm in ((0, "psm"), (1, "icp")):
+        st, pose, ret = ctx.match_host(which, ref, act)
+        assert st == g[nm + "_status"][0] and same_bits(pose, g[nm + "_pose"][0])
+        if st == 0:
+            exy, na = ctx.error_index2_host(ref, act, (0, 0, 0), pose)
+            assert na == g[nm + "_nassoc"][0] and same_bits(exy, g[nm + "_exy"][0])
+    ctx.close()
+
+
+def test_failure_status_codes(torch_mod):
+    """Empty / featureless scans must fail like the reference's `throw 1` paths."""
+    torch = torch_mod
+    from laser_slam_amd import capi
+    p = capi.param_preset("LMS511")
+    ctx = capi.Context(p)
+    n = p.points
+    r = np.full((2, n), p.max_range + 1, np.float32)          # nothing in range
+    d_r = dev(torch, r, np.float32); d_bad = torch.zeros(2, n, dtype=torch.uint8, device="cuda")
+    d_seg = torch.zeros(2, n, dtype=torch.int16, device="cuda")
+    ctx.preprocess_batch(2, d_r, d_bad, d_seg)
+    out_p = run_match(torch, ctx, 0, d_r.cpu().numpy(), d_bad.cpu().numpy(), d_seg.cpu().numpy(), [0], [1])
+    out_i = run_match(torch, ctx, 1, d_r.cpu().numpy(), d_bad.cpu().numpy(), d_seg.cpu().numpy(), [0], [1])
+    assert out_p["status"][0] == capi.ST_NO_ORIENT
+    assert out_i["status"][0] == capi.ST_FEW_POINTS
+    assert np.all(out_p["pose"] == 0) and np.all(out_i["pose"] == 0)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["mit", "fr079"])
+def test_grid_vs_golden(name, torch_mod):
+    torch = torch_mod
+    from laser_slam_amd import capi
+    z = np.load(os.path.join(GOLDEN, "pmap_%s.npz" % name))
+    G = z["geom"]
+    ctx = capi.Context(capi.param_preset("LMS511"))
+    grid = capi.Grid(ctx, int(G[0]), int(G[1]), int(G[2]), int(G[3]), float(G[4]), float(G[5]), float(G[6]))
+    S, nb = z["gx"].shape
+    # batched device path
+    grid.update_batch(S, nb, dev(torch, z["gx"], np.float32), dev(torch, z["gy"], np.float32),
+                      dev(torch, z["robot"][:, :2], np.float32), dev(torch, z["robot"][:, 2], np.int32))
+    grid.compute_prob()
+    hit, sm, prob = grid.layers()
+    assert np.array_equal(hit, z["hit"].astype(np.float32))
+    assert np.array_equal(sm, z["sum"].astype(np.float32))
+    assert same_bits(prob, z["prob"])
+    cx, cy = grid.cloud(0.95)
+    assert same_bits(cx, z["cloud_x"]) and same_bits(cy, z["cloud_y"])
+    # host one-scan-at-a-time path (CPMap::updateMap signature)
+    grid.clear()
+    for k in range(S):
+        nv = int(z["robot"][k, 2])
+        grid.update_host(z["gx"][k, :nv], z["gy"][k, :nv], float(z["robot"][k, 0]), float(z["robot"][k, 1]))
+    hit2, sm2, _ = grid.layers()
+    assert np.array_equal(hit2, hit) and np.array_equal(sm2, sm)
+    grid.close(); ctx.close()
+
+
+def test_grid_vs_oracle_random(torch_mod):
+    """Random rays incl. out-of-map endpoints, degenerate rays, negative coordinates."""
+    torch = torch_mod
+    from laser_slam_amd import capi
+    from oracle_lib import OraclePMap
+    rng = np.random.default_rng(3)
+    sx, sy, cx, cy, offx, offy, res = 300, 200, 120, 70, 1.25, -2.5, 0.05
+    ctx = capi.Context(capi.param_preset("LMS211"))
+    grid = capi.Grid(ctx, sx, sy, cx, cy, offx, offy, res)
+    o = OraclePMap(sx, sy, cx, cy, offx, offy, res)
+    S, nb = 24, 181
+    gx = np.zeros((S, nb), np.float32); gy = np.zeros((S, nb), np.float32); rob = np.zeros((S, 2), np.float32)
+    for s in range(S):
+        rob[s] = rng.uniform(-4, 8, 2)
+        ang = rng.uniform(0, 2 * np.pi, nb); d = rng.uniform(0, 12, nb)
+        gx[s] = rob[s, 0] + d * np.cos(ang); gy[s] = rob[s, 1] + d * np.sin(ang)
+        if s == 3:
+            gx[s] = rob[s, 0]; gy[s] = rob[s, 1]          # all rays degenerate
+        o.update(gx[s], gy[s], float(rob[s, 0]), float(rob[s, 1]))
+    grid.update_batch(S, nb, dev(torch, gx, np.float32), dev(torch, gy, np.float32), dev(torch, rob, np.float32))
+    grid.compute_prob(); o.compute()
+    for a, b in zip(grid.layers(), o.layers()):
+        assert same_bits(a, b)
+    for _ in range(200):
+        px, py = [float(np.float32(v)) for v in rng.uniform(-9, 9, 2)]
+        assert grid.cell(px, py) == o.cell(px, py)
+    grid.close(); ctx.close()
