@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Headline benchmark: scan-matches/s on synthetic 1081-beam scans (BASELINE.json).
+
+A "step" = one batch of `--pairs` scan-pair matches (pm_icp, the matcher behind the
+reference's FMatch front door) over a device-resident, already preprocessed scan set.
+Inputs are in HBM before the timed region.  With N ranks (torch.distributed / RCCL)
+each rank matches its own batch (independent pairs -> no data-path collective, weak
+scaling); value = all pairs of all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with the contract's fields plus `roofline`
+(dominant kernel = icp_kernel, algorithmic bytes per SURVEY.md §8d) and
+`cpu_baseline` (the reference built in place when oracle/_ref travelled, else the
+oracle port; bounded sample on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_PAIR = 2 * 1081 * 4 + 12 + 20      # 8 680 B per 1081-beam pair
+HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3
+
+
+def build_scan_set(n_scans, seeds):
+    from laser_slam_amd import synth
+    sets = [synth.make_scans(n_scans, noise_seed=synth.WORLD_SEED + j)[0] for j in range(seeds)]
+    return np.concatenate(sets, 0)
+
+
+def cpu_baseline(raw, n_pairs, which):
+    """Time the CPU path on a bounded sample of the same workload (rank 0 only)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from laser_slam_amd import synth
+    use_ref = oracle_lib.have_ref()
+    eng = oracle_lib.Ref(**synth.SYN1081) if use_ref else oracle_lib.Oracle(**synth.SYN1081)
+    pre = [eng.preprocess(raw[k]) for k in range(n_pairs + 1)]
+    t0 = time.perf_counter()
+    ok = 0
+    for b in range(n_pairs):
+        res = eng.match(which, pre[b], pre[b + 1])
+        ok += res[0] == 0
+    dt = time.perf_counter() - t0
+    return {"value": n_pairs / dt, "unit": "scan-matches/s", "cores": 1,
+            "kind": "reference" if use_ref else "port",
+            "sample": "%d consecutive synthetic 1081-beam pairs, pm_icp, single thread, preprocessing excluded (%.1f s)"
+                      % (n_pairs, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=32768, help="scan pairs per step per GPU")
+    ap.add_argument("--matcher", default="icp", choices=["icp", "psm"])
+    ap.add_argument("--cpu-pairs", type=int, default=400)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--extras", action="store_true", help="also time PSM, preprocess and grid update")
+    args = ap.parse_args()
+
+    import torch
+    from laser_slam_amd import capi, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev_index = torch.cuda.current_device()
+
+    # ---- workload: synthetic 1081-beam scans, consecutive pairs, zero initial guess ----
+    n_base, seeds = 200, 8
+    raw = build_scan_set(n_base, seeds)                       # [1600][1081]
+    S, n = raw.shape
+    p = capi.param_make(**synth.SYN1081)
+    ctx = capi.Context(p, dev_index)
+    # launch on a torch-owned (non-default) stream so that torch.cuda.Event brackets the kernels
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
+    d_r = torch.from_numpy(raw).cuda()
+    d_bad = torch.zeros(S, n, dtype=torch.uint8, device="cuda")
+    d_seg = torch.zeros(S, n, dtype=torch.int16, device="cuda")
+    ctx.preprocess_batch(S, d_r, d_bad, d_seg)
+    # pairs (k-1, k) inside each seed's run, tiled up to the batch size; each rank takes a
+    # different rotation so ranks do not match identical pairs
+    base_pairs = np.array([(s * n_base + k - 1, s * n_base + k) for s in range(seeds) for k in range(1, n_base)], np.int32)
+    B = args.pairs
+    sel = (np.arange(B) + rank * 7919) % len(base_pairs)
+    d_ri = torch.from_numpy(np.ascontiguousarray(base_pairs[sel, 0])).cuda()
+    d_ai = torch.from_numpy(np.ascontiguousarray(base_pairs[sel, 1])).cuda()
+    pose = torch.zeros(B, 3, device="cuda")
+    st = torch.zeros(B, dtype=torch.int32, device="cuda")
+    it = torch.zeros(B, dtype=torch.int32, device="cuda")
+    which = capi.MATCH_ICP if args.matcher == "icp" else capi.MATCH_PSM
+
+    def step():
+        ctx.match_batch(which, B, d_r, d_bad, d_seg, d_ri, d_ai, pose, d_status=st, d_iters=it)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        step()
+        ev[k][1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    mean_iters = float(it.float().mean().item())
+    fail_frac = float((st != 0).float().mean().item())
+    total_pairs = B * args.steps * world
+    value = total_pairs / elapsed
+
+    out = None
+    if rank == 0:
+        achieved = BYTES_PER_PAIR * B / (kernel_ms * 1e-3) / 1e9
+        W = p.window
+        flops_pair = mean_iters * (n * 2 * W * 6 + 60 * n) if which == capi.MATCH_ICP else \
+            mean_iters / 2 * ((2 * W + 1) * n * 3) + mean_iters * 60 * n
+        out = {
+            "metric": "scan-matches/sec (1081-beam)", "value": value, "unit": "scan-matches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic 1081-beam scans (270 deg, W=200), consecutive pairs, zero initial guess, "
+                                   "pm_%s batched one wave per pair" % args.matcher,
+                       "pairs_per_step_per_gpu": B, "beams": n, "matcher": "pm_" + args.matcher,
+                       "mean_iterations": mean_iters, "failed_fraction": fail_frac, "parallelism": "pairs sharded x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "%s_kernel" % args.matcher, "kernel_ms": kernel_ms,
+                         "bytes_per_pair": BYTES_PER_PAIR,
+                         "note": "matcher is VALU/LDS-bound (SURVEY 8d): fp32_vector_frac is the meaningful ceiling",
+                         "fp32_vector_frac": flops_pair * B / (kernel_ms * 1e-3) / (FP32_PEAK_TFLOPS * 1e12),
+                         "flops_per_pair_model": flops_pair},
+        }
+        if args.extras:
+            out["extras"] = extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p)
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(raw, args.cpu_pairs, 1 if which == capi.MATCH_ICP else 0)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p):
+    """Secondary kernels of the path, timed the same way (not the headline)."""
+    from laser_slam_amd import synth
+    res = {}
+    pose = torch.zeros(B, 3, device="cuda")
+
+    def timed(fn, reps=3):
+        fn(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    ms = timed(lambda: ctx.match_batch(capi.MATCH_PSM, B, d_r, d_bad, d_seg, d_ri, d_ai, pose))
+    res["pm_psm_matches_per_s"] = B / (ms * 1e-3)
+    S, n = raw.shape
+    r2 = torch.from_numpy(raw).cuda(); b2 = torch.zeros_like(d_bad); s2 = torch.zeros_like(d_seg)
+    ms = timed(lambda: ctx.preprocess_batch(S, r2, b2, s2), reps=1)
+    res["preprocess_scans_per_s"] = S / (ms * 1e-3)
+    # grid update: 4096^2 @ 5 cm, scans inserted at their true poses
+    fi = capi.param_tables(p)[0]
+    nb = 256
+    _, poses = synth.make_scans(1)
+    poses = synth.path_pose(np.arange(nb))
+    rr = raw[:nb] / 100.0
+    gx = (poses[:, 0:1] + rr * np.cos(poses[:, 2:3] + fi[None])).astype(np.float32)
+    gy = (poses[:, 1:2] + rr * np.sin(poses[:, 2:3] + fi[None])).astype(np.float32)
+    grid = capi.Grid(ctx, 4096, 4096, 1024, 1024, 0.0, 0.0, 0.05)
+    dgx, dgy = torch.from_numpy(gx).cuda(), torch.from_numpy(gy).cuda()
+    drob = torch.from_numpy(poses[:, :2].astype(np.float32)).cuda()
+    ms = timed(lambda: grid.update_batch(nb, n, dgx, dgy, drob), reps=2)
+    cells = float(np.mean(np.maximum(np.abs(gx - poses[:, 0:1]), np.abs(gy - poses[:, 1:2])) / 0.05)) + 1
+    res["grid_update_scans_per_s"] = nb / (ms * 1e-3)
+    res["grid_update_cells_per_s"] = nb * n * cells / (ms * 1e-3)
+    res["grid_update_GBps_algorithmic"] = nb * n * (cells * 8 + 16) / (ms * 1e-3) / 1e9
+    ms = timed(lambda: grid.compute_prob(), reps=3)
+    res["grid_prob_GBps"] = 12 * 4096 * 4096 / (ms * 1e-3) / 1e9
+    grid.close()
+    return res
+
+
+if __name__ == "__main__":
+    main()
