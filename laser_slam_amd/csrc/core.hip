@@ -55,7 +55,7 @@ static lsa::DevParam dev_param(const lsa_ctx* c)
     return P;
 }
 
-static int icp_lds(int n) { int Np = (n + 63) & ~63; return 42 * Np + 2048; }
+static int icp_lds(int n) { return lsa::icp_lds_bytes(n); }
 static int psm_lds(int n) { int Np = (n + 63) & ~63; return 35 * Np; }
 static int pre_lds(int n) { int Np = (n + 63) & ~63; return 12 * Np; }
 
@@ -278,7 +278,7 @@ int lsa_match_batch(lsa_ctx* c, int which, int B,
     HIP_TRY(hipSetDevice(c->device));
     const lsa::DevParam P = dev_param(c);
     if (which == LSA_MATCH_ICP)
-        hipLaunchKernelGGL(lsa::icp_kernel, dim3(B), dim3(64), icp_lds(P.n), c->stream, P, B, d_r, d_bad, d_seg,
+        hipLaunchKernelGGL(lsa::icp_kernel, dim3(B), dim3(lsa::ICP_THREADS), icp_lds(P.n), c->stream, P, B, d_r, d_bad, d_seg,
                            d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters);
     else
         hipLaunchKernelGGL(lsa::psm_kernel, dim3(B), dim3(64), psm_lds(P.n), c->stream, P, B, d_r, d_bad, d_seg,

@@ -30,15 +30,10 @@ namespace lsa {
 // LDS carve-up (byte offsets, Np = N rounded up to 64).  Regions are reused
 // across the phases of an iteration.
 //
-//  ICP (42 Np + 2 KiB)                         PSM (35 Np)
-//   [ 0, 8) ref_xy float2 (ref_r at the end)    [ 0, 4) ref_r
-//   [ 8,12) act_r                               [ 4, 8) act_r
-//   [12,20) pr,pf -> q (ix,iy) float2           [ 8,16) pr,pf      -> terms 0,1
-//   [20,28) keys -> NN result -> match list     [16,24) keys       -> terms 2,3
-//   [28,36) nxy float2                          [24,28) new_r      -> |dr|
-//   [36,40) owner u32                           [28,32) err[2W+1]  -> term 4
-//   [40,41) ref_bad  [41,42) pair_ok            [32,33) ref_bad [33,34) pair_ok [34,35) new_bad
-//   [42Np, +2 KiB) trim pool
+//  PSM / projection / error-index kernels (35 Np, one wave per pair):
+//   [ 0, 4) ref_r   [ 4, 8) act_r   [ 8,16) pr,pf -> terms 0,1   [16,24) keys -> terms 2,3
+//   [24,28) new_r -> |dr|   [28,32) err[2W+1] -> term 4   [32,33) ref_bad [33,34) pair_ok [34,35) new_bad
+//  ICP kernel: see icp_kernel.hip
 // ---------------------------------------------------------------------------
 
 struct Lds {
@@ -58,26 +53,13 @@ struct Lds {
     uint8_t* new_bad;
     float* pool_d;
     uint32_t* pool_ij;
+    const float* g_act_r;      // ICP v2 reads the current scan's ranges from HBM/L2 (act_r == nullptr)
+    float4* V;                 // ICP v2: ordered value list (nx, ny, ix, iy) -> products
+    unsigned long long* poolA; // ICP v2 trim pool (double buffered) + eviction scratch
+    unsigned long long* poolB;
+    unsigned long long* evict;
+    float* misc;               // broadcast slots
 };
-
-__device__ __forceinline__ Lds carve_icp(char* base, int Np)
-{
-    Lds L = {};
-    L.ref_xy = (float2*)base;
-    L.ref_r = (float*)base;
-    L.act_r = (float*)(base + 8 * Np);
-    L.pr = (float*)(base + 12 * Np);
-    L.pf = (float*)(base + 16 * Np);
-    L.q = (float2*)(base + 12 * Np);
-    L.key = (unsigned long long*)(base + 20 * Np);
-    L.nxy = (float2*)(base + 28 * Np);
-    L.owner = (uint32_t*)(base + 36 * Np);
-    L.ref_bad = (uint8_t*)(base + 40 * Np);
-    L.pair_ok = (uint8_t*)(base + 41 * Np);
-    L.pool_d = (float*)(base + 42 * Np);
-    L.pool_ij = (uint32_t*)(base + 42 * Np + 1024);
-    return L;
-}
 
 __device__ __forceinline__ Lds carve_psm(char* base, int Np)
 {
@@ -113,10 +95,10 @@ __device__ __forceinline__ int key_bad(unsigned long long k) { return k == KEY_I
 // atomic-min keys so that its outcome equals the sequential loop's.
 __device__ void scan_project(const DevParam& P, const Lds& L, float ax, float ay, float ath)
 {
-    const int N = P.n, lane = lane_id();
-    for (int i = lane; i < N; i += WAVE) {
+    const int N = P.n, tid = threadIdx.x, nth = blockDim.x;
+    for (int i = tid; i < N; i += nth) {
         float d = ath + P.fi[i];
-        float rr = L.act_r[i];
+        float rr = L.act_r ? L.act_r[i] : L.g_act_r[i];
         float x = rr * cosf_(d) + ax;
         float y = rr * sinf_(d) + ay;
         L.pr[i] = sqrtf(x * x + y * y);
@@ -126,7 +108,7 @@ __device__ void scan_project(const DevParam& P, const Lds& L, float ax, float ay
         L.key[i] = KEY_INIT;
     }
     __syncthreads();
-    for (int i = lane; i < N; i += WAVE) {
+    for (int i = tid; i < N; i += nth) {
         if (!L.pair_ok[i]) continue;
         float fc = L.pf[i], fp = L.pf[i - 1];
         if ((double)fabsf_(fc - fp) >= LSA_ZPI) continue;
@@ -182,84 +164,12 @@ __device__ __forceinline__ float seg_foot(float x1, float y1, float x2, float y2
     return sqrtf((x3 - fx) * (x3 - fx) + (y3 - fy) * (y3 - fy));
 }
 
-// candidate reference-side point for the pair (cur i -> ref j), :1883-1917
-__device__ __forceinline__ float2 interp_candidate(const Lds& L, int N, int i, int j)
-{
-    float2 p = L.nxy[i];
-    float2 rj = L.ref_xy[j];
-    float d1 = -1.0f, d2 = -1.0f, f1x = 0, f1y = 0, f2x = 0, f2y = 0;
-    if (j > 0) { float2 a = L.ref_xy[j - 1]; d1 = seg_foot(a.x, a.y, rj.x, rj.y, p.x, p.y, f1x, f1y); }
-    if (j < N - 1) { float2 b = L.ref_xy[j + 1]; d2 = seg_foot(rj.x, rj.y, b.x, b.y, p.x, p.y, f2x, f2y); }
-    float2 out = rj;
-    float d0 = sqrtf((rj.x - p.x) * (rj.x - p.x) + (rj.y - p.y) * (rj.y - p.y));
-    if (d1 > 0 && d1 < d0) { out.x = f1x; out.y = f1y; d0 = d1; }
-    if (d2 > 0 && d2 < d0) { out.x = f2x; out.y = f2y; }
-    return out;
-}
-
-struct Rec { float d; uint32_t ij; };   // match record: distance, cur beam | ref beam << 16
-
-__device__ __forceinline__ Rec ld_rec(const unsigned long long* p)
-{
-    unsigned long long v = *p;
-    Rec r; r.d = u2f((uint32_t)v); r.ij = (uint32_t)(v >> 32);
-    return r;
-}
-__device__ __forceinline__ void st_rec(unsigned long long* p, Rec r)
-{
-    *p = (unsigned long long)f2u(r.d) | ((unsigned long long)r.ij << 32);
-}
-
-// ---------------------------------------------------------------------------
-// The partial bubble sort of :1836-1857 (`drop` passes, strict '<' swaps) is a
-// pipeline of `drop` stages that each carry their running maximum; its first
-// n-drop outputs are: out[t-drop] = min(pool U {a[t]}) where pool holds the `drop`
-// largest records seen so far, ties ordered by arrival.  The pool is kept sorted
-// (descending) in LDS; each step is a wave-parallel insert.  Only the kept prefix
-// is produced (the dropped tail is never read by the reference either).
-__device__ void trim_worst(const Lds& L, int n, int drop)
-{
-    const int lane = lane_id();
-    int psize = 0;
-    for (int t = 0; t < n; ++t) {
-        Rec x = ld_rec(&L.key[t]);
-        // p = number of pool records with d > x.d (a prefix of the sorted pool)
-        int p = 0;
-        float old_d[4]; uint32_t old_ij[4];
-        #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            int s = lane + 64 * s4;
-            bool in = s < psize;
-            float pd = in ? L.pool_d[s] : 0.0f;
-            p += __popcll(__ballot(in && pd > x.d));
-            // value that would move into slot s on a right shift
-            old_d[s4] = (s >= 1 && s - 1 < psize) ? L.pool_d[s - 1] : 0.0f;
-            old_ij[s4] = (s >= 1 && s - 1 < psize) ? L.pool_ij[s - 1] : 0u;
-        }
-        if (psize >= drop && p == drop) {          // smaller than the whole pool: passes straight through
-            if (lane == 0) st_rec(&L.key[t - drop], x);
-            continue;
-        }
-        if (psize >= drop) {
-            if (lane == 0) { Rec e; e.d = L.pool_d[drop - 1]; e.ij = L.pool_ij[drop - 1]; st_rec(&L.key[t - drop], e); }
-        }
-        int new_size = psize < drop ? psize + 1 : drop;
-        #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            int s = lane + 64 * s4;
-            if (s > p && s < new_size) { L.pool_d[s] = old_d[s4]; L.pool_ij[s] = old_ij[s4]; }
-            if (s == p) { L.pool_d[s] = x.d; L.pool_ij[s] = x.ij; }
-        }
-        psize = new_size;
-    }
-}
-
 // ---------------------------------------------------------------------------
 // pm_error_index2 tail (:1311-1338) on the projection currently held in L.key.
 // Ordered sums by lanes 0 (x) and 1 (y).
 __device__ void error_index2_tail(const DevParam& P, const Lds& L, float* exy, int* n_assoc)
 {
-    const int N = P.n, lane = lane_id();
+    const int N = P.n, lane = threadIdx.x;
     float acc = 0.0f;
     int cnt = 0;
     if (lane < 2) {
@@ -280,203 +190,7 @@ __device__ void error_index2_tail(const DevParam& P, const Lds& L, float* exy, i
     }
 }
 
-// ---------------------------------------------------------------------------
-// ICP kernel
-__global__ __launch_bounds__(64) void icp_kernel(
-    DevParam P, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
-    const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
-    const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
-    float* __restrict__ err_xy, int* __restrict__ n_assoc, int* __restrict__ status_out, int* __restrict__ iters_out)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int N = P.n, Np = (N + 63) & ~63, W = P.window, lane = lane_id();
-    const Lds L = carve_icp(smem, Np);
-
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        const size_t ro = (size_t)ref_idx[b] * N, ao = (size_t)act_idx[b] * N;
-        __syncthreads();
-        for (int i = lane; i < N; i += WAVE) {
-            float rr = g_r[ro + i];
-            L.ref_xy[i] = make_float2(rr * P.co[i], rr * P.si[i]);      // :1710-1711
-            L.ref_bad[i] = g_bad[ro + i];
-            L.act_r[i] = g_r[ao + i];
-            uint8_t ok = 0;
-            if (i >= 1) {
-                uint16_t s1 = g_seg[ao + i], s0 = g_seg[ao + i - 1];
-                ok = (s1 != 0 && s1 == s0 && g_bad[ao + i] == 0 && g_bad[ao + i - 1] == 0) ? 1 : 0;   // :1396
-            }
-            L.pair_ok[i] = ok;
-            L.owner[i] = 0;
-        }
-        float ax, ay, ath;
-        rel_pose(init_pose ? init_pose + 6 * (size_t)b : nullptr, ax, ay, ath);
-        const float ax0 = init_pose ? init_pose[6 * (size_t)b + 3] : 0.0f;
-        const float ay0 = init_pose ? init_pose[6 * (size_t)b + 4] : 0.0f;
-        const float ath0 = init_pose ? init_pose[6 * (size_t)b + 5] : 0.0f;
-        float dx = 0, dy = 0, dth = 0;
-        int small = 0, status = LSA_ST_OK, n = 0, drop = 0, keep = 0;
-        __syncthreads();
-
-        int iter = -1;
-        while (++iter < LSA_ITER_ICP && small < 3) {
-            if (((double)(fabsf_(dx) + fabsf_(dy)) + (double)fabsf_(dth) * LSA_ZR2D) < LSA_STOP_ICP) small++;
-            else small = 0;                                                     // :1728
-
-            scan_project(P, L, ax, ay, ath);                                    // flags only, :1750
-
-            const float co = cosf_(ath), si = sinf_(ath);                       // :1753-1758
-            for (int i = lane; i < N; i += WAVE) {
-                float rr = L.act_r[i];
-                float cx = rr * P.co[i], cy = rr * P.si[i];                     // act.x/act.y, :1713-1714
-                L.nxy[i] = make_float2(cx * co - cy * si + ax, cx * si + cy * co + ay);
-            }
-            __syncthreads();
-
-            // nearest reference point inside [i-W, i+W), :1785-1810
-            for (int base = 0; base < N; base += WAVE) {
-                const int i = base + lane;
-                const bool live = i < N && key_bad(L.key[i < N ? i : 0]) == 0;
-                float best = 1000000.0f;
-                int bj = -1;
-                float2 p = L.nxy[i < N ? i : 0];
-                for (int o = -W; o < W; ++o) {
-                    int j = i + o;
-                    if (live && j >= 0 && j < N && L.ref_bad[j] == 0) {
-                        float2 rj = L.ref_xy[j];
-                        float ex = p.x - rj.x, ey = p.y - rj.y;
-                        float d = ex * ex + ey * ey;
-                        if (d < best) { best = d; bj = j; }
-                    }
-                }
-                if (i < N) {
-                    Rec r;
-                    float sd = sqrtf(best);
-                    r.d = (live && bj >= 0 && sd < LSA_MAX_ERROR) ? sd : -1.0f;   // :1811
-                    r.ij = (uint32_t)i | ((uint32_t)(bj < 0 ? 0 : bj) << 16);
-                    st_rec(&L.key[i], r);
-                }
-            }
-            __syncthreads();
-            // compaction in beam order (in place: destination index <= source index)
-            n = 0;
-            for (int base = 0; base < N; base += WAVE) {
-                const int i = base + lane;
-                Rec r; r.d = -1.0f; r.ij = 0;
-                if (i < N) r = ld_rec(&L.key[i]);
-                const bool ok = r.d >= 0.0f;
-                const unsigned long long mask = __ballot(ok);
-                if (ok) st_rec(&L.key[n + prefix_popc(mask)], r);
-                n += __popcll(mask);
-            }
-            __syncthreads();
-            if (n < P.min_valid) { status = LSA_ST_FEW_POINTS; break; }        // :1825-1832
-
-            drop = (int)((double)n * 0.2);                                      // :1836
-            keep = n - drop;
-            trim_worst(L, n, drop);
-            __syncthreads();
-
-            // reference-side interpolation, :1867-1926.  ix/iy are indexed by the
-            // reference beam and later pairs overwrite earlier ones: the pair with
-            // the largest list position owns the slot.
-            for (int k = lane; k < keep; k += WAVE) {
-                Rec r = ld_rec(&L.key[k]);
-                atomicMax(&L.owner[r.ij >> 16], (uint32_t)(k + 1));
-            }
-            __syncthreads();
-            for (int k = lane; k < keep; k += WAVE) {
-                Rec r = ld_rec(&L.key[k]);
-                const int i = r.ij & 0xffff, j = r.ij >> 16;
-                if (L.owner[j] == (uint32_t)(k + 1)) L.q[j] = interp_candidate(L, N, i, j);
-            }
-            __syncthreads();
-
-            // closed-form rigid fit, :1936-1986.  Four ordered sums side by side:
-            // lane 0: sum nx, lane 1: sum ny, lane 2: sum ix, lane 3: sum iy.
-            float mean = 0.0f;
-            if (lane < 4) {
-                const float* basep = lane < 2 ? (const float*)L.nxy : (const float*)L.q;
-                const int comp = lane & 1;
-                for (int k = 0; k < keep; ++k) {
-                    uint32_t ij = (uint32_t)(L.key[k] >> 32);
-                    int idx = lane < 2 ? (int)(ij & 0xffff) : (int)(ij >> 16);
-                    mean += basep[2 * idx + comp];
-                }
-                mean /= (float)keep;
-            }
-            const float mpx = __shfl(mean, 0), mpy = __shfl(mean, 1), mqx = __shfl(mean, 2), mqy = __shfl(mean, 3);
-            float cov = 0.0f;
-            if (lane < 4) {
-                // lane 0: sxx (nx,ix)  lane 1: sxy (nx,iy)  lane 2: syx (ny,ix)  lane 3: syy (ny,iy)
-                const int pc = lane >> 1, qc = lane & 1;
-                const float mp = pc ? mpy : mpx, mq = qc ? mqy : mqx;
-                const float* np_ = (const float*)L.nxy;
-                const float* qp_ = (const float*)L.q;
-                for (int k = 0; k < keep; ++k) {
-                    uint32_t ij = (uint32_t)(L.key[k] >> 32);
-                    float pv = np_[2 * (int)(ij & 0xffff) + pc], qv = qp_[2 * (int)(ij >> 16) + qc];
-                    cov += (pv - mp) * (qv - mq);
-                }
-            }
-            const float sxx = __shfl(cov, 0), sxy = __shfl(cov, 1), syx = __shfl(cov, 2), syy = __shfl(cov, 3);
-            dth = atan2f_(sxy - syx, sxx + syy);                                // :1984
-            dx = mqx - ax - (cosf_(dth) * (mpx - ax) - sinf_(dth) * (mpy - ay));
-            dy = mqy - ay - (sinf_(dth) * (mpx - ax) + cosf_(dth) * (mpy - ay));
-            ax += dx;
-            ay += dy;
-            ath += dth;
-            ath = norm_a(ath);
-
-            // release the owner slots for the next iteration
-            for (int k = lane; k < keep; k += WAVE) L.owner[(uint32_t)(L.key[k] >> 32) >> 16] = 0;
-            __syncthreads();
-        }
-
-        // :2012-2020.  The returned value averages the residuals of the first `drop`
-        // kept pairs of the last iteration, each against its own candidate point.
-        float ret = 0.0f;
-        if (status == LSA_ST_OK) {
-            if (lane == 0) {
-                float acc = 0.0f;
-                for (int k = 0; k < drop; ++k) {
-                    Rec r = ld_rec(&L.key[k]);
-                    const int i = r.ij & 0xffff, j = r.ij >> 16;
-                    float2 c = interp_candidate(L, N, i, j);
-                    float2 p = L.nxy[i];
-                    acc += sqrtf((p.x - c.x) * (p.x - c.x) + (p.y - c.y) * (p.y - c.y));
-                }
-                ret = acc / (float)drop;
-            }
-        }
-        if (lane == 0) {
-            const bool ok = status == LSA_ST_OK;
-            pose_out[3 * (size_t)b + 0] = ok ? ax : ax0;       // lsa untouched on throw
-            pose_out[3 * (size_t)b + 1] = ok ? ay : ay0;
-            pose_out[3 * (size_t)b + 2] = ok ? ath : ath0;
-            if (ret_out) ret_out[b] = ret;
-            if (status_out) status_out[b] = status;
-            if (iters_out) iters_out[b] = iter;
-        }
-        if (err_xy) {
-            __syncthreads();
-            if (status == LSA_ST_OK) {
-                // pm_error_index2 at the result (FMatch, :105): ref at the origin, cur at (ax,ay,ath)
-                for (int i = lane; i < N; i += WAVE) L.ref_r[i] = g_r[ro + i];   // ref_xy no longer needed
-                __syncthreads();
-                float ex, ey, eth;
-                if (init_pose) {
-                    float ip[6] = {init_pose[6 * (size_t)b], init_pose[6 * (size_t)b + 1], init_pose[6 * (size_t)b + 2], ax, ay, ath};
-                    rel_pose(ip, ex, ey, eth);
-                } else { ex = ax; ey = ay; eth = ath; }
-                scan_project(P, L, ex, ey, eth);
-                error_index2_tail(P, L, err_xy + 2 * (size_t)b, n_assoc ? n_assoc + b : nullptr);
-            } else if (lane < 2) {
-                err_xy[2 * (size_t)b + lane] = -1.0f;
-                if (lane == 0 && n_assoc) n_assoc[b] = 0;
-            }
-        }
-    }
-}
+#include "icp_kernel.hip"
 
 // ---------------------------------------------------------------------------
 // PSM kernel.

@@ -175,8 +175,17 @@ void orc_preprocess(const orc_param* p, float* r, int* bad, int* seg)
 /* ------------------------------------------------------------------------ */
 /* pm_scan_project, :1356-1479                                              */
 
+static void scan_project_ex(const orc_param* p, const float* r, const int* bad, const int* seg,
+                            const float pose[3], float* new_r, int* new_bad, float* pr_out, float* pf_out);
+
 void orc_scan_project(const orc_param* p, const float* r, const int* bad, const int* seg,
                       const float pose[3], float* new_r, int* new_bad)
+{
+    scan_project_ex(p, r, bad, seg, pose, new_r, new_bad, NULL, NULL);
+}
+
+static void scan_project_ex(const orc_param* p, const float* r, const int* bad, const int* seg,
+                            const float pose[3], float* new_r, int* new_bad, float* pr_out, float* pf_out)
 {
     const int n = p->points;
     float* pr = (float*)malloc(sizeof(float) * n);   /* range in the ref frame */
@@ -216,6 +225,8 @@ void orc_scan_project(const orc_param* p, const float* r, const int* bad, const 
             }
         }
     }
+    if (pr_out) memcpy(pr_out, pr, sizeof(float) * n);
+    if (pf_out) memcpy(pf_out, pf, sizeof(float) * n);
     free(pr); free(pf);
 }
 
@@ -382,6 +393,67 @@ static float seg_foot(float x1, float y1, float x2, float y2, float x3, float y3
     return sqrtf((x3 - *fx) * (x3 - *fx) + (y3 - *fy) * (y3 - *fy));
 }
 
+/* Debug hook (tests only): checks the GPU kernel's bearing-bounded nearest-neighbour
+ * search (laser_slam_amd/csrc/icp_kernel.hip) against the brute-force result. */
+int orc_debug_nn = 0;
+int orc_debug_nn_mismatches = 0;
+static void orc_debug_nn_check(const orc_param* p, int i, int lo, int hi, float px, float py,
+                               const float* rx, const float* ry, const int* ref_bad,
+                               float pr, float pf, int bj, float best, int iter)
+{
+    const int N = p->points;
+    float rho = pr * 0.999f - 0.01f;
+    float half = 0.5f * (float)(N - 1) * p->dfi;
+    float a = pf - (p->fi_min + half);
+    a -= 6.2831853f * rintf(a * 0.15915494f);
+    int c0 = (int)rintf((a + half) / p->dfi);
+    int c = c0 < lo ? lo : (c0 > hi - 1 ? hi - 1 : c0);
+    float b1 = 1000000.0f;
+    for (int o = -1; o <= 1; ++o) {
+        int j = c + o;
+        if (j >= lo && j < hi && !ref_bad[j]) {
+            float ex = px - rx[j], ey = py - ry[j], d = ex * ex + ey * ey;
+            if (d < b1) b1 = d;
+        }
+    }
+    int M = -1, j0 = lo, j1 = hi - 1;
+    if (b1 < 1000000.0f && rho > 0.0f) {
+        float tc = b1 < 10001.0f ? b1 : 10001.0f;
+        float ratio = sqrtf(tc) * 1.001f / rho;
+        if (ratio < 1.0f) M = (int)(1.5708f * ratio / p->dfi) + 4;
+    }
+    float b2 = 1000000.0f;
+    int bj2 = -1;
+    if (M < 0) {
+        for (int j = lo; j < hi; ++j)
+            if (!ref_bad[j]) {
+                float ex = px - rx[j], ey = py - ry[j], d = ex * ex + ey * ey;
+                if (d < b2) { b2 = d; bj2 = j; }
+            }
+    } else {
+        int T = (int)rintf(6.2831853f / p->dfi), done = lo - 1;
+        for (int im = -1; im <= 1; ++im) {
+            int cc = c0 + im * T;
+            int s0 = cc - M > done + 1 ? cc - M : done + 1;
+            int e0 = cc + M < hi - 1 ? cc + M : hi - 1;
+            for (int j = s0; j <= e0; ++j)
+                if (!ref_bad[j]) {
+                    float ex = px - rx[j], ey = py - ry[j], d = ex * ex + ey * ey;
+                    if (d < b2) { b2 = d; bj2 = j; }
+                }
+            if (e0 > done) done = e0;
+        }
+        j0 = c0 - M; j1 = c0 + M;
+    }
+    int a1 = bj >= 0 && sqrtf(best) < 100.0f, a2 = bj2 >= 0 && sqrtf(b2) < 100.0f;
+    if (a1 != a2 || (a1 && bj != bj2)) {
+        orc_debug_nn_mismatches++;
+        if (orc_debug_nn > 1)
+            fprintf(stderr, "nn-prune mismatch iter %d beam %d: brute j=%d d=%g  pruned j=%d d=%g  c=%d rho=%g pf=%g range [%d,%d] window [%d,%d)\n",
+                    iter, i, bj, best, bj2, b2, c, rho, pf, j0, j1, lo, hi);
+    }
+}
+
 /* pm_icp, :1653-2021 */
 static int icp_core(const orc_param* p,
                     const float* ref_r, const int* ref_bad, const float ref_pose[3],
@@ -414,7 +486,8 @@ static int icp_core(const orc_param* p,
         if ((fabsf(dx) + fabsf(dy) + fabsf(dth) * Z_R2D) < Z_STOP_ICP) small++; else small = 0;  /* :1728 */
 
         cur[0] = ax; cur[1] = ay; cur[2] = ath;
-        orc_scan_project(p, act_r, act_bad, act_seg, cur, new_r, new_bad);   /* flags only */
+        float* dbg_pr = orc_debug_nn ? (float*)malloc(sizeof(float) * n * 2) : NULL;
+        scan_project_ex(p, act_r, act_bad, act_seg, cur, new_r, new_bad, dbg_pr, dbg_pr ? dbg_pr + n : NULL);   /* flags only */
 
         float co = cosf(ath), si = sinf(ath);
         for (int i = 0; i < n; ++i) {             /* :1755-1758 */
@@ -436,10 +509,12 @@ static int icp_core(const orc_param* p,
                 float d = ex * ex + ey * ey;
                 if (d < best) { best = d; bj = j; }
             }
+            if (dbg_pr) orc_debug_nn_check(p, i, lo, hi, nx[i], ny[i], rx_, ry_, ref_bad, dbg_pr[i], dbg_pr[n + i], bj, best, iter);
             if (bj >= 0 && sqrtf(best) < (float)Z_MAX_ERROR) {
                 mi[m] = i; mj[m] = bj; dist[m] = sqrtf(best); m++;
             }
         }
+        free(dbg_pr);
         if (m < p->min_valid) { status = ORC_FEW_POINTS; break; }           /* :1825-1832 */
 
         /* partial bubble sort: worst 20 % to the tail, :1836-1857 */
