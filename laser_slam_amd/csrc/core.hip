@@ -72,6 +72,18 @@ static int check_param(const lsa_laser_param* p)
 
 extern "C" {
 
+#ifdef LSA_PHASE_STAMPS
+// diagnostic build only: read and reset the per-phase cycle counters of icp_kernel
+int lsa_debug_phase_cycles(unsigned long long* out16)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(lsa::lsa_phase_cycles), sizeof(unsigned long long) * 16));
+    unsigned long long z[16] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lsa::lsa_phase_cycles), z, sizeof z));
+    return LSA_OK;
+}
+#endif
+
 const char* lsa_version(void) { return "laser_slam_amd 0.1 (gfx950)"; }
 
 const char* lsa_last_error(void) { return g_err.c_str(); }

@@ -13,30 +13,43 @@
 //   [ 8Np ,16Np)  K        u64 scatter-min keys -> per-beam NN record -> match list (in place)
 //   [16Np ,16Np+VB) D      pr,pf of the projection (NN reads them as search centre)
 //                          -> V: ordered (nx,ny,ix,iy) float4 list -> W: the four products
-//   [.. , +4Np)   owner    u32 per reference beam; aliases the trim pool (2 x k records + 64)
+//                          (the trim pools and scratch also live here, between NN and V)
+//   [.. , +4Np)   owner    u32 per reference beam
 //   [.. , +2Np)   ref_bad, pair_ok bytes
 //   [.. , +256)   broadcast slots
 // The current scan's ranges stay in HBM/L2 (read coalesced once per phase).
 
 constexpr int ICP_THREADS = 256;
+
+// Diagnostic build only (-DLSA_PHASE_STAMPS): per-phase cycle shares, accumulated by
+// thread 0 of each workgroup into lsa_phase_cycles[] (never compiled into the product).
+#ifdef LSA_PHASE_STAMPS
+__device__ unsigned long long lsa_phase_cycles[16];
+#define STAMP(slot) do { if (tid == 0) { unsigned long long t_ = __builtin_readcyclecounter(); ph[slot] += t_ - t_last; t_last = t_; } } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
 constexpr float NN_CAP = 10001.0f;     // matches with d^2 >= 100^2 are rejected anyway (:1811)
 
+constexpr int TRIM_CHUNK = 256;        // records consumed per step of the partial bubble sort
+
+// D region: max of { pr,pf of the projection | the ordered value lists | trim pools + scratch }
 __host__ __device__ inline int icp_v_bytes(int n)
 {
     int Np = (n + 63) & ~63;
     int keep_max = n - (int)((double)n * 0.2) + 2;
-    int vb = 16 * keep_max;
+    int vb = 16 * ((keep_max + 3) & ~3);
     if (vb < 8 * Np) vb = 8 * Np;
+    int kmax = (int)((double)n * 0.2) + 1;
+    int tb = 2 * kmax * 8 + TRIM_CHUNK * (8 + 3 * 4);   // two pools, eviction slots, three float rows
+    if (vb < tb) vb = tb;
     return (vb + 63) & ~63;
 }
-// owner array (u32 per reference beam); the trim pool (2 x kmax records + 64) aliases it
+// owner array: u32 per reference beam
 __host__ __device__ inline int icp_o_bytes(int n)
 {
     int Np = (n + 63) & ~63;
-    int kmax = (int)((double)n * 0.2) + 1;
-    int pool = (2 * kmax + 64) * 8;
-    int ob = 4 * Np > pool ? 4 * Np : pool;
-    return (ob + 63) & ~63;
+    return 4 * Np;
 }
 __host__ __device__ inline int icp_lds_bytes(int n)
 {
@@ -58,9 +71,10 @@ __device__ __forceinline__ Lds carve_icp(char* base, int n)
     char* o = d + icp_v_bytes(n);
     L.owner = (uint32_t*)o;
     const int kmax = (int)((double)n * 0.2) + 1;
-    L.poolA = (unsigned long long*)o;
+    L.poolA = (unsigned long long*)d;               // trim pools + scratch alias the D region
     L.poolB = L.poolA + kmax;
-    L.evict = L.poolB + kmax;                       // 64 records
+    L.evict = L.poolB + kmax;                       // TRIM_CHUNK records, then 3 x TRIM_CHUNK floats
+    L.pool_d = (float*)(L.evict + TRIM_CHUNK);
     char* f = o + icp_o_bytes(n);
     L.ref_bad = (uint8_t*)f;
     L.pair_ok = (uint8_t*)(f + Np);
@@ -70,11 +84,6 @@ __device__ __forceinline__ Lds carve_icp(char* base, int n)
 
 struct Rec { float d; uint32_t ij; };   // match record: distance, cur beam | ref beam << 16
 
-__device__ __forceinline__ Rec unpack_rec(unsigned long long v)
-{
-    Rec r; r.d = u2f((uint32_t)v); r.ij = (uint32_t)(v >> 32);
-    return r;
-}
 __device__ __forceinline__ unsigned long long pack_rec(float d, uint32_t ij)
 {
     return (unsigned long long)f2u(d) | ((unsigned long long)ij << 32);
@@ -88,6 +97,12 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+
+__device__ __forceinline__ float bcast_f(float v, int src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+__device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
 // candidate reference-side point for the pair (cur point p -> ref j), :1883-1917
 __device__ __forceinline__ float2 interp_candidate(const Lds& L, int N, float2 p, int j)
@@ -113,97 +128,294 @@ __device__ __forceinline__ float2 cur_point(const DevParam& P, const float* g_ac
 }
 
 // ---------------------------------------------------------------------------
-// Partial bubble sort of :1836-1857 (`k` passes, strict '<' swaps), wave 0 only.
+// Nearest reference point inside [i-W, i+W), :1785-1810, exact.
+//
+// A reference point on the ray at bearing fi_j is at least rho*sin(|fi_j - phi|) away
+// from p = (rho, phi), so only rays within asin(sqrt(best)/rho) of phi can hold the
+// minimum; asin(t) <= t + (pi/2 - 1) t^3 on [0,1] keeps the bound free of
+// transcendentals.  `best` comes from the three rays around the bearing of p.  The
+// candidate set is the union of up to three index ranges (the bearing and its images
+// one turn away, for fields of view wider than 180 deg), visited in increasing j; the
+// minimum keeps the reference's tie rule (first strict minimum = smallest j).
+struct NnPlan { int lo, hi, c0, M; };     // window [lo,hi), centre, half width (M < 0: whole window)
+
+// Ray j is excluded only if |j - c| > M with c within half a ray of the bearing of p (one ray
+// for the images, whose period is rounded), i.e. its angular distance exceeds
+// (M - 1/2) dfi >= asin bound + dfi/2 for M = floor(bound/dfi) + 2 (images: + 3).
+__device__ __forceinline__ void nn_range(const NnPlan& pl, int T, int im, int& done, int& s0, int& e0)
+{
+    if (pl.M < 0) { s0 = im == -1 ? pl.lo : 1; e0 = im == -1 ? pl.hi - 1 : 0; return; }
+    const int cc = pl.c0 + im * T, m = im == 0 ? pl.M : pl.M + 1;
+    s0 = cc - m > done + 1 ? cc - m : done + 1;
+    e0 = cc + m < pl.hi - 1 ? cc + m : pl.hi - 1;
+    if (e0 > done) done = e0;
+}
+
+__device__ __forceinline__ void nn_eval(const Lds& L, float2 p, int j, float& best, int& best_j)
+{
+    if (L.ref_bad[j] == 0) {
+        const float2 rj = L.ref_xy[j];
+        const float ex = p.x - rj.x, ey = p.y - rj.y;
+        const float d = ex * ex + ey * ey;                 // :1803
+        if (d < best || (d == best && j < best_j)) { best = d; best_j = j; }
+    }
+}
+
+// four consecutive rays with their loads issued together
+__device__ __forceinline__ void nn_eval4(const Lds& L, float2 p, int j, float& best, int& best_j)
+{
+    const uint8_t b0 = L.ref_bad[j], b1 = L.ref_bad[j + 1], b2 = L.ref_bad[j + 2], b3 = L.ref_bad[j + 3];
+    const float2 r0 = L.ref_xy[j], r1 = L.ref_xy[j + 1], r2 = L.ref_xy[j + 2], r3 = L.ref_xy[j + 3];
+    float ex, ey, d;
+    ex = p.x - r0.x; ey = p.y - r0.y; d = ex * ex + ey * ey; if (b0 == 0 && d < best) { best = d; best_j = j; }
+    ex = p.x - r1.x; ey = p.y - r1.y; d = ex * ex + ey * ey; if (b1 == 0 && d < best) { best = d; best_j = j + 1; }
+    ex = p.x - r2.x; ey = p.y - r2.y; d = ex * ex + ey * ey; if (b2 == 0 && d < best) { best = d; best_j = j + 2; }
+    ex = p.x - r3.x; ey = p.y - r3.y; d = ex * ex + ey * ey; if (b3 == 0 && d < best) { best = d; best_j = j + 3; }
+}
+
+constexpr int NN_SHORT = 32;      // candidate counts above this are searched by the whole wave
+
+// one wave, beams base..base+63 with their points p (live = projected flag clear);
+// writes the per-beam NN record into L.key[i]
+__device__ __forceinline__ void nn_chunk(const DevParam& P, const Lds& L, int base, float2 p, bool live,
+                                         unsigned long long* slot, int& jprev)
+{
+    const int N = P.n, W = P.window, lane = lane_id();
+    const int i = base + lane;
+    const int T = (int)rintf(6.2831853f / P.dfi);
+    NnPlan pl = {0, 0, 0, -1};
+    int len = 0;
+    if (live) {
+        pl.lo = i - W < 0 ? 0 : i - W;
+        pl.hi = i + W > N ? N : i + W;
+        const float rho = L.pr[i] * 0.999f - 0.01f;
+        // centre: bearing of p relative to the middle of the field of view, wrapped to [-pi, pi]
+        const float half = 0.5f * (float)(N - 1) * P.dfi;
+        float a = L.pf[i] - (P.fi_min + half);
+        a -= 6.2831853f * rintf(a * 0.15915494f);
+        pl.c0 = (int)rintf((a + half) / P.dfi);
+        const int c = pl.c0 < pl.lo ? pl.lo : (pl.c0 > pl.hi - 1 ? pl.hi - 1 : pl.c0);
+        // seed distance: the ray at the bearing of p and last iteration's match
+        float b1 = 1000000.0f;
+        int bj1 = 0x7fffffff;
+        nn_eval(L, p, c, b1, bj1);
+        if (jprev >= pl.lo && jprev < pl.hi) nn_eval(L, p, jprev, b1, bj1);
+        if (b1 < 1000000.0f && rho > 0.0f) {
+            const float tcap = b1 < NN_CAP ? b1 : NN_CAP;
+            const float t = sqrtf(tcap) * 1.001f / rho;
+            if (t < 1.0f) pl.M = (int)((t + 0.5708f * t * t * t) / P.dfi) + 2;
+        }
+        int done = pl.lo - 1, s0, e0;
+        #pragma unroll
+        for (int im = -1; im <= 1; ++im) { nn_range(pl, T, im, done, s0, e0); len += e0 >= s0 ? e0 - s0 + 1 : 0; }
+    }
+    float best = 1000000.0f;
+    int best_j = 0x7fffffff;
+    const bool is_long = live && len > NN_SHORT;
+    if (live && !is_long) {
+        int done = pl.lo - 1, s0, e0;
+        #pragma unroll
+        for (int im = -1; im <= 1; ++im) {
+            nn_range(pl, T, im, done, s0, e0);
+            int j = s0;
+            for (; j + 3 <= e0; j += 4) nn_eval4(L, p, j, best, best_j);
+            for (; j <= e0; ++j) nn_eval(L, p, j, best, best_j);
+        }
+    }
+    // long candidate lists: the whole wave scans one beam's ranges, 64 rays at a time
+    for (unsigned long long m = __ballot(is_long); m; m &= m - 1) {
+        const int s = __builtin_ctzll(m);
+        const float2 bp = make_float2(bcast_f(p.x, s), bcast_f(p.y, s));
+        NnPlan bpl = {bcast_i(pl.lo, s), bcast_i(pl.hi, s), bcast_i(pl.c0, s), bcast_i(pl.M, s)};
+        float cb = 1000000.0f;
+        int cj = 0x7fffffff;
+        int done = bpl.lo - 1, s0, e0;
+        #pragma unroll
+        for (int im = -1; im <= 1; ++im) {
+            nn_range(bpl, T, im, done, s0, e0);
+            for (int j = s0 + lane; j <= e0; j += WAVE) nn_eval(L, bp, j, cb, cj);
+        }
+        // wave minimum of (distance, ray) through one LDS atomic (distances are >= 0, so the
+        // IEEE bit pattern orders like the value; ties resolve to the smaller ray index)
+        if (lane == 0) *slot = ~0ull;
+        wave_sync();
+        if (cj != 0x7fffffff) atomicMin(slot, ((unsigned long long)f2u(cb) << 32) | (unsigned)cj);
+        wave_sync();
+        const unsigned long long res = *slot;
+        if (lane == s && res != ~0ull) { best = u2f((uint32_t)(res >> 32)); best_j = (int)(uint32_t)res; }
+        wave_sync();
+    }
+    jprev = live && best_j != 0x7fffffff ? best_j : -1;
+    if (i < N) {
+        float rd = -1.0f;
+        int bj = 0;
+        if (live && best_j != 0x7fffffff) {
+            const float sd = sqrtf(best);
+            if (sd < LSA_MAX_ERROR) { rd = sd; bj = best_j; }                  // :1811
+        }
+        L.key[i] = pack_rec(rd, (uint32_t)i | ((uint32_t)bj << 16));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Partial bubble sort of :1836-1857 (`k` passes, strict '<' swaps), whole workgroup.
 //
 // k bubble passes are a pipeline of k stages that each carry their running maximum,
 // i.e. a pool holding the k largest records seen so far (ties ordered by arrival):
 //     out[t-k] = min(pool U {a[t]}),   pool <- the rest.
-// Records are consumed 64 at a time.  For a record x of the chunk let
-//     b = #{earlier records with key > key(x)} = (pool records > x) + (earlier lanes > x);
-// x enters the pool iff b < k, otherwise it is emitted in place.  The records that
-// leave the pool in this chunk are the smallest of (pool U entering), in ascending
-// order, one per entering record once the pool is full.  All of it is computed with
-// rank counting (no sequential insertion), and only the kept prefix out[0..n-k) is
-// produced - the reference never reads the dropped tail either.
-__device__ void trim_worst(const Lds& L, int n, int k)
+// The first k records always enter the pool and are rank-sorted.  After that 256
+// records are consumed per step.  For a record x let
+//     b = #{earlier records with key > key(x)} = (pool records > x) + (earlier records of the step > x);
+// x enters the pool iff b < k, otherwise it is emitted in place.  The records leaving
+// the pool in a step are the smallest of (pool U entering), in ascending order, one
+// per entering record.  Everything is rank counting and binary search (no sequential
+// insertion); only the kept prefix out[0..n-k) is produced - the reference never reads
+// the dropped tail either.
+
+// index of this thread's flag among the set flags of the workgroup (thread order), and the total
+__device__ __forceinline__ int block_rank(bool flag, int& total, volatile int* wcnt)
 {
-    const int lane = lane_id();
+    const unsigned long long mask = __ballot(flag);
+    const int wave = threadIdx.x >> 6;
+    if (lane_id() == 0) wcnt[wave] = __popcll(mask);
+    __syncthreads();
+    const int c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+    total = c0 + c1 + c2 + c3;
+    const int off = (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+    __syncthreads();
+    return off + prefix_popc(mask);
+}
+
+// #{p < min(limit,cnt) : row[p] > d} + #{limit <= p < cnt : row[p] >= d}.
+// Distances are >= 0, so the IEEE bit patterns order like the values and ">= d" is
+// "> bits(d) - 1" on the signed patterns; rows are padded to a multiple of 4 with -1.
+__device__ __forceinline__ int count_split(const float* row, int cnt, float d, int limit)
+{
+    const int4* r4 = (const int4*)row;
+    const int t1 = (int)f2u(d), t2 = t1 - 1;
+    const int nq = (cnt + 3) >> 2, qa = limit >> 2;      // quads [0,qa) lie entirely below `limit`
+    int c = 0, qd = 0;
+    #pragma unroll 4
+    for (; qd < qa; ++qd) {
+        const int4 v = r4[qd];
+        c += (v.x > t1) + (v.y > t1) + (v.z > t1) + (v.w > t1);
+    }
+    if (qd < nq && (limit & 3)) {                        // the quad that straddles `limit`
+        const int4 v = r4[qd];
+        const int p = qd * 4;
+        c += (p     < cnt && v.x > (p     < limit ? t1 : t2)) ? 1 : 0;
+        c += (p + 1 < cnt && v.y > (p + 1 < limit ? t1 : t2)) ? 1 : 0;
+        c += (p + 2 < cnt && v.z > (p + 2 < limit ? t1 : t2)) ? 1 : 0;
+        c += (p + 3 < cnt && v.w > (p + 3 < limit ? t1 : t2)) ? 1 : 0;
+        ++qd;
+    }
+    #pragma unroll 4
+    for (; qd < nq; ++qd) {
+        const int4 v = r4[qd];
+        c += (v.x > t2) + (v.y > t2) + (v.z > t2) + (v.w > t2);
+    }
+    return c;
+}
+
+__device__ void trim_worst(const Lds& L, int n, int k, volatile int* wcnt)
+{
+    const int tid = threadIdx.x;
     unsigned long long* A = L.key;
     unsigned long long* Pc = L.poolA;
     unsigned long long* Pn = L.poolB;
-    int psize = 0;
-    const int nslot = (k + 63) >> 6;           // pool slots per lane (<= 4, host-checked)
-    for (int t0 = 0; t0 < n; t0 += WAVE) {
-        const int t = t0 + lane;
+    float* cd = L.pool_d;                            // candidates' distances (arrival order)
+    float* ce = L.pool_d + TRIM_CHUNK;               // entering records' distances (arrival order)
+    float* se = L.pool_d + 2 * TRIM_CHUNK;           // entering records' distances, descending
+    // the first k records (k <= TRIM_CHUNK, host-checked): rank sort, descending by (distance, arrival)
+    {
+        const unsigned long long rec = tid < k ? A[tid] : 0ull;
+        const float d = rec_d(rec);
+        if (tid < k) cd[tid] = d;
+        if (tid < 4 && k + tid < ((k + 3) & ~3)) cd[k + tid] = -1.0f;
+        __syncthreads();
+        if (tid < k) Pc[count_split(cd, k, d, tid + 1)] = rec;
+        __syncthreads();
+    }
+    for (int t0 = k; t0 < n; t0 += TRIM_CHUNK) {
+        const int t = t0 + tid;
         const bool valid = t < n;
         const unsigned long long rec = valid ? A[t] : 0ull;
         const float d = rec_d(rec);
-        const bool full = psize == k;
-        const float theta = full ? rec_d(Pc[k - 1]) : -1.0f;
+        const float theta = rec_d(Pc[k - 1]);
         const bool cand = valid && d >= theta;
-        // pool records strictly greater: first index with pool.d <= d (pool is descending)
-        int g1 = 0;
+        int q;
+        const int cpos = block_rank(cand, q, wcnt);
+        if (q == 0) { if (valid) A[t - k] = rec; continue; }
+        if (cand) cd[cpos] = d;
+        if (tid < 4 && q + tid < ((q + 3) & ~3)) cd[q + tid] = -1.0f;      // pad the row
+        int g1 = 0;                                  // pool records strictly greater
         if (cand) {
-            int lo = 0, hi = psize;
+            int lo = 0, hi = k;
             while (lo < hi) {
-                int mid = (lo + hi) >> 1;
+                const int mid = (lo + hi) >> 1;
                 if (rec_d(Pc[mid]) > d) lo = mid + 1; else hi = mid;
             }
             g1 = lo;
         }
-        const unsigned long long cm = __ballot(cand);
-        int g2 = 0;
-        for (unsigned long long m = cm; m; m &= m - 1) {
-            const int s = __builtin_ctzll(m);
-            const float ds = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), s));
-            g2 += (s < lane && ds > d) ? 1 : 0;
-        }
+        __syncthreads();
+        // earlier records of this step that are strictly greater (later ones never count)
+        const int g2 = cand ? count_split(cd, cpos, d, cpos) : 0;
         const bool ent = cand && (g1 + g2 < k);
-        const unsigned long long em = __ballot(ent);
-        const int E = __popcll(em);
-        if (valid && !ent) A[t - k] = rec;                    // passes straight through (t >= k here)
+        int E;
+        const int epos = block_rank(ent, E, wcnt);
+        if (valid && !ent) A[t - k] = rec;           // passes straight through
         if (E == 0) continue;
-
-        float pd[4];
-        unsigned long long pv[4];
-        int cnt[4] = {0, 0, 0, 0};
-        #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = lane + 64 * r;
-            pv[r] = (r < nslot && i < psize) ? Pc[i] : 0ull;
-            pd[r] = rec_d(pv[r]);
-        }
-        int h = 0;
-        for (unsigned long long m = em; m; m &= m - 1) {
-            const int s = __builtin_ctzll(m);
-            const float ds = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), s));
-            h += (ds > d || (ds == d && s > lane)) ? 1 : 0;
-            #pragma unroll
-            for (int r = 0; r < 4; ++r) cnt[r] += ds >= pd[r] ? 1 : 0;
-        }
-        const int tot = psize + E;
-        const int fill = k - psize;                            // entering records that only fill the pool
+        if (ent) ce[epos] = d;
+        if (tid < 4 && E + tid < ((E + 3) & ~3)) ce[E + tid] = -1.0f;
+        __syncthreads();
+        // entering records with a greater key
+        const int h = ent ? count_split(ce, E, d, epos + 1) : 0;
+        if (ent) se[h] = d;
+        __syncthreads();
+        const int top = k + E - 1;
         if (ent) {
             const int pos = g1 + h;
-            if (pos < k) Pn[pos] = rec; else L.evict[(tot - 1) - pos] = rec;
+            if (pos < k) Pn[pos] = rec; else L.evict[top - pos] = rec;
         }
-        #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = lane + 64 * r;
-            if (r < nslot && i < psize) {
-                const int ni = i + cnt[r];
-                if (ni < k) Pn[ni] = pv[r]; else L.evict[(tot - 1) - ni] = pv[r];
+        for (int i = tid; i < k; i += ICP_THREADS) {
+            const unsigned long long pv = Pc[i];
+            const float pd = rec_d(pv);
+            int lo = 0, hi = E;                      // entering records with distance >= pd
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (se[mid] >= pd) lo = mid + 1; else hi = mid;
             }
+            const int ni = i + lo;
+            if (ni < k) Pn[ni] = pv; else L.evict[top - ni] = pv;
         }
-        wave_sync();
-        if (ent) {
-            const int e = prefix_popc(em);
-            if (e >= fill) A[t - k] = L.evict[e - fill];
-        }
-        wave_sync();
+        __syncthreads();
+        if (ent) A[t - k] = L.evict[epos];           // evictions come out in ascending order
+        __syncthreads();
         unsigned long long* sw = Pc; Pc = Pn; Pn = sw;
-        psize = tot < k ? tot : k;
     }
+}
+
+// ordered sum of arr[0..cnt) in index order (one lane), loads software-pipelined
+__device__ __forceinline__ float ordered_sum(const float* arr, int cnt)
+{
+    const float4* v = (const float4*)arr;            // arrays are 16-byte aligned and padded
+    const int nq = cnt >> 2;
+    float acc = 0.0f;
+    float4 buf[4];
+    #pragma unroll
+    for (int u = 0; u < 4; ++u) buf[u] = v[u];       // reads past cnt stay inside the padded array
+    int qd = 0;
+    for (; qd + 4 <= nq; qd += 4) {
+        float4 nxt[4];
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) nxt[u] = v[qd + 4 + u];
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) { acc += buf[u].x; acc += buf[u].y; acc += buf[u].z; acc += buf[u].w; }
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) buf[u] = nxt[u];
+    }
+    for (int k2 = qd * 4; k2 < cnt; ++k2) acc += arr[k2];
+    return acc;
 }
 
 // ---------------------------------------------------------------------------
@@ -214,10 +426,13 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
     float* __restrict__ err_xy, int* __restrict__ n_assoc, int* __restrict__ status_out, int* __restrict__ iters_out)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int N = P.n, W = P.window, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int N = P.n, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     Lds L = carve_icp(smem, N);
-    volatile int* imisc = (volatile int*)L.misc;              // [0] n   [1] status
+    volatile int* imisc = (volatile int*)L.misc;              // [0] n
     volatile float* fmisc = (volatile float*)L.misc + 8;      // [0..3] means  [4..7] covariances
+    // ordered value lists (SoA, padded): nx | ny | ix | iy, later the four product lists
+    const int VS = icp_v_bytes(N) / 16;                       // floats per list (multiple of 4, + slack)
+    float* const V0 = (float*)L.V;
 
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const size_t ro = (size_t)ref_idx[b] * N, ao = (size_t)act_idx[b] * N;
@@ -242,7 +457,12 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
         float dx = 0, dy = 0, dth = 0;
         int small = 0, status = LSA_ST_OK, n = 0, drop = 0, keep = 0;
         float co = 1.0f, si = 0.0f, pax = 0.0f, pay = 0.0f;
+        int jprev[5] = {-1, -1, -1, -1, -1};       // last iteration's match of this thread's beams (search seed)
         __syncthreads();
+#ifdef LSA_PHASE_STAMPS
+        unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long t_last = __builtin_readcyclecounter();
+#endif
 
         int iter = -1;
         while (++iter < LSA_ITER_ICP && small < 3) {
@@ -251,84 +471,28 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
 
             scan_project(P, L, ax, ay, ath);                                    // flags only, :1750
             co = cosf_(ath); si = sinf_(ath);                                   // :1753-1754
+            STAMP(0);
 
-            // ---- nearest reference point inside [i-W, i+W), :1785-1822 -------------
-            // Exact result of the brute-force scan, found with a bearing bound: a
-            // reference point on the ray at bearing fi_j is at least rho*sin|fi_j - phi|
-            // away from p = (rho, phi), so only rays within asin(sqrt(best)/rho) of phi
-            // can hold the minimum; asin(t) <= (pi/2) t keeps it free of transcendentals.
-            for (int i = tid; i < N; i += ICP_THREADS) {
-                const unsigned long long kk = L.key[i];
-                float rd = -1.0f;
-                int bj = 0;
-                if (key_bad(kk) == 0) {
-                    const float2 p = cur_point(P, L.g_act_r, i, co, si, ax, ay);
-                    const int lo = i - W < 0 ? 0 : i - W, hi = i + W > N ? N : i + W;   // [lo,hi)
-                    const float rho = L.pr[i] * 0.999f - 0.01f;
-                    // search centre: bearing of p relative to the middle of the field of view,
-                    // wrapped to [-pi, pi] (the projection keeps bearings in [-pi/2, 3pi/2))
-                    const float half = 0.5f * (float)(N - 1) * P.dfi;
-                    float a = L.pf[i] - (P.fi_min + half);
-                    a -= 6.2831853f * rintf(a * 0.15915494f);
-                    const int c0 = (int)rintf((a + half) / P.dfi);
-                    const int c = c0 < lo ? lo : (c0 > hi - 1 ? hi - 1 : c0);
-                    float best = 1000000.0f;
-                    #pragma unroll
-                    for (int o = -1; o <= 1; ++o) {
-                        const int j = c + o;
-                        if (j >= lo && j < hi && L.ref_bad[j] == 0) {
-                            const float2 rj = L.ref_xy[j];
-                            const float ex = p.x - rj.x, ey = p.y - rj.y;
-                            const float d = ex * ex + ey * ey;
-                            best = d < best ? d : best;
-                        }
-                    }
-                    int M = -1;
-                    if (best < 1000000.0f && rho > 0.0f) {
-                        const float tcap = best < NN_CAP ? best : NN_CAP;
-                        const float ratio = sqrtf(tcap) * 1.001f / rho;
-                        if (ratio < 1.0f) M = (int)(1.5708f * ratio / P.dfi) + 4;
-                    }
-                    best = 1000000.0f;
-                    int best_j = -1;
-                    if (M < 0) {
-                        for (int j = lo; j < hi; ++j) {
-                            if (L.ref_bad[j] == 0) {
-                                const float2 rj = L.ref_xy[j];
-                                const float ex = p.x - rj.x, ey = p.y - rj.y;
-                                const float d = ex * ex + ey * ey;
-                                if (d < best) { best = d; best_j = j; }
-                            }
-                        }
-                    } else {
-                        // rays within M bearings of p, including the images one turn away
-                        // (fields of view wider than 180 deg), visited in increasing j
-                        const int T = (int)rintf(6.2831853f / P.dfi);
-                        int done = lo - 1;
-                        #pragma unroll
-                        for (int im = -1; im <= 1; ++im) {
-                            const int cc = c0 + im * T;
-                            const int s0 = cc - M > done + 1 ? cc - M : done + 1;
-                            const int e0 = cc + M < hi - 1 ? cc + M : hi - 1;
-                            for (int j = s0; j <= e0; ++j) {
-                                if (L.ref_bad[j] == 0) {
-                                    const float2 rj = L.ref_xy[j];
-                                    const float ex = p.x - rj.x, ey = p.y - rj.y;
-                                    const float d = ex * ex + ey * ey;
-                                    if (d < best) { best = d; best_j = j; }
-                                }
-                            }
-                            if (e0 > done) done = e0;
-                        }
-                    }
-                    const float sd = sqrtf(best);
-                    if (best_j >= 0 && sd < LSA_MAX_ERROR) { rd = sd; bj = best_j; }      // :1811
+            {
+                // points of this wave's beams first (global loads in flight together), then the search
+                float2 pts[5];
+                bool lv[5];
+                #pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    const int i = wave * WAVE + r * ICP_THREADS + lane;
+                    lv[r] = i < N && key_bad(L.key[i < N ? i : 0]) == 0;
+                    pts[r] = lv[r] ? cur_point(P, L.g_act_r, i, co, si, ax, ay) : make_float2(0.0f, 0.0f);
                 }
-                L.key[i] = pack_rec(rd, (uint32_t)i | ((uint32_t)bj << 16));
+                #pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    const int base = wave * WAVE + r * ICP_THREADS;
+                    if (base < N) nn_chunk(P, L, base, pts[r], lv[r], (unsigned long long*)(L.misc + 32) + wave, jprev[r]);
+                }
             }
             __syncthreads();
+            STAMP(1);
 
-            // ---- wave 0: compaction in beam order, then the partial bubble sort ------
+            // ---- wave 0: compaction in beam order ------------------------------------
             if (wave == 0) {
                 int m = 0;
                 for (int base = 0; base < N; base += WAVE) {
@@ -339,15 +503,17 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
                     if (ok) L.key[m + prefix_popc(mask)] = v;       // destination <= source index
                     m += __popcll(mask);
                 }
-                wave_sync();
-                if (m >= P.min_valid) trim_worst(L, m, (int)((double)m * 0.2));         // :1836-1857
                 if (lane == 0) imisc[0] = m;
             }
             __syncthreads();
+            STAMP(2);
             n = imisc[0];
             if (n < P.min_valid) { status = LSA_ST_FEW_POINTS; break; }                  // :1825-1832
-            drop = (int)((double)n * 0.2);
+            drop = (int)((double)n * 0.2);                                              // :1836
             keep = n - drop;
+            trim_worst(L, n, drop, imisc + 2);                                          // :1839-1857
+            __syncthreads();
+            STAMP(3);
 
             // ---- interpolation of the reference side, :1867-1926 ---------------------
             // ix/iy are indexed by the reference beam and later pairs overwrite earlier
@@ -365,34 +531,24 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
                 const float2 p = cur_point(P, L.g_act_r, i, co, si, ax, ay);
                 const float2 po = io == i ? p : cur_point(P, L.g_act_r, io, co, si, ax, ay);
                 const float2 q = interp_candidate(L, N, po, j);
-                L.V[k] = make_float4(p.x, p.y, q.x, q.y);
+                V0[k] = p.x; V0[VS + k] = p.y; V0[2 * VS + k] = q.x; V0[3 * VS + k] = q.y;
             }
             __syncthreads();
+            STAMP(4);
 
-            // ---- closed-form rigid fit, :1936-1986: ordered sums -----------------------
-            if (tid < 4) {
-                const float* v = (const float*)L.V + tid;
-                float acc = 0.0f;
-                #pragma unroll 8
-                for (int k = 0; k < keep; ++k) acc += v[4 * k];
-                fmisc[tid] = acc / (float)keep;
-            }
+            // ---- closed-form rigid fit, :1936-1986: ordered sums, one lane per sum -------
+            if (tid < 4) fmisc[tid] = ordered_sum(V0 + tid * VS, keep) / (float)keep;
             __syncthreads();
+            STAMP(5);
             const float mpx = fmisc[0], mpy = fmisc[1], mqx = fmisc[2], mqy = fmisc[3];
             for (int k = tid; k < keep; k += ICP_THREADS) {
-                const float4 v = L.V[k];
-                const float a = v.x - mpx, c = v.y - mpy, e = v.z - mqx, f = v.w - mqy;
-                L.V[k] = make_float4(a * e, a * f, c * e, c * f);            // sxx, sxy, syx, syy terms
+                const float a = V0[k] - mpx, c = V0[VS + k] - mpy, e = V0[2 * VS + k] - mqx, f = V0[3 * VS + k] - mqy;
+                V0[k] = a * e; V0[VS + k] = a * f; V0[2 * VS + k] = c * e; V0[3 * VS + k] = c * f;   // sxx sxy syx syy
             }
             __syncthreads();
-            if (tid < 4) {
-                const float* v = (const float*)L.V + tid;
-                float acc = 0.0f;
-                #pragma unroll 8
-                for (int k = 0; k < keep; ++k) acc += v[4 * k];
-                fmisc[4 + tid] = acc;
-            }
+            if (tid < 4) fmisc[4 + tid] = ordered_sum(V0 + tid * VS, keep);
             __syncthreads();
+            STAMP(6);
             const float sxx = fmisc[4], sxy = fmisc[5], syx = fmisc[6], syy = fmisc[7];
             dth = atan2f_(sxy - syx, sxx + syy);                                // :1984
             dx = mqx - ax - (cosf_(dth) * (mpx - ax) - sinf_(dth) * (mpy - ay));
@@ -403,12 +559,16 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
             ath += dth;
             ath = norm_a(ath);
             __syncthreads();
+            STAMP(7);
         }
+#ifdef LSA_PHASE_STAMPS
+        if (tid == 0) for (int s_ = 0; s_ < 8; ++s_) atomicAdd(&lsa_phase_cycles[s_], ph[s_]);
+#endif
 
         // :2012-2020.  The returned value averages the residuals of the first `drop`
         // kept pairs of the last iteration, each against its own candidate point.
         if (status == LSA_ST_OK) {
-            float* resid = (float*)L.V;
+            float* resid = V0;
             for (int k = tid; k < drop; k += ICP_THREADS) {
                 const uint32_t ij = (uint32_t)(L.key[k] >> 32);
                 const float2 p = cur_point(P, L.g_act_r, ij & 0xffff, co, si, pax, pay);

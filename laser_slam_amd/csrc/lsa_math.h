@@ -97,6 +97,32 @@ LSA_HD float sincos_core(float y, int which)
 LSA_HD float sinf_(float x) { return sincos_core(x, 0); }
 LSA_HD float cosf_(float x) { return sincos_core(x, 1); }
 
+// both at once: one range reduction, bit-identical to sinf_(y) and cosf_(y)
+LSA_HD void sincosf_(float y, float& sn, float& cs)
+{
+    double x = y;
+    const uint32_t top = abstop12(y);
+    if (top < abstop12(0x1.921FB6p-1f)) {
+        if (top < abstop12(0x1p-12f)) { sn = y; cs = 1.0f; return; }
+        const double x2 = x * x;
+        sn = sin_poly(x, x2);
+        cs = cos_poly(x2, false);
+        return;
+    }
+    if (top < abstop12(120.0f)) {
+        double r = x * LSA_HPI_INV;
+        int n = ((int32_t)r + 0x800000) >> 24;
+        x = __builtin_fma(-(double)n, LSA_HPI, x);
+        const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+        const bool neg = (n & 2) != 0;
+        const double x2 = x * x;
+        const float a = sin_poly(x * sgn, x2), b = cos_poly(x2, neg);
+        if (n & 1) { sn = b; cs = a; } else { sn = a; cs = b; }
+        return;
+    }
+    sn = cs = u2f(0x7fc00000u);
+}
+
 // ---- atanf / atan2f (FP32 kernels) ---------------------------------------
 
 LSA_HD float fabsf_(float x) { return u2f(f2u(x) & 0x7fffffffu); }

@@ -99,8 +99,10 @@ __device__ void scan_project(const DevParam& P, const Lds& L, float ax, float ay
     for (int i = tid; i < N; i += nth) {
         float d = ath + P.fi[i];
         float rr = L.act_r ? L.act_r[i] : L.g_act_r[i];
-        float x = rr * cosf_(d) + ax;
-        float y = rr * sinf_(d) + ay;
+        float sd, cd;
+        sincosf_(d, sd, cd);
+        float x = rr * cd + ax;
+        float y = rr * sd + ay;
         L.pr[i] = sqrtf(x * x + y * y);
         float a = atan2f_(y, x);
         if (x < 0 && y < 0) a = (float)((double)a + 2.0 * LSA_ZPI);

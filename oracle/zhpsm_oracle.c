@@ -399,7 +399,7 @@ int orc_debug_nn = 0;
 int orc_debug_nn_mismatches = 0;
 static void orc_debug_nn_check(const orc_param* p, int i, int lo, int hi, float px, float py,
                                const float* rx, const float* ry, const int* ref_bad,
-                               float pr, float pf, int bj, float best, int iter)
+                               float pr, float pf, int bj, float best, int iter, int* jprev)
 {
     const int N = p->points;
     float rho = pr * 0.999f - 0.01f;
@@ -409,18 +409,21 @@ static void orc_debug_nn_check(const orc_param* p, int i, int lo, int hi, float 
     int c0 = (int)rintf((a + half) / p->dfi);
     int c = c0 < lo ? lo : (c0 > hi - 1 ? hi - 1 : c0);
     float b1 = 1000000.0f;
-    for (int o = -1; o <= 1; ++o) {
-        int j = c + o;
-        if (j >= lo && j < hi && !ref_bad[j]) {
-            float ex = px - rx[j], ey = py - ry[j], d = ex * ex + ey * ey;
-            if (d < b1) b1 = d;
+    {
+        int seeds[2] = {c, jprev[i]};
+        for (int q = 0; q < 2; ++q) {
+            int j = seeds[q];
+            if (j >= lo && j < hi && !ref_bad[j]) {
+                float ex = px - rx[j], ey = py - ry[j], d = ex * ex + ey * ey;
+                if (d < b1) b1 = d;
+            }
         }
     }
     int M = -1, j0 = lo, j1 = hi - 1;
     if (b1 < 1000000.0f && rho > 0.0f) {
         float tc = b1 < 10001.0f ? b1 : 10001.0f;
-        float ratio = sqrtf(tc) * 1.001f / rho;
-        if (ratio < 1.0f) M = (int)(1.5708f * ratio / p->dfi) + 4;
+        float t = sqrtf(tc) * 1.001f / rho;
+        if (t < 1.0f) M = (int)((t + 0.5708f * t * t * t) / p->dfi) + 2;
     }
     float b2 = 1000000.0f;
     int bj2 = -1;
@@ -433,9 +436,9 @@ static void orc_debug_nn_check(const orc_param* p, int i, int lo, int hi, float 
     } else {
         int T = (int)rintf(6.2831853f / p->dfi), done = lo - 1;
         for (int im = -1; im <= 1; ++im) {
-            int cc = c0 + im * T;
-            int s0 = cc - M > done + 1 ? cc - M : done + 1;
-            int e0 = cc + M < hi - 1 ? cc + M : hi - 1;
+            int cc = c0 + im * T, mm = im == 0 ? M : M + 1;
+            int s0 = cc - mm > done + 1 ? cc - mm : done + 1;
+            int e0 = cc + mm < hi - 1 ? cc + mm : hi - 1;
             for (int j = s0; j <= e0; ++j)
                 if (!ref_bad[j]) {
                     float ex = px - rx[j], ey = py - ry[j], d = ex * ex + ey * ey;
@@ -445,6 +448,7 @@ static void orc_debug_nn_check(const orc_param* p, int i, int lo, int hi, float 
         }
         j0 = c0 - M; j1 = c0 + M;
     }
+    jprev[i] = bj2;
     int a1 = bj >= 0 && sqrtf(best) < 100.0f, a2 = bj2 >= 0 && sqrtf(b2) < 100.0f;
     if (a1 != a2 || (a1 && bj != bj2)) {
         orc_debug_nn_mismatches++;
@@ -480,6 +484,8 @@ static int icp_core(const orc_param* p,
     float dx = 0, dy = 0, dth = 0, abs_err = 0;
     int small = 0, status = ORC_OK, n_tail = 0;
     pose_out[0] = act_pose[0]; pose_out[1] = act_pose[1]; pose_out[2] = act_pose[2];
+    int* dbg_jprev = NULL;
+    if (orc_debug_nn) { dbg_jprev = (int*)malloc(sizeof(int) * n); for (int i = 0; i < n; ++i) dbg_jprev[i] = -1; }
 
     int iter = -1;
     while (++iter < Z_ITER_ICP && small < 3) {
@@ -498,7 +504,7 @@ static int icp_core(const orc_param* p,
         /* correspondence search, :1785-1822 */
         int m = 0;
         for (int i = 0; i < n; ++i) {
-            if (new_bad[i]) continue;
+            if (new_bad[i]) { if (dbg_jprev) dbg_jprev[i] = -1; continue; }
             int lo = i - W; if (lo < 0) lo = 0;
             int hi = i + W; if (hi > n) hi = n;
             float best = 1000000;
@@ -509,7 +515,7 @@ static int icp_core(const orc_param* p,
                 float d = ex * ex + ey * ey;
                 if (d < best) { best = d; bj = j; }
             }
-            if (dbg_pr) orc_debug_nn_check(p, i, lo, hi, nx[i], ny[i], rx_, ry_, ref_bad, dbg_pr[i], dbg_pr[n + i], bj, best, iter);
+            if (dbg_pr) orc_debug_nn_check(p, i, lo, hi, nx[i], ny[i], rx_, ry_, ref_bad, dbg_pr[i], dbg_pr[n + i], bj, best, iter, dbg_jprev);
             if (bj >= 0 && sqrtf(best) < (float)Z_MAX_ERROR) {
                 mi[m] = i; mj[m] = bj; dist[m] = sqrtf(best); m++;
             }
@@ -578,7 +584,7 @@ static int icp_core(const orc_param* p,
         pose_out[0] = ax; pose_out[1] = ay; pose_out[2] = ath;
     }
     if (iters_out) *iters_out = iter;
-    free(buf); free(ibuf);
+    free(buf); free(ibuf); free(dbg_jprev);
     return status;
 }
 

@@ -33,6 +33,7 @@ int main(int argc, char** argv)
                 for (uint32_t sign = 0; sign < 2; ++sign) {
                     float x = lsa::u2f((uint32_t)u | (sign << 31));
                     if (!same(lsa::sinf_(x), sinf(x))) { if (bs < 3) fprintf(stderr, "sin %a: %a vs %a\n", x, lsa::sinf_(x), sinf(x)); ++bs; }
+                    { float sn, cs; lsa::sincosf_(x, sn, cs); if (!same(sn, sinf(x)) || !same(cs, cosf(x))) { if (bs < 3) fprintf(stderr, "sincos %a\n", x); ++bs; } }
                     if (!same(lsa::cosf_(x), cosf(x))) { if (bc < 3) fprintf(stderr, "cos %a: %a vs %a\n", x, lsa::cosf_(x), cosf(x)); ++bc; }
                 }
             }
