@@ -397,6 +397,7 @@ static float seg_foot(float x1, float y1, float x2, float y2, float x3, float y3
  * search (laser_slam_amd/csrc/icp_kernel.hip) against the brute-force result. */
 int orc_debug_nn = 0;
 int orc_debug_nn_mismatches = 0;
+long long orc_debug_nn_stats[8];   /* beams, candidates, long lists (>32), whole-window, hist... */
 static void orc_debug_nn_check(const orc_param* p, int i, int lo, int hi, float px, float py,
                                const float* rx, const float* ry, const int* ref_bad,
                                float pr, float pf, int bj, float best, int iter, int* jprev)
@@ -447,6 +448,24 @@ static void orc_debug_nn_check(const orc_param* p, int i, int lo, int hi, float 
             if (e0 > done) done = e0;
         }
         j0 = c0 - M; j1 = c0 + M;
+    }
+    {
+        int len = 0;
+        if (M < 0) len = hi - lo;
+        else {
+            int T = (int)rintf(6.2831853f / p->dfi), done = lo - 1;
+            for (int im = -1; im <= 1; ++im) {
+                int cc = c0 + im * T, mm = im == 0 ? M : M + 1;
+                int s0 = cc - mm > done + 1 ? cc - mm : done + 1;
+                int e0 = cc + mm < hi - 1 ? cc + mm : hi - 1;
+                if (e0 >= s0) len += e0 - s0 + 1;
+                if (e0 > done) done = e0;
+            }
+        }
+        orc_debug_nn_stats[0]++; orc_debug_nn_stats[1] += len;
+        if (len > 32) { orc_debug_nn_stats[2]++; orc_debug_nn_stats[4] += len; }
+        if (M < 0) orc_debug_nn_stats[3]++;
+        if (len <= 8) orc_debug_nn_stats[5]++; else if (len <= 16) orc_debug_nn_stats[6]++; else if (len <= 32) orc_debug_nn_stats[7]++;
     }
     jprev[i] = bj2;
     int a1 = bj >= 0 && sqrtf(best) < 100.0f, a2 = bj2 >= 0 && sqrtf(b2) < 100.0f;
