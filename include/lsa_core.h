@@ -113,6 +113,12 @@ void lsa_host_free(void* h_ptr);
  *      ZHPolar_Match.cpp:861-866, 1495-1639 ---------------------------------- */
 int lsa_preprocess_batch(lsa_ctx* c, int n_scans, float* d_r /*in/out*/,
                          uint8_t* d_bad /*in/out*/, uint16_t* d_seg /*out*/);
+/* the three stages individually (public methods pm_median_filter :1610,
+ * pm_find_far_points :1583, pm_segment_scan :1495); stages = OR of LSA_PRE_* */
+#define LSA_PRE_MEDIAN  1
+#define LSA_PRE_FAR     2
+#define LSA_PRE_SEGMENT 4
+int lsa_preprocess_stages_batch(lsa_ctx* c, int n_scans, float* d_r, uint8_t* d_bad, uint16_t* d_seg, int stages);
 
 /* ---- batched matcher: pm_psm / pm_icp (+ optional pm_error_index2,
  *      ZHPolar_Match.cpp:1279) -------------------------------------------------
@@ -142,6 +148,14 @@ int lsa_scan_project_batch(lsa_ctx* c, int n_scans, const float* d_r, const uint
                            const uint16_t* d_seg, const float* d_pose,
                            float* d_new_r, uint8_t* d_new_bad);
 
+/* pm_orientation_search :1152 (mode 0, d_out4[4b] = dth) and pm_translation_estimation
+ * :1015 (mode 1, d_out4[4b..] = dx, dy, avg_err; weight_c = the C argument) for B items
+ * given as reference rows (r, bad) and projected rows (new_r, new_bad), each [B][N]. */
+int lsa_psm_stage_batch(lsa_ctx* c, int mode, int n_items, float weight_c,
+                        const float* d_ref_r, const uint8_t* d_ref_bad,
+                        const float* d_new_r, const uint8_t* d_new_bad,
+                        float* d_out4, int32_t* d_status);
+
 /* ---- single-pair host convenience (B = 1 of the above, host pointers, int flags
  *      as in struct _PMScan, PolarParameter.h:105-184) --------------------------
  * FMatch semantics (ZHPolar_Match.cpp:81-121): preprocess act (and ref when
@@ -151,6 +165,14 @@ int lsa_fmatch_host(lsa_ctx* c, float* h_ref_r, int32_t* h_ref_bad, int32_t* h_r
                     float* h_act_r, int32_t* h_act_bad, int32_t* h_act_seg, int first,
                     float h_pose_out[3], float h_ret_pair[2]);
 int lsa_preprocess_host(lsa_ctx* c, float* h_r, int32_t* h_bad, int32_t* h_seg);
+int lsa_preprocess_stages_host(lsa_ctx* c, float* h_r, int32_t* h_bad, int32_t* h_seg, int stages);
+int lsa_scan_project_host(lsa_ctx* c, const float* h_r, const int32_t* h_bad, const int32_t* h_seg,
+                          const float h_pose[3], float* h_new_r, int32_t* h_new_bad);
+int lsa_orientation_search_host(lsa_ctx* c, const float* h_ref_r, const int32_t* h_ref_bad,
+                                const float* h_new_r, const int32_t* h_new_bad, float* dth, int32_t* status);
+int lsa_translation_estimation_host(lsa_ctx* c, const float* h_ref_r, const int32_t* h_ref_bad,
+                                    const float* h_new_r, const int32_t* h_new_bad, float weight_c,
+                                    float* dx, float* dy, float* avg_err, int32_t* status);
 int lsa_match_host(lsa_ctx* c, int which,
                    const float* h_ref_r, const int32_t* h_ref_bad, const float h_ref_pose[3],
                    const float* h_act_r, const int32_t* h_act_bad, const int32_t* h_act_seg,

@@ -67,6 +67,12 @@ def lib():
     L.lsa_memset.argtypes = [vp, vp, C.c_int, C.c_uint64]
     L.lsa_carmen_read.argtypes = [C.POINTER(LaserParam), C.c_char_p, C.c_char_p, C.POINTER(C.c_int)] + [C.POINTER(vp)] * 5
     L.lsa_preprocess_batch.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.lsa_preprocess_stages_batch.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
+    L.lsa_preprocess_stages_host.argtypes = [vp, vp, vp, vp, C.c_int]
+    L.lsa_psm_stage_batch.argtypes = [vp, C.c_int, C.c_int, C.c_float] + [vp] * 6
+    L.lsa_scan_project_host.argtypes = [vp] + [vp] * 6
+    L.lsa_orientation_search_host.argtypes = [vp] + [vp] * 6
+    L.lsa_translation_estimation_host.argtypes = [vp] + [vp] * 4 + [C.c_float] + [vp] * 4
     L.lsa_match_batch.argtypes = [vp, C.c_int, C.c_int] + [vp] * 12
     L.lsa_error_index2_batch.argtypes = [vp, C.c_int] + [vp] * 8
     L.lsa_scan_project_batch.argtypes = [vp, C.c_int] + [vp] * 6
@@ -204,6 +210,38 @@ class Context:
         seg = np.zeros(self.n, np.int32)
         check(self.L.lsa_preprocess_host(self.h, _hp(r), _hp(bad), _hp(seg)), "lsa_preprocess_host")
         return r, bad, seg
+
+    def preprocess_stages_host(self, r, bad, seg, stages):
+        r = np.ascontiguousarray(r, np.float32).copy()
+        bad = np.ascontiguousarray(bad, np.int32).copy()
+        seg = np.ascontiguousarray(seg, np.int32).copy()
+        check(self.L.lsa_preprocess_stages_host(self.h, _hp(r), _hp(bad), _hp(seg), stages), "lsa_preprocess_stages_host")
+        return r, bad, seg
+
+    def scan_project_host(self, r, bad, seg, pose):
+        pose = np.ascontiguousarray(pose, np.float32)
+        new_r = np.zeros(self.n, np.float32)
+        new_bad = np.zeros(self.n, np.int32)
+        check(self.L.lsa_scan_project_host(self.h, _hp(r), _hp(bad), _hp(seg), _hp(pose), _hp(new_r), _hp(new_bad)),
+              "lsa_scan_project_host")
+        return new_r, new_bad
+
+    def orientation_search_host(self, ref_r, ref_bad, new_r, new_bad):
+        dth = C.c_float(0)
+        st = C.c_int32(0)
+        check(self.L.lsa_orientation_search_host(self.h, _hp(ref_r), _hp(ref_bad), _hp(new_r), _hp(new_bad),
+                                                 C.cast(C.byref(dth), vp), C.cast(C.byref(st), vp)),
+              "lsa_orientation_search_host")
+        return st.value, dth.value
+
+    def translation_estimation_host(self, ref_r, ref_bad, new_r, new_bad, weight_c=4900.0):
+        dx, dy, err = C.c_float(0), C.c_float(0), C.c_float(0)
+        st = C.c_int32(0)
+        check(self.L.lsa_translation_estimation_host(self.h, _hp(ref_r), _hp(ref_bad), _hp(new_r), _hp(new_bad),
+                                                     weight_c, C.cast(C.byref(dx), vp), C.cast(C.byref(dy), vp),
+                                                     C.cast(C.byref(err), vp), C.cast(C.byref(st), vp)),
+              "lsa_translation_estimation_host")
+        return st.value, dx.value, dy.value, err.value
 
     def match_host(self, which, ref, act, ref_pose=None, act_pose=None):
         rp = None if ref_pose is None else np.ascontiguousarray(ref_pose, np.float32)

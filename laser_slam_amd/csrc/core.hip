@@ -56,7 +56,7 @@ static lsa::DevParam dev_param(const lsa_ctx* c)
 }
 
 static int icp_lds(int n) { return lsa::icp_lds_bytes(n); }
-static int psm_lds(int n) { int Np = (n + 63) & ~63; return 35 * Np; }
+static int psm_lds(int n) { return lsa::psm_lds_bytes(n); }
 static int pre_lds(int n) { int Np = (n + 63) & ~63; return 12 * Np; }
 
 static int check_param(const lsa_laser_param* p)
@@ -266,13 +266,33 @@ int lsa_memset(lsa_ctx* c, void* d, int v, uint64_t bytes)
 }
 
 // ---- launches ---------------------------------------------------------------
-int lsa_preprocess_batch(lsa_ctx* c, int S, float* d_r, uint8_t* d_bad, uint16_t* d_seg)
+int lsa_preprocess_stages_batch(lsa_ctx* c, int S, float* d_r, uint8_t* d_bad, uint16_t* d_seg, int stages)
 {
     if (!c || !d_r || !d_bad || !d_seg) return fail(LSA_E_ARG, "null argument");
+    if ((stages & ~7) || stages == 0) return fail(LSA_E_ARG, "stages must be a non-empty subset of MEDIAN|FAR|SEGMENT");
     if (S <= 0) return LSA_OK;
     HIP_TRY(hipSetDevice(c->device));
     hipLaunchKernelGGL(lsa::preprocess_kernel, dim3(S), dim3(64), pre_lds(c->p.points), c->stream,
-                       dev_param(c), S, d_r, d_bad, d_seg);
+                       dev_param(c), S, d_r, d_bad, d_seg, stages);
+    HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+
+int lsa_preprocess_batch(lsa_ctx* c, int S, float* d_r, uint8_t* d_bad, uint16_t* d_seg)
+{
+    return lsa_preprocess_stages_batch(c, S, d_r, d_bad, d_seg, LSA_PRE_MEDIAN | LSA_PRE_FAR | LSA_PRE_SEGMENT);
+}
+
+// pm_orientation_search (mode 0) / pm_translation_estimation (mode 1) for B (reference row, projected row) items
+int lsa_psm_stage_batch(lsa_ctx* c, int mode, int B, float weight_c, const float* d_ref_r, const uint8_t* d_ref_bad,
+                        const float* d_new_r, const uint8_t* d_new_bad, float* d_out4, int32_t* d_status)
+{
+    if (!c || !d_ref_r || !d_ref_bad || !d_new_r || !d_new_bad || !d_out4 || !d_status) return fail(LSA_E_ARG, "null argument");
+    if (mode != 0 && mode != 1) return fail(LSA_E_ARG, "mode must be 0 (orientation) or 1 (translation)");
+    if (B <= 0) return LSA_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(lsa::psm_stage_kernel, dim3(B), dim3(lsa::PSM_THREADS), psm_lds(c->p.points), c->stream,
+                       dev_param(c), B, mode, weight_c, d_ref_r, d_ref_bad, d_new_r, d_new_bad, d_out4, d_status);
     HIP_TRY(hipGetLastError());
     return LSA_OK;
 }
@@ -293,7 +313,7 @@ int lsa_match_batch(lsa_ctx* c, int which, int B,
         hipLaunchKernelGGL(lsa::icp_kernel, dim3(B), dim3(lsa::ICP_THREADS), icp_lds(P.n), c->stream, P, B, d_r, d_bad, d_seg,
                            d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters);
     else
-        hipLaunchKernelGGL(lsa::psm_kernel, dim3(B), dim3(64), psm_lds(P.n), c->stream, P, B, d_r, d_bad, d_seg,
+        hipLaunchKernelGGL(lsa::psm_kernel, dim3(B), dim3(lsa::PSM_THREADS), psm_lds(P.n), c->stream, P, B, d_r, d_bad, d_seg,
                            d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters);
     HIP_TRY(hipGetLastError());
     return LSA_OK;
@@ -338,14 +358,78 @@ static int unstage_scan(lsa_ctx* c, int slot, float* r, int32_t* bad, int32_t* s
     return LSA_OK;
 }
 
-int lsa_preprocess_host(lsa_ctx* c, float* r, int32_t* bad, int32_t* seg)
+int lsa_preprocess_stages_host(lsa_ctx* c, float* r, int32_t* bad, int32_t* seg, int stages)
 {
     if (!c || !r || !bad || !seg) return fail(LSA_E_ARG, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_staging(c); if (rc) return rc;
-    rc = stage_scan(c, 0, r, bad, nullptr); if (rc) return rc;
-    rc = lsa_preprocess_batch(c, 1, c->d_r, c->d_bad, c->d_seg); if (rc) return rc;
+    rc = stage_scan(c, 0, r, bad, seg); if (rc) return rc;
+    rc = lsa_preprocess_stages_batch(c, 1, c->d_r, c->d_bad, c->d_seg, stages); if (rc) return rc;
     return unstage_scan(c, 0, r, bad, seg);
+}
+
+int lsa_preprocess_host(lsa_ctx* c, float* r, int32_t* bad, int32_t* seg)
+{
+    return lsa_preprocess_stages_host(c, r, bad, seg, LSA_PRE_MEDIAN | LSA_PRE_FAR | LSA_PRE_SEGMENT);
+}
+
+// pm_scan_project for one host scan (new_bad as int, like the reference's signature)
+int lsa_scan_project_host(lsa_ctx* c, const float* r, const int32_t* bad, const int32_t* seg, const float pose[3],
+                          float* new_r, int32_t* new_bad)
+{
+    if (!c || !r || !pose || !new_r || !new_bad) return fail(LSA_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_staging(c); if (rc) return rc;
+    const int n = c->p.points;
+    rc = stage_scan(c, 1, r, bad, seg); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_small, pose, 12, hipMemcpyHostToDevice, c->stream));
+    rc = lsa_scan_project_batch(c, 1, c->d_r + n, c->d_bad + n, c->d_seg + n, c->d_small, c->d_r, c->d_bad);
+    if (rc) return rc;
+    std::vector<uint8_t> b8(n);
+    HIP_TRY(hipMemcpyAsync(new_r, c->d_r, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(b8.data(), c->d_bad, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i) new_bad[i] = b8[i];
+    return LSA_OK;
+}
+
+static int psm_stage_host(lsa_ctx* c, int mode, float Cw, const float* ref_r, const int32_t* ref_bad,
+                          const float* new_r, const int32_t* new_bad, float out[4], int32_t* status)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_staging(c); if (rc) return rc;
+    const int n = c->p.points;
+    rc = stage_scan(c, 0, ref_r, ref_bad, nullptr); if (rc) return rc;
+    rc = stage_scan(c, 1, new_r, new_bad, nullptr); if (rc) return rc;
+    rc = lsa_psm_stage_batch(c, mode, 1, Cw, c->d_r, c->d_bad, c->d_r + n, c->d_bad + n, c->d_small + 12, c->d_ismall + 3);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->d_small + 12, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(status, c->d_ismall + 3, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LSA_OK;
+}
+
+int lsa_orientation_search_host(lsa_ctx* c, const float* ref_r, const int32_t* ref_bad, const float* new_r,
+                                const int32_t* new_bad, float* dth, int32_t* status)
+{
+    if (!c || !ref_r || !new_r || !dth || !status) return fail(LSA_E_ARG, "null argument");
+    float out[4];
+    int rc = psm_stage_host(c, 0, 0.0f, ref_r, ref_bad, new_r, new_bad, out, status);
+    if (rc) return rc;
+    *dth = out[0];
+    return LSA_OK;
+}
+
+int lsa_translation_estimation_host(lsa_ctx* c, const float* ref_r, const int32_t* ref_bad, const float* new_r,
+                                    const int32_t* new_bad, float weight_c, float* dx, float* dy, float* avg_err,
+                                    int32_t* status)
+{
+    if (!c || !ref_r || !new_r || !dx || !dy || !avg_err || !status) return fail(LSA_E_ARG, "null argument");
+    float out[4];
+    int rc = psm_stage_host(c, 1, weight_c, ref_r, ref_bad, new_r, new_bad, out, status);
+    if (rc) return rc;
+    *dx = out[0]; *dy = out[1]; *avg_err = out[2];
+    return LSA_OK;
 }
 
 static int run_pair(lsa_ctx* c, int which, const float* ref_pose, const float* act_pose, bool want_err,

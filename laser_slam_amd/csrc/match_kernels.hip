@@ -194,176 +194,7 @@ __device__ void error_index2_tail(const DevParam& P, const Lds& L, float* exy, i
 
 #include "icp_kernel.hip"
 
-// ---------------------------------------------------------------------------
-// PSM kernel.
-//   orientation search (:1152-1261): lane k accumulates the shift di = k - W in
-//   beam order (each lane owns whole shifts, so the order is the reference's);
-//   translation estimation (:1015-1131): the six ordered sums run in lanes 0..5.
-__global__ __launch_bounds__(64) void psm_kernel(
-    DevParam P, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
-    const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
-    const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
-    float* __restrict__ err_xy, int* __restrict__ n_assoc, int* __restrict__ status_out, int* __restrict__ iters_out)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int N = P.n, Np = (N + 63) & ~63, W = P.window, lane = lane_id();
-    const Lds L = carve_psm(smem, Np);
-    const int K = 2 * W + 1;                 // K <= Np is checked by the launcher
-    float* err = L.err;
-    // translation terms reuse the projection scratch (dead once new_r/new_bad are unpacked)
-    float* const term0 = L.pr; float* const term1 = L.pf;
-    float* const term2 = (float*)L.key; float* const term3 = (float*)L.key + Np;
-    float* const term4 = L.err; float* const term5 = L.new_r;
-
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        const size_t ro = (size_t)ref_idx[b] * N, ao = (size_t)act_idx[b] * N;
-        __syncthreads();
-        for (int i = lane; i < N; i += WAVE) {
-            L.ref_r[i] = g_r[ro + i];
-            L.ref_bad[i] = g_bad[ro + i];
-            L.act_r[i] = g_r[ao + i];
-            uint8_t ok = 0;
-            if (i >= 1) {
-                uint16_t s1 = g_seg[ao + i], s0 = g_seg[ao + i - 1];
-                ok = (s1 != 0 && s1 == s0 && g_bad[ao + i] == 0 && g_bad[ao + i - 1] == 0) ? 1 : 0;
-            }
-            L.pair_ok[i] = ok;
-        }
-        float ax, ay, ath;
-        rel_pose(init_pose ? init_pose + 6 * (size_t)b : nullptr, ax, ay, ath);
-        const float ax0 = init_pose ? init_pose[6 * (size_t)b + 3] : 0.0f;
-        const float ay0 = init_pose ? init_pose[6 * (size_t)b + 4] : 0.0f;
-        const float ath0 = init_pose ? init_pose[6 * (size_t)b + 5] : 0.0f;
-        const float C = LSA_WEIGHT;
-        float dx = 0, dy = 0, dth = 0, avg = 100000000.0f;
-        int small = 0, status = LSA_ST_OK;
-        __syncthreads();
-
-        int iter = -1;
-        while (++iter < LSA_ITER_PSM && small < 3) {
-            if ((double)(fabsf_(dx) + fabsf_(dy) + fabsf_(dth)) < LSA_STOP_PSM) small++; else small = 0;   // :933
-
-            scan_project(P, L, ax, ay, ath);
-            // unpack the keys into new_r / new_bad (A region is free again)
-            for (int i = lane; i < N; i += WAVE) {
-                unsigned long long k = L.key[i];
-                L.new_r[i] = key_r(k);
-                L.new_bad[i] = (uint8_t)key_bad(k);
-            }
-            __syncthreads();
-
-            if ((iter & 1) == 0) {
-                // ---- orientation search ----
-                for (int k = lane; k < K; k += WAVE) {
-                    const int di = k - W;
-                    const int lo = di <= 0 ? -di : 0, hi = di <= 0 ? N : N - di;
-                    float e = 0.0f, cnt = 0.0f;
-                    for (int i = lo; i < hi; ++i) {
-                        float delta = fabsf_(L.new_r[i] - L.ref_r[i + di]);
-                        if (L.new_bad[i] == 0 && L.ref_bad[i + di] == 0) { e += delta; cnt += 1.0f; }
-                    }
-                    err[k] = cnt > 0.0f ? e / cnt : 10000.0f;
-                }
-                __syncthreads();
-                // first strict minimum (:1225-1234): wave arg-min on (err, k)
-                float bm = 100000.0f;
-                int bk = -1;
-                for (int k = lane; k < K; k += WAVE) {
-                    float e = err[k];
-                    if (e < bm) { bm = e; bk = k; }
-                }
-                for (int off = 32; off >= 1; off >>= 1) {
-                    float om = __shfl_xor(bm, off);
-                    int ok = __shfl_xor(bk, off);
-                    bool take = (ok >= 0) && (bk < 0 || om < bm || (om == bm && ok < bk));
-                    if (take) { bm = om; bk = ok; }
-                }
-                const int imin = bk;
-                if (imin < 0 || err[imin] >= 10000.0f) { status = LSA_ST_NO_ORIENT; break; }   // :1236-1240
-                dth = (float)(imin - W) * P.dfi;                                             // :1241
-                if (imin >= 1 && imin < K - 1) {
-                    const float em = err[imin - 1], e0 = err[imin], ep = err[imin + 1];
-                    float D = (float)((double)(em + ep) - 2.0 * (double)e0);
-                    float d = 10000.0f;
-                    if ((double)fabsf_(D) > 0.01 && em > e0 && ep > e0) d = (float)((double)((em - ep) / D) / 2.0);
-                    if (fabsf_(d) < 1.0f) dth += d * P.dfi;
-                }
-                ath += dth;
-                __syncthreads();
-                continue;
-            }
-
-            // ---- translation estimation ----
-            // per-beam terms in parallel (zero when the beam is gated out: adding
-            // +0.0f leaves an ordered FP32 sum unchanged), then six ordered sums.
-            int cnt = 0;
-            for (int base = 0; base < N; base += WAVE) {
-                const int i = base + lane;
-                bool ok = false;
-                if (i < N) {
-                    float nr = L.new_r[i];
-                    float dr = L.ref_r[i] - nr;
-                    ok = L.ref_bad[i] == 0 && L.new_bad[i] == 0 && nr < (float)P.max_range &&
-                         nr > LSA_MIN_RANGE && fabsf_(dr) < LSA_MAX_ERROR;                 // :1034
-                    float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-                    if (ok) {
-                        float w = C / (dr * dr + C);
-                        float c = P.co[i], s = P.si[i];
-                        float wc = c * w, ws = s * w;
-                        t0 = wc * dr; t1 = ws * dr; t2 = wc * c; t3 = wc * s; t4 = ws * s;
-                    }
-                    term0[i] = t0; term1[i] = t1; term2[i] = t2;
-                    term3[i] = t3; term4[i] = t4; term5[i] = fabsf_(dr);
-                }
-                cnt += __popcll(__ballot(ok));
-            }
-            __syncthreads();
-            float acc = 0.0f;
-            if (lane < 6) {
-                const float* tp = lane == 0 ? term0 : lane == 1 ? term1 : lane == 2 ? term2
-                                : lane == 3 ? term3 : lane == 4 ? term4 : term5;
-                for (int i = 0; i < N; ++i) acc += tp[i];
-            }
-            const float hw1 = __shfl(acc, 0), hw2 = __shfl(acc, 1), h11 = __shfl(acc, 2),
-                        h12 = __shfl(acc, 3), h22 = __shfl(acc, 4), abs_err = __shfl(acc, 5);
-            __syncthreads();
-            if (cnt < P.min_valid) { status = LSA_ST_FEW_POINTS; break; }                  // :1089
-            const float D = h11 * h22 - h12 * 0.0f;                                         // :1102 (hwh21 == 0)
-            if ((double)D < 0.001) { status = LSA_ST_SINGULAR; break; }                    // :1103
-            const float i11 = h22 / D, i12 = -h12 / D, i21 = -h12 / D, i22 = h11 / D;
-            dx = i11 * hw1 + i12 * hw2;
-            dy = i21 * hw1 + i22 * hw2;
-            avg = abs_err / (float)cnt;
-            ax += dx;
-            ay += dy;
-        }
-
-        if (lane == 0) {
-            const bool ok = status == LSA_ST_OK;
-            pose_out[3 * (size_t)b + 0] = ok ? ax : ax0;
-            pose_out[3 * (size_t)b + 1] = ok ? ay : ay0;
-            pose_out[3 * (size_t)b + 2] = ok ? ath : ath0;
-            if (ret_out) ret_out[b] = ok ? avg : 0.0f;
-            if (status_out) status_out[b] = status;
-            if (iters_out) iters_out[b] = iter;
-        }
-        if (err_xy) {
-            __syncthreads();
-            if (status == LSA_ST_OK) {
-                float ex, ey, eth;
-                if (init_pose) {
-                    float ip[6] = {init_pose[6 * (size_t)b], init_pose[6 * (size_t)b + 1], init_pose[6 * (size_t)b + 2], ax, ay, ath};
-                    rel_pose(ip, ex, ey, eth);
-                } else { ex = ax; ey = ay; eth = ath; }
-                scan_project(P, L, ex, ey, eth);
-                error_index2_tail(P, L, err_xy + 2 * (size_t)b, n_assoc ? n_assoc + b : nullptr);
-            } else if (lane < 2) {
-                err_xy[2 * (size_t)b + lane] = -1.0f;
-                if (lane == 0 && n_assoc) n_assoc[b] = 0;
-            }
-        }
-    }
-}
+#include "psm_kernel.hip"
 
 // ---------------------------------------------------------------------------
 // Stand-alone pm_error_index2 (:1279-1339), one wave per pair, at the poses given
@@ -436,7 +267,7 @@ __global__ __launch_bounds__(64) void project_kernel(
 // a run-length state machine: both are recurrences along the beam index, so one
 // lane walks the scan (staged in LDS); the far test is per beam.
 __global__ __launch_bounds__(64) void preprocess_kernel(
-    DevParam P, int S, float* __restrict__ g_r, uint8_t* __restrict__ g_bad, uint16_t* __restrict__ g_seg)
+    DevParam P, int S, float* __restrict__ g_r, uint8_t* __restrict__ g_bad, uint16_t* __restrict__ g_seg, int stages)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = P.n, Np = (N + 63) & ~63, lane = lane_id();
@@ -446,9 +277,9 @@ __global__ __launch_bounds__(64) void preprocess_kernel(
     for (int s = blockIdx.x; s < S; s += gridDim.x) {
         const size_t so = (size_t)s * N;
         __syncthreads();
-        for (int i = lane; i < N; i += WAVE) { r[i] = g_r[so + i]; bad[i] = g_bad[so + i]; seg[i] = 0; }
+        for (int i = lane; i < N; i += WAVE) { r[i] = g_r[so + i]; bad[i] = g_bad[so + i]; seg[i] = (stages & 4) ? 0 : g_seg[so + i]; }
         __syncthreads();
-        if (lane == 0) {
+        if (lane == 0 && (stages & 1)) {
             for (int i = 0; i < N; ++i) {
                 float w[5];
                 #pragma unroll
@@ -466,10 +297,11 @@ __global__ __launch_bounds__(64) void preprocess_kernel(
             }
         }
         __syncthreads();
-        for (int i = lane; i < N; i += WAVE)
-            if (r[i] > (float)P.max_range) bad[i] |= 1;
+        if (stages & 2)
+            for (int i = lane; i < N; i += WAVE)
+                if (r[i] > (float)P.max_range) bad[i] |= 1;
         __syncthreads();
-        if (lane == 0) {
+        if (lane == 0 && (stages & 4)) {
             const float lim = LSA_SEG_MAX_DIST;
             int id = 1, run;
             if (fabsf_(r[0] - r[1]) < lim) { seg[0] = id; seg[1] = id; run = 2; }

@@ -1,0 +1,274 @@
+// pm_psm (src/zhpsm/ZHPolar_Match.cpp:890-1003) on gfx950, included from
+// match_kernels.hip inside namespace lsa (after icp_kernel.hip).
+//
+// One 256-thread workgroup per scan pair.
+//   orientation search (:1152-1261): thread k owns the shift di = k - W and accumulates
+//     |new_r[i] - ref_r[i+di]| in beam order, so every sum has the reference's order.  The
+//     validity tests are folded into the data: invalid readings are stored as NaN (and the
+//     reference row is NaN-padded by W on both sides), so a term counts iff it is not NaN and
+//     all threads run the same loop with no bounds or flag tests;
+//   translation estimation (:1015-1131): per-beam terms in parallel, six ordered sums in
+//     six lanes.
+//
+// LDS (Np = N rounded up to 64; 35 Np bytes + 64):
+//   [ 0, 4) ref_r   [ 4, 8) act_r   [ 8,24) projection scratch (pr, pf, u64 keys)
+//                                     -> NaN-masked rows for the orientation search
+//                                     -> translation terms 0..3
+//   [24,28) new_r -> |dr| term   [28,32) err[2W+1] -> term 4
+//   [32,33) ref_bad  [33,34) pair_ok  [34,35) new_bad
+
+constexpr int PSM_THREADS = 256;
+
+__host__ __device__ inline int psm_lds_bytes(int n) { int Np = (n + 63) & ~63; return 35 * Np + 64; }
+
+// NaN-masked rows: nrm[i] = new_r or NaN; rfm[W + j] = ref_r[j] or NaN, NaN outside [0,N)
+__device__ __forceinline__ void build_masked_rows(const DevParam& P, const Lds& L, float* nrm, float* rfm)
+{
+    const int N = P.n, W = P.window;
+    const float qnan = u2f(0x7fc00000u);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) nrm[i] = L.new_bad[i] ? qnan : L.new_r[i];
+    for (int j = threadIdx.x; j < N + 2 * W + 4; j += blockDim.x) {
+        const int src = j - W;
+        rfm[j] = (src >= 0 && src < N && L.ref_bad[src] == 0) ? L.ref_r[src] : qnan;
+    }
+}
+
+// pm_orientation_search (:1152-1261) on L.new_r/new_bad vs L.ref_r/ref_bad.  Whole
+// workgroup; returns the status, dth by reference.  Uses pr/pf/key as scratch.
+__device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, volatile float* bc)
+{
+    const int N = P.n, W = P.window, K = 2 * W + 1, tid = threadIdx.x;
+    float* nrm = L.pr;                 // N floats (the pr row)
+    float* rfm = L.pf;                 // N + 2W + 4 floats (pf row + the key rows)
+    float* err = L.err;
+    build_masked_rows(P, L, nrm, rfm);
+    __syncthreads();
+    for (int k = tid; k < K; k += blockDim.x) {
+        const float* rb = rfm + k;                  // rfm[W + i + di] with di = k - W
+        float e = 0.0f, cnt = 0.0f;
+        int i = 0;
+        for (; i + 4 <= N; i += 4) {
+            const float4 a = *(const float4*)(nrm + i);
+            const float b0 = rb[i], b1 = rb[i + 1], b2 = rb[i + 2], b3 = rb[i + 3];
+            float d;
+            d = fabsf_(a.x - b0); if (d == d) { e += d; cnt += 1.0f; }
+            d = fabsf_(a.y - b1); if (d == d) { e += d; cnt += 1.0f; }
+            d = fabsf_(a.z - b2); if (d == d) { e += d; cnt += 1.0f; }
+            d = fabsf_(a.w - b3); if (d == d) { e += d; cnt += 1.0f; }
+        }
+        for (; i < N; ++i) {
+            const float d = fabsf_(nrm[i] - rb[i]);
+            if (d == d) { e += d; cnt += 1.0f; }
+        }
+        err[k] = cnt > 0.0f ? e / cnt : 10000.0f;                                     // :1203-1206
+    }
+    __syncthreads();
+    // first strict minimum (:1225-1234): arg-min on (err, k) by wave 0
+    if (tid < WAVE) {
+        float bm = 100000.0f;
+        int bk = -1;
+        for (int k = tid; k < K; k += WAVE) {
+            const float e = err[k];
+            if (e < bm) { bm = e; bk = k; }
+        }
+        #pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float om = __shfl_xor(bm, off);
+            const int ok = __shfl_xor(bk, off);
+            const bool take = (ok >= 0) && (bk < 0 || om < bm || (om == bm && ok < bk));
+            if (take) { bm = om; bk = ok; }
+        }
+        if (tid == 0) ((volatile int*)bc)[0] = bk;
+    }
+    __syncthreads();
+    const int imin = ((volatile int*)bc)[0];
+    if (imin < 0 || err[imin] >= 10000.0f) return LSA_ST_NO_ORIENT;                    // :1236-1240
+    dth = (float)(imin - W) * P.dfi;                                                  // :1241
+    if (imin >= 1 && imin < K - 1) {                                                  // :1244-1254
+        const float em = err[imin - 1], e0 = err[imin], ep = err[imin + 1];
+        const float D = (float)((double)(em + ep) - 2.0 * (double)e0);
+        float d = 10000.0f;
+        if ((double)fabsf_(D) > 0.01 && em > e0 && ep > e0) d = (float)((double)((em - ep) / D) / 2.0);
+        if (fabsf_(d) < 1.0f) dth += d * P.dfi;
+    }
+    return LSA_ST_OK;
+}
+
+// pm_translation_estimation (:1015-1131) on L.new_r/new_bad vs L.ref_r/ref_bad.
+// Per-beam terms in parallel (zero when the beam is gated out: adding +0.0f leaves an
+// ordered FP32 sum unchanged), then six ordered sums.  Destroys new_r and err.
+__device__ int translation_estimation(const DevParam& P, const Lds& L, float C, float& dx, float& dy, float& avg,
+                                      volatile float* bc)
+{
+    const int N = P.n, Np = (N + 63) & ~63, tid = threadIdx.x;
+    float* const term[6] = {L.pr, L.pf, (float*)L.key, (float*)L.key + Np, L.err, L.new_r};
+    int mine = 0;
+    for (int i = tid; i < Np; i += blockDim.x) {
+        float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+        if (i < N) {
+            const float nr = L.new_r[i];
+            const float dr = L.ref_r[i] - nr;
+            const bool ok = L.ref_bad[i] == 0 && L.new_bad[i] == 0 && nr < (float)P.max_range &&
+                            nr > LSA_MIN_RANGE && fabsf_(dr) < LSA_MAX_ERROR;          // :1034
+            if (ok) {
+                const float w = C / (dr * dr + C);
+                const float c = P.co[i], s = P.si[i];
+                const float wc = c * w, ws = s * w;
+                t0 = wc * dr; t1 = ws * dr; t2 = wc * c; t3 = wc * s; t4 = ws * s;
+                mine++;
+            }
+            t5 = fabsf_(dr);
+        }
+        term[0][i] = t0; term[1][i] = t1; term[2][i] = t2; term[3][i] = t3; term[4][i] = t4; term[5][i] = t5;
+    }
+    // number of gated-in beams
+    const int wave = tid >> 6;
+    int wsum = mine;
+    #pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) wsum += __shfl_xor(wsum, off);
+    if (lane_id() == 0) ((volatile int*)bc)[8 + wave] = wsum;
+    __syncthreads();
+    int cnt = 0;
+    for (unsigned w = 0; w < (blockDim.x >> 6); ++w) cnt += ((volatile int*)bc)[8 + w];
+    if (tid < 6) bc[tid] = ordered_sum(term[tid], N);
+    __syncthreads();
+    const float hw1 = bc[0], hw2 = bc[1], h11 = bc[2], h12 = bc[3], h22 = bc[4], abs_err = bc[5];
+    __syncthreads();
+    if (cnt < P.min_valid) return LSA_ST_FEW_POINTS;                                   // :1089
+    const float D = h11 * h22 - h12 * 0.0f;                                           // :1102 (hwh21 == 0)
+    if ((double)D < 0.001) return LSA_ST_SINGULAR;                                     // :1103
+    const float i11 = h22 / D, i12 = -h12 / D, i21 = -h12 / D, i22 = h11 / D;
+    dx = i11 * hw1 + i12 * hw2;
+    dy = i21 * hw1 + i22 * hw2;
+    avg = abs_err / (float)cnt;
+    return LSA_ST_OK;
+}
+
+__device__ __forceinline__ void unpack_projection(const DevParam& P, const Lds& L)
+{
+    for (int i = threadIdx.x; i < P.n; i += blockDim.x) {
+        const unsigned long long k = L.key[i];
+        L.new_r[i] = key_r(k);
+        L.new_bad[i] = (uint8_t)key_bad(k);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void load_pair_psm(const DevParam& P, const Lds& L, const float* g_r, const uint8_t* g_bad,
+                                              const uint16_t* g_seg, size_t ro, size_t ao)
+{
+    const int N = P.n;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        L.ref_r[i] = g_r[ro + i];
+        L.ref_bad[i] = g_bad[ro + i];
+        L.act_r[i] = g_r[ao + i];
+        uint8_t ok = 0;
+        if (i >= 1) {
+            uint16_t s1 = g_seg[ao + i], s0 = g_seg[ao + i - 1];
+            ok = (s1 != 0 && s1 == s0 && g_bad[ao + i] == 0 && g_bad[ao + i - 1] == 0) ? 1 : 0;   // :1396
+        }
+        L.pair_ok[i] = ok;
+    }
+}
+
+__global__ __launch_bounds__(PSM_THREADS, 4) void psm_kernel(
+    DevParam P, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
+    const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
+    const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
+    float* __restrict__ err_xy, int* __restrict__ n_assoc, int* __restrict__ status_out, int* __restrict__ iters_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = P.n, Np = (N + 63) & ~63, tid = threadIdx.x;
+    const Lds L = carve_psm(smem, Np);
+    volatile float* bc = (volatile float*)(smem + 35 * Np);
+
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const size_t ro = (size_t)ref_idx[b] * N, ao = (size_t)act_idx[b] * N;
+        __syncthreads();
+        load_pair_psm(P, L, g_r, g_bad, g_seg, ro, ao);
+        float ax, ay, ath;
+        rel_pose(init_pose ? init_pose + 6 * (size_t)b : nullptr, ax, ay, ath);
+        const float ax0 = init_pose ? init_pose[6 * (size_t)b + 3] : 0.0f;
+        const float ay0 = init_pose ? init_pose[6 * (size_t)b + 4] : 0.0f;
+        const float ath0 = init_pose ? init_pose[6 * (size_t)b + 5] : 0.0f;
+        const float C = LSA_WEIGHT;      // `C /= 50` at iter == 10 (:973) is dead code: 10 is even
+        float dx = 0, dy = 0, dth = 0, avg = 100000000.0f;
+        int small = 0, status = LSA_ST_OK;
+        __syncthreads();
+
+        int iter = -1;
+        while (++iter < LSA_ITER_PSM && small < 3) {
+            if ((double)(fabsf_(dx) + fabsf_(dy) + fabsf_(dth)) < LSA_STOP_PSM) small++; else small = 0;   // :933
+            scan_project(P, L, ax, ay, ath);
+            unpack_projection(P, L);
+            if ((iter & 1) == 0) {
+                status = orientation_search(P, L, dth, bc);
+                if (status) break;
+                ath += dth;
+                __syncthreads();
+                continue;
+            }
+            status = translation_estimation(P, L, C, dx, dy, avg, bc);
+            if (status) break;
+            ax += dx;
+            ay += dy;
+        }
+
+        if (tid == 0) {
+            const bool ok = status == LSA_ST_OK;
+            pose_out[3 * (size_t)b + 0] = ok ? ax : ax0;
+            pose_out[3 * (size_t)b + 1] = ok ? ay : ay0;
+            pose_out[3 * (size_t)b + 2] = ok ? ath : ath0;
+            if (ret_out) ret_out[b] = ok ? avg : 0.0f;
+            if (status_out) status_out[b] = status;
+            if (iters_out) iters_out[b] = iter;
+        }
+        if (err_xy) {
+            __syncthreads();
+            if (status == LSA_ST_OK) {
+                float ex, ey, eth;
+                if (init_pose) {
+                    float ip[6] = {init_pose[6 * (size_t)b], init_pose[6 * (size_t)b + 1], init_pose[6 * (size_t)b + 2], ax, ay, ath};
+                    rel_pose(ip, ex, ey, eth);
+                } else { ex = ax; ey = ay; eth = ath; }
+                scan_project(P, L, ex, ey, eth);
+                error_index2_tail(P, L, err_xy + 2 * (size_t)b, n_assoc ? n_assoc + b : nullptr);
+            } else if (tid < 2) {
+                err_xy[2 * (size_t)b + tid] = -1.0f;
+                if (tid == 0 && n_assoc) n_assoc[b] = 0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Stand-alone stages (public methods of CPolarMatch): one workgroup per item.
+//   mode 0: pm_orientation_search      out[4b..] = {dth, -, -, -}
+//   mode 1: pm_translation_estimation  out[4b..] = {dx, dy, avg_err, -}
+// Inputs are reference-scan rows (r, bad) and projected rows (new_r, new_bad).
+__global__ __launch_bounds__(PSM_THREADS, 4) void psm_stage_kernel(
+    DevParam P, int B, int mode, float Cw, const float* __restrict__ ref_r, const uint8_t* __restrict__ ref_bad,
+    const float* __restrict__ new_r, const uint8_t* __restrict__ new_bad, float* __restrict__ out, int* __restrict__ status_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = P.n, Np = (N + 63) & ~63, tid = threadIdx.x;
+    const Lds L = carve_psm(smem, Np);
+    volatile float* bc = (volatile float*)(smem + 35 * Np);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const size_t o = (size_t)b * N;
+        __syncthreads();
+        for (int i = tid; i < N; i += blockDim.x) {
+            L.ref_r[i] = ref_r[o + i]; L.ref_bad[i] = ref_bad[o + i];
+            L.new_r[i] = new_r[o + i]; L.new_bad[i] = new_bad[o + i];
+        }
+        __syncthreads();
+        float a = 0, c = 0, d = 0;
+        int st;
+        if (mode == 0) st = orientation_search(P, L, a, bc);
+        else st = translation_estimation(P, L, Cw, a, c, d, bc);
+        if (tid == 0) {
+            out[4 * b] = a; out[4 * b + 1] = c; out[4 * b + 2] = d; out[4 * b + 3] = 0.0f;
+            status_out[b] = st;
+        }
+    }
+}

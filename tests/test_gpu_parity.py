@@ -110,6 +110,36 @@ def test_scan_project(name, torch_mod):
 
 
 @pytest.mark.parametrize("name", list(SETS))
+def test_psm_stages_host_api(name, torch_mod):
+    """pm_scan_project / pm_orientation_search / pm_translation_estimation / single
+    preprocess stages through the host entry points the drop-in classes use."""
+    g = load(name)
+    ctx, _ = make_ctx(name, g)
+    for t, k in enumerate(g["stage_idx"]):
+        act = (g["pre_r"][k], g["pre_bad"][k], g["pre_seg"][k])
+        nr, nb = ctx.scan_project_host(*act, g["stage_pose"][t])
+        assert same_bits(nr, g["stage_new_r"][t]) and np.array_equal(nb, g["stage_new_bad"][t])
+        st, dth = ctx.orientation_search_host(g["pre_r"][k - 1], g["pre_bad"][k - 1], nr, nb)
+        assert (st != 0) == (g["stage_orient"][t, 0] != 0)
+        if st == 0:
+            assert np.float32(dth) == g["stage_orient"][t, 1]
+        st, dx, dy, err = ctx.translation_estimation_host(g["pre_r"][k - 1], g["pre_bad"][k - 1], nr, nb)
+        assert (st != 0) == (g["stage_trans"][t, 0] != 0)
+        if st == 0:
+            assert same_bits(np.array([dx, dy, err], np.float32), g["stage_trans"][t, 1:])
+    n = g["raw_r"].shape[1]
+    z = np.zeros(n, np.int32)
+    for k in range(g["median_only"].shape[0]):
+        r, bad, seg = ctx.preprocess_stages_host(g["raw_r"][k], g["raw_bad"][k], z, 1)      # median only
+        assert same_bits(r, g["median_only"][k]) and np.array_equal(bad, g["raw_bad"][k])
+        r2, bad2, seg2 = ctx.preprocess_stages_host(r, bad, z, 2)                            # far only
+        assert same_bits(r2, r) and np.array_equal(bad2, g["pre_bad"][k])
+        r3, bad3, seg3 = ctx.preprocess_stages_host(r2, bad2, z, 4)                          # segment only
+        assert np.array_equal(seg3, g["pre_seg"][k]) and np.array_equal(bad3, bad2)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", list(SETS))
 @pytest.mark.parametrize("which", [0, 1])
 def test_match_vs_golden(name, which, torch_mod):
     torch = torch_mod
