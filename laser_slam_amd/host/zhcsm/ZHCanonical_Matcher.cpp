@@ -1,0 +1,142 @@
+#include "ZHCanonical_Matcher.h"
+#include "../zhpsm/PolarParameter.h"
+#include "lsa_core.h"
+#include <iostream>
+#include <stdexcept>
+
+namespace {
+void must(int rc, const char* what)
+{
+    if (rc != LSA_OK) throw std::runtime_error(std::string(what) + ": " + lsa_last_error());
+}
+lsa_laser_param toCore(const Base_PARAM* p)
+{
+    lsa_laser_param c;
+    c.points = p->pm_l_points; c.fov_deg = p->pm_fov; c.max_range = p->pm_max_range;
+    c.min_range = p->pm_min_range; c.min_valid = p->pm_min_valid_points; c.window = p->pm_scan_window;
+    c.fi_min = p->pm_fi_min; c.fi_max = p->pm_fi_max; c.dfi = p->pm_dfi;
+    return c;
+}
+}
+
+// The constructor is O(parameter block): the reference builds one matcher per pose node
+// (FlirterNode.cpp:75,103,132), so no device resource is touched until the first match.
+CCanonicalMatcher::CCanonicalMatcher(struct _PARAM* p)
+    : threshold_angular_(0.17f), threshold_dist_sq_(0.25f), m_pParam(p), pm_fi(0), pm_si(0), pm_co(0),
+      m_ctx(0), m_pKeyframe(0), m_ownParam(false), m_doCov(false)
+{
+    if (m_pParam == 0) { m_pParam = new _PM_SICK_LMS151; m_ownParam = true; }   // ZHCanonical_Matcher.cpp ctor default
+    for (int i = 0; i < 9; ++i) m_cov[i] = 0;
+    pm_init();
+}
+
+CCanonicalMatcher::~CCanonicalMatcher()
+{
+    delete[] pm_fi; delete[] pm_si; delete[] pm_co;
+    delete m_pKeyframe;
+    if (m_ctx) lsa_ctx_destroy(m_ctx);
+    if (m_ownParam) delete m_pParam;
+}
+
+void CCanonicalMatcher::pm_init()
+{
+    const int n = m_pParam->pm_l_points;
+    delete[] pm_fi; delete[] pm_si; delete[] pm_co;
+    pm_fi = new float[n]; pm_si = new float[n]; pm_co = new float[n];
+    lsa_laser_param c = toCore(m_pParam);
+    lsa_param_tables(&c, pm_fi, pm_si, pm_co);
+}
+
+void CCanonicalMatcher::sm_init(struct _PARAM* p) { if (p) { m_pParam = p; pm_init(); } }
+void CCanonicalMatcher::setCov(bool b) { m_doCov = b; }
+void CCanonicalMatcher::setThreshold(float ang, float dist) { threshold_angular_ = ang; threshold_dist_sq_ = dist * dist; }
+
+bool CCanonicalMatcher::newKeyframeNeeded(double p[3])
+{
+    const float x = p[0], y = p[1], th = p[2];
+    if (th > threshold_angular_) return true;
+    return x * x + y * y > threshold_dist_sq_;
+}
+
+static lsa_ctx* ensure(lsa_ctx*& ctx, const Base_PARAM* p)
+{
+    lsa_laser_param want = toCore(p);
+    if (!ctx) { must(lsa_ctx_create(&ctx, 0, &want), "lsa_ctx_create"); return ctx; }
+    lsa_laser_param have;
+    lsa_ctx_get_param(ctx, &have);
+    if (have.points != want.points || have.max_range != want.max_range || have.fi_min != want.fi_min ||
+        have.dfi != want.dfi || have.window != want.window || have.min_valid != want.min_valid)
+        must(lsa_ctx_set_param(ctx, &want), "lsa_ctx_set_param");
+    return ctx;
+}
+
+// 5-tap median on the ranges (ZHCanonical_Matcher.cpp:159-189, same recurrence as pm_median_filter)
+void CCanonicalMatcher::median_filter(struct _PMScan* ls)
+{
+    ensure(m_ctx, m_pParam);
+    must(lsa_preprocess_stages_host(m_ctx, ls->r, ls->bad, ls->seg, LSA_PRE_MEDIAN), "median_filter");
+}
+
+// validity as fromPMScan2LDP (:193-227): r in (min_range, max_range); then segment + match
+float CCanonicalMatcher::matchPair(struct _PMScan* ref, struct _PMScan* cur)
+{
+    ensure(m_ctx, m_pParam);
+    const int n = m_pParam->pm_l_points;
+    struct _PMScan* s[2] = {ref, cur};
+    for (int k = 0; k < 2; ++k) {
+        for (int i = 0; i < n; ++i)
+            s[k]->bad[i] = (s[k]->r[i] <= m_pParam->pm_min_range || s[k]->r[i] >= m_pParam->pm_max_range) ? PM_RANGE : 0;
+        must(lsa_preprocess_stages_host(m_ctx, s[k]->r, s[k]->bad, s[k]->seg, LSA_PRE_SEGMENT), "segment");
+    }
+    const float zero[3] = {0, 0, 0};
+    float pose[3] = {0, 0, 0}, ret = 0;
+    int32_t st = 0;
+    must(lsa_match_host(m_ctx, LSA_MATCH_ICP, ref->r, ref->bad, zero, cur->r, cur->bad, cur->seg, zero, pose, &ret, &st),
+         "lsa_match_host");
+    if (st != LSA_ST_OK) {
+        cout << "icp_failed!" << endl;
+        return -1;
+    }
+    cur->rx = pose[0]; cur->ry = pose[1]; cur->th = pose[2];
+    if (m_doCov) {
+        float exy[2] = {0, 0};
+        int32_t na = 0;
+        must(lsa_error_index2_host(m_ctx, ref->r, ref->bad, zero, cur->r, cur->bad, cur->seg, pose, exy, &na), "error_index2");
+        for (int i = 0; i < 9; ++i) m_cov[i] = 0;
+        m_cov[0] = exy[0]; m_cov[4] = exy[1];                         // [m^2]
+        const double mean_r = 5.0;                                    // lever arm for the heading variance [m]
+        m_cov[8] = (exy[0] + exy[1]) / (mean_r * mean_r);
+    }
+    return 0;
+}
+
+float CCanonicalMatcher::FMatch(struct _PMScan* lsr, struct _PMScan* lsa, bool bFirst)     // :229-249
+{
+    if (bFirst) median_filter(lsr);
+    median_filter(lsa);
+    lsr->rx = lsr->ry = lsr->th = 0;
+    lsa->rx = lsa->ry = lsa->th = 0;
+    return matchPair(lsr, lsa);
+}
+
+void CCanonicalMatcher::resetKeyFrame(struct _PMScan* lsa)                                  // :359-365
+{
+    delete m_pKeyframe;
+    m_pKeyframe = new _PMScan(*lsa);
+}
+
+float CCanonicalMatcher::FMatchKeyFrame(struct _PMScan* lsa)                                // :301-358
+{
+    median_filter(lsa);
+    if (m_pKeyframe == 0) {
+        m_pKeyframe = new _PMScan(*lsa);
+        return 2;                        // first laser data
+    }
+    m_pKeyframe->rx = m_pKeyframe->ry = m_pKeyframe->th = 0;
+    lsa->rx = lsa->ry = lsa->th = 0;
+    const float ret = matchPair(m_pKeyframe, lsa);
+    // the reference replaces the key frame by the current scan after every match (:367-368)
+    delete m_pKeyframe;
+    m_pKeyframe = new _PMScan(*lsa);
+    return ret;
+}

@@ -1,0 +1,76 @@
+// Drop-in CPolarMatch (reference: src/zhpsm/ZHPolar_Match.h:16-88) over the MI355X
+// core's C ABI (include/lsa_core.h).  Same public methods, members, units (cm / rad)
+// and `throw int` behaviour; the arithmetic runs in HIP kernels.
+#ifndef POLAR_MATCH_H
+#define POLAR_MATCH_H
+
+#include <string>
+#include <utility>
+#include <vector>
+#include "PolarParameter.h"
+using namespace std;
+
+struct lsa_ctx;
+
+class CPolarMatch {
+public:
+    CPolarMatch(string laser_name);
+    ~CPolarMatch();
+
+    // front door used by mapGraph / slam (ZHPolar_Match.cpp:81-121): returns the x/y
+    // variances [m^2] of pm_error_index2, (-1,-1) when the match fails
+    pair<float, float> FMatch(PMScan* lsr, PMScan* lsa, bool bFirst = false);
+
+public:
+    void pm_median_filter(PMScan* ls);
+    void pm_find_far_points(PMScan* ls);
+    void pm_segment_scan(PMScan* ls);
+    bool pm_is_corridor(PMScan*);
+    void pm_scan_project(const PMScan* act, PM_TYPE* new_r, int* new_bad);
+    PM_TYPE pm_orientation_search(const PMScan* ref, const PM_TYPE* new_r, const int* new_bad);
+    PM_TYPE pm_translation_estimation(const PMScan* ref, const PM_TYPE* new_r, const int* new_bad, PM_TYPE C,
+                                      PM_TYPE* dx, PM_TYPE* dy);
+    pair<PM_TYPE, PM_TYPE> pm_error_index2(PMScan* ref, PMScan* cur, int* associatedPoints = NULL);
+    void pm_init();
+    void pm_preprocessScan(PMScan* ls);
+    PM_TYPE pm_psm(const PMScan* lsr, PMScan* lsa);      // throws int on failure
+    PM_TYPE pm_icp(const PMScan* lsr, PMScan* lsa);      // throws int on failure
+    PM_TYPE point_line_distance(PM_TYPE x1, PM_TYPE y1, PM_TYPE x2, PM_TYPE y2, PM_TYPE x3, PM_TYPE y3,
+                                PM_TYPE* x, PM_TYPE* y);
+
+public:
+    bool readSICK(string filename);
+    bool readFlirt(string filename);
+    bool readCarmon(string filename, string laser = "");
+    bool readRawSeed(string filename);
+
+public:
+    PM_TYPE* pm_fi;
+    PM_TYPE* pm_si;
+    PM_TYPE* pm_co;
+
+public:
+    Base_PARAM* m_pParam;
+    bool m_bReady;
+    vector<_PMScan*> m_SickScans;
+
+public:
+    void clearRecord();
+
+    // ---- additions (not in the reference): the batched path the throughput comes from.
+    // Matches scan k against scan k-1 for every k in m_SickScans (zero initial guess,
+    // scans preprocessed on the device); which = 0 pm_psm, 1 pm_icp.  poses: 3 floats per
+    // pair (cm, cm, rad), status: 0 ok / else the reference would have thrown.
+    bool matchConsecutive(int which, vector<float>& poses, vector<int>& status);
+    lsa_ctx* context();
+
+private:
+    CPolarMatch(const CPolarMatch&);
+    CPolarMatch& operator=(const CPolarMatch&);
+    void syncParam();           // push m_pParam to the device context when a caller changed it
+    void allocTables(int n);
+    lsa_ctx* m_ctx;
+    int m_tableLen;
+};
+
+#endif

@@ -1,0 +1,115 @@
+"""GPU: the C++ drop-in classes (CPolarMatch, CPMap, CCanonicalMatcher, OrientedPoint2D)
+driven like the reference's own callers, compared bit-for-bit with the golden vectors."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, ROOT, SETS, load, same_bits
+
+pytestmark = pytest.mark.gpu
+
+LIBDIR = os.path.join(ROOT, "laser_slam_amd", "lib")
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("dropin") / "host_dropin_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "laser_slam_amd", "host"),
+                           os.path.join(ROOT, "tests", "native", "host_dropin_test.cpp"), "-o", out,
+                           "-L", LIBDIR, "-llsa_host", "-llsa_core", "-Wl,-rpath," + LIBDIR])
+    return out
+
+
+def hexf(tok):
+    return np.float32(float.fromhex(tok))
+
+
+@pytest.mark.parametrize("name", ["mit", "intel", "indoor"])
+def test_cpolarmatch_dropin(name, exe):
+    g = load(name)
+    laser, fn, tag = SETS[name]
+    n_pairs = 12
+    res = subprocess.run([exe, "match", laser, os.path.join(GOLDEN, fn), tag, str(n_pairs)],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    rows = [l.split() for l in res.stdout.splitlines()]
+    by = lambda k: [r for r in rows if r and r[0] == k]
+    for r in by("fmatch"):
+        b = int(r[1])
+        got = np.array([hexf(t) for t in r[2:5]], np.float32)
+        assert same_bits(got, g["fmatch_pose"][b]), (b, got, g["fmatch_pose"][b])
+        pair = np.array([hexf(t) for t in r[5:7]], np.float32)
+        assert same_bits(pair, g["fmatch_pair"][b])
+    assert len(by("fmatch")) == n_pairs
+    for nm in ("psm", "icp"):
+        for r in by(nm):
+            b, status = int(r[1]), int(r[2])
+            assert (status != 0) == (g[nm + "_status"][b] != 0)
+            if status == 0:
+                assert same_bits(np.array([hexf(t) for t in r[3:6]], np.float32), g[nm + "_pose"][b])
+                assert same_bits(hexf(r[6]), g[nm + "_ret"][b])
+                assert int(r[7]) == g[nm + "_nassoc"][b]
+                if int(r[7]) > 0:
+                    assert same_bits(np.array([hexf(r[8]), hexf(r[9])], np.float32), g[nm + "_exy"][b])
+            else:
+                assert status == 1                      # the reference throws 1
+                assert all(hexf(t) == 0 for t in r[3:6])   # lsa untouched
+    for r in by("batch"):
+        b = int(r[1])
+        assert (int(r[2]) != 0) == (g["icp_status"][b] != 0)
+        assert same_bits(np.array([hexf(t) for t in r[3:6]], np.float32), g["icp_pose"][b])
+    # stage methods against the CPU oracle
+    from oracle_lib import Oracle
+    o = Oracle(laser)
+    from helpers import golden_param
+    gp = golden_param(g)
+    o.set_fimin_maxrange(np.float32(gp["fi_min"]), int(gp["max_range"]))
+    act = (g["pre_r"][1], g["pre_bad"][1], g["pre_seg"][1])
+    nr, nb = o.scan_project(*act, np.array([3.5, -2.25, 0.03], np.float32))
+    h = 2166136261
+    for a, b_ in zip(nr.view(np.uint32).tolist(), nb.tolist()):
+        h = ((h ^ a) * 16777619) & 0xffffffff
+        h = ((h ^ (b_ & 0xffffffff)) * 16777619) & 0xffffffff
+    st = by("stage")[0]
+    assert int(st[1], 16) == h
+    so, dth = o.orientation_search(g["pre_r"][0], g["pre_bad"][0], nr, nb)
+    assert (int(st[2]) != 0) == (so != 0)
+    if so == 0:
+        assert hexf(st[3]) == np.float32(dth)
+    stt, dx, dy, err = o.translation_estimation(g["pre_r"][0], g["pre_bad"][0], nr, nb)
+    assert (int(st[4]) != 0) == (stt != 0)
+    if stt == 0:
+        assert same_bits(np.array([hexf(t) for t in st[5:8]], np.float32), np.array([dx, dy, err], np.float32))
+    assert int(by("corridor")[0][1]) in (0, 1, -2, -3)
+    csm = by("csm")[0]
+    assert float(csm[1]) == 2.0 and float(csm[2]) in (0.0, -1.0)          # first frame stored, then a match
+    se2 = [float.fromhex(t) for t in by("se2")[0][1:]]
+    assert np.allclose(se2[3:], [0.25, -0.5, 0.125], atol=1e-12)          # p (-) (p (+) q) == q
+
+
+@pytest.mark.parametrize("name", ["mit"])
+def test_cpmap_dropin(name, exe, tmp_path):
+    z = np.load(os.path.join(GOLDEN, "pmap_%s.npz" % name))
+    G = z["geom"]
+    S, nb = z["gx"].shape
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<4i2fd2i", int(G[0]), int(G[1]), int(G[2]), int(G[3]), float(G[4]), float(G[5]), float(G[6]), S, nb))
+        f.write(z["gx"].astype(np.float32).tobytes()); f.write(z["gy"].astype(np.float32).tobytes())
+        f.write(z["robot"].astype(np.float32).tobytes())
+    res = subprocess.run([exe, "pmap", fin, fout], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    raw = open(fout, "rb").read()
+    cells = int(G[0]) * int(G[1])
+    lay = np.frombuffer(raw, np.float32, 3 * cells).reshape(3, int(G[0]), int(G[1]))
+    assert np.array_equal(lay[0], z["hit"].astype(np.float32))
+    assert np.array_equal(lay[1], z["sum"].astype(np.float32))
+    assert same_bits(lay[2], z["prob"])
+    nc = struct.unpack_from("<i", raw, 12 * cells)[0]
+    cx = np.frombuffer(raw, np.float32, nc, 12 * cells + 4)
+    cy = np.frombuffer(raw, np.float32, nc, 12 * cells + 4 + 4 * nc)
+    assert same_bits(cx, z["cloud_x"]) and same_bits(cy, z["cloud_y"])
