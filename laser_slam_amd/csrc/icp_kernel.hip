@@ -15,7 +15,7 @@
 //                          -> V: ordered (nx,ny,ix,iy) float4 list -> W: the four products
 //                          (the trim pools and scratch also live here, between NN and V)
 //   [.. , +4Np)   owner    u32 per reference beam
-//   [.. , +2Np)   ref_bad, pair_ok bytes
+//   [.. , +4Np)   ref_bad, pair_ok bytes; jprev u16 (last match per beam, the NN seed)
 //   [.. , +256)   broadcast slots
 // The current scan's ranges stay in HBM/L2 (read coalesced once per phase).
 
@@ -26,8 +26,11 @@ constexpr int ICP_THREADS = 256;
 #ifdef LSA_PHASE_STAMPS
 __device__ unsigned long long lsa_phase_cycles[16];
 #define STAMP(slot) do { if (tid == 0) { unsigned long long t_ = __builtin_readcyclecounter(); ph[slot] += t_ - t_last; t_last = t_; } } while (0)
+// sub-phase stamp: `dep` is a value the stamped work produced (forces completion before the clock read)
+#define SUBSTAMP(slot, dep) do { if (tid == 0) { float d_ = (dep); asm volatile("" :: "v"(d_)); unsigned long long t_ = __builtin_readcyclecounter(); ph[slot] += t_ - t_sub; t_sub = t_; } } while (0)
 #else
 #define STAMP(slot) do {} while (0)
+#define SUBSTAMP(slot, dep) do {} while (0)
 #endif
 constexpr float NN_CAP = 10001.0f;     // matches with d^2 >= 100^2 are rejected anyway (:1811)
 
@@ -54,7 +57,7 @@ __host__ __device__ inline int icp_o_bytes(int n)
 __host__ __device__ inline int icp_lds_bytes(int n)
 {
     int Np = (n + 63) & ~63;
-    return 16 * Np + icp_v_bytes(n) + icp_o_bytes(n) + 2 * Np + 256;
+    return 16 * Np + icp_v_bytes(n) + icp_o_bytes(n) + 4 * Np + 256;
 }
 
 __device__ __forceinline__ Lds carve_icp(char* base, int n)
@@ -78,7 +81,8 @@ __device__ __forceinline__ Lds carve_icp(char* base, int n)
     char* f = o + icp_o_bytes(n);
     L.ref_bad = (uint8_t*)f;
     L.pair_ok = (uint8_t*)(f + Np);
-    L.misc = (float*)(f + 2 * Np);
+    L.jprev = (uint16_t*)(f + 2 * Np);          // last iteration's match per beam (+1; 0 = none)
+    L.misc = (float*)(f + 4 * Np);
     return L;
 }
 
@@ -174,59 +178,95 @@ __device__ __forceinline__ void nn_eval4(const Lds& L, float2 p, int j, float& b
 }
 
 constexpr int NN_SHORT = 32;      // candidate counts above this are searched by the whole wave
+constexpr int NN_FLAT = 8;        // candidate counts up to this are evaluated straight-line
 
-// one wave, beams base..base+63 with their points p (live = projected flag clear);
-// writes the per-beam NN record into L.key[i]
-__device__ __forceinline__ void nn_chunk(const DevParam& P, const Lds& L, int base, float2 p, bool live,
-                                         unsigned long long* slot, int& jprev)
+// per-beam search state
+struct NnBeam {
+    float2 p;
+    NnPlan pl;
+    int s0, e0;          // main range (image 0), already clipped to the window
+    int len;             // total candidates over the three images
+    bool live, flat;     // flat: one range of at most NN_FLAT rays
+    float best;
+    int best_j;
+};
+
+// predicated evaluation of ray j (LDS address clamped so that the loads are unconditional)
+__device__ __forceinline__ void nn_eval_pred(const Lds& L, int N, float2 p, int j, bool pred, float& best, int& best_j)
 {
-    const int N = P.n, W = P.window, lane = lane_id();
-    const int i = base + lane;
-    const int T = (int)rintf(6.2831853f / P.dfi);
-    NnPlan pl = {0, 0, 0, -1};
-    int len = 0;
-    if (live) {
-        pl.lo = i - W < 0 ? 0 : i - W;
-        pl.hi = i + W > N ? N : i + W;
-        const float rho = L.pr[i] * 0.999f - 0.01f;
-        // centre: bearing of p relative to the middle of the field of view, wrapped to [-pi, pi]
-        const float half = 0.5f * (float)(N - 1) * P.dfi;
-        float a = L.pf[i] - (P.fi_min + half);
-        a -= 6.2831853f * rintf(a * 0.15915494f);
-        pl.c0 = (int)rintf((a + half) / P.dfi);
-        const int c = pl.c0 < pl.lo ? pl.lo : (pl.c0 > pl.hi - 1 ? pl.hi - 1 : pl.c0);
-        // seed distance: the ray at the bearing of p and last iteration's match
-        float b1 = 1000000.0f;
-        int bj1 = 0x7fffffff;
-        nn_eval(L, p, c, b1, bj1);
-        if (jprev >= pl.lo && jprev < pl.hi) nn_eval(L, p, jprev, b1, bj1);
-        if (b1 < 1000000.0f && rho > 0.0f) {
-            const float tcap = b1 < NN_CAP ? b1 : NN_CAP;
-            const float t = sqrtf(tcap) * 1.001f / rho;
-            if (t < 1.0f) pl.M = (int)((t + 0.5708f * t * t * t) / P.dfi) + 2;
-        }
-        int done = pl.lo - 1, s0, e0;
-        #pragma unroll
-        for (int im = -1; im <= 1; ++im) { nn_range(pl, T, im, done, s0, e0); len += e0 >= s0 ? e0 - s0 + 1 : 0; }
-    }
-    float best = 1000000.0f;
-    int best_j = 0x7fffffff;
-    const bool is_long = live && len > NN_SHORT;
-    if (live && !is_long) {
-        int done = pl.lo - 1, s0, e0;
+    const int jc = j < 0 ? 0 : (j > N - 1 ? N - 1 : j);
+    const uint8_t bad = L.ref_bad[jc];
+    const float2 rj = L.ref_xy[jc];
+    const float ex = p.x - rj.x, ey = p.y - rj.y;
+    const float d = ex * ex + ey * ey;                 // :1803
+    const bool take = pred && bad == 0 && (d < best || (d == best && j < best_j));
+    best = take ? d : best;
+    best_j = take ? j : best_j;
+}
+
+// plan for beam i (straight-line): centre from the projected bearing, seed distance from the
+// ray at that bearing and last iteration's match, half width from the asin bound
+__device__ __forceinline__ void nn_plan(const DevParam& P, const Lds& L, int i, bool live, float2 p, int jprev,
+                                        int T, float inv_dfi, NnBeam& b)
+{
+    const int N = P.n, W = P.window;
+    const int ic = i < N ? i : N - 1;
+    b.p = p; b.live = live;
+    b.pl.lo = ic - W < 0 ? 0 : ic - W;
+    b.pl.hi = ic + W > N ? N : ic + W;
+    const float rho = L.pr[ic] * 0.999f - 0.01f;
+    const float half = 0.5f * (float)(N - 1) * P.dfi;
+    float a = L.pf[ic] - (P.fi_min + half);
+    a -= 6.2831853f * rintf(a * 0.15915494f);
+    b.pl.c0 = (int)rintf((a + half) / P.dfi);
+    const int c = b.pl.c0 < b.pl.lo ? b.pl.lo : (b.pl.c0 > b.pl.hi - 1 ? b.pl.hi - 1 : b.pl.c0);
+    float b1 = 1000000.0f;
+    int bj1 = 0x7fffffff;
+    nn_eval_pred(L, N, p, c, true, b1, bj1);
+    nn_eval_pred(L, N, p, jprev, jprev >= b.pl.lo && jprev < b.pl.hi, b1, bj1);
+    // planning only (conservative margins absorb the approximate sqrt / reciprocal)
+    const float tcap = b1 < NN_CAP ? b1 : NN_CAP;
+    const float t = __builtin_amdgcn_sqrtf(tcap) * 1.001f * __builtin_amdgcn_rcpf(rho > 1e-3f ? rho : 1e-3f);
+    const bool bounded = b1 < 1000000.0f && rho > 0.0f && t < 1.0f;
+    b.pl.M = bounded ? (int)((t + 0.5708f * t * t * t) * inv_dfi) + 2 : -1;
+    int done = b.pl.lo - 1, s0, e0, len = 0, l0 = 0;
+    nn_range(b.pl, T, -1, done, s0, e0); len += e0 >= s0 ? e0 - s0 + 1 : 0;
+    if (b.pl.M < 0) { b.s0 = s0; b.e0 = e0; l0 = len; }
+    nn_range(b.pl, T, 0, done, s0, e0); len += e0 >= s0 ? e0 - s0 + 1 : 0;
+    if (b.pl.M >= 0) { b.s0 = s0; b.e0 = e0; l0 = e0 >= s0 ? e0 - s0 + 1 : 0; }
+    nn_range(b.pl, T, 1, done, s0, e0); len += e0 >= s0 ? e0 - s0 + 1 : 0;
+    b.len = live ? len : 0;
+    b.flat = live && len == l0 && len <= NN_FLAT;
+    b.best = 1000000.0f;
+    b.best_j = 0x7fffffff;
+}
+
+__device__ __forceinline__ void nn_flat(const Lds& L, int N, NnBeam& b)
+{
+    #pragma unroll
+    for (int o = 0; o < NN_FLAT; ++o) nn_eval_pred(L, N, b.p, b.s0 + o, b.flat && b.s0 + o <= b.e0, b.best, b.best_j);
+}
+
+// the general path: lists of up to NN_SHORT rays serially per lane, longer ones by the whole wave
+__device__ __forceinline__ void nn_general(const DevParam& P, const Lds& L, int T, NnBeam& b, unsigned long long* slot)
+{
+    const int lane = lane_id();
+    const bool serial = b.live && !b.flat && b.len <= NN_SHORT;
+    if (serial) {
+        int done = b.pl.lo - 1, s0, e0;
         #pragma unroll
         for (int im = -1; im <= 1; ++im) {
-            nn_range(pl, T, im, done, s0, e0);
+            nn_range(b.pl, T, im, done, s0, e0);
             int j = s0;
-            for (; j + 3 <= e0; j += 4) nn_eval4(L, p, j, best, best_j);
-            for (; j <= e0; ++j) nn_eval(L, p, j, best, best_j);
+            for (; j + 3 <= e0; j += 4) nn_eval4(L, b.p, j, b.best, b.best_j);
+            for (; j <= e0; ++j) nn_eval(L, b.p, j, b.best, b.best_j);
         }
     }
-    // long candidate lists: the whole wave scans one beam's ranges, 64 rays at a time
+    const bool is_long = b.live && !b.flat && b.len > NN_SHORT;
     for (unsigned long long m = __ballot(is_long); m; m &= m - 1) {
         const int s = __builtin_ctzll(m);
-        const float2 bp = make_float2(bcast_f(p.x, s), bcast_f(p.y, s));
-        NnPlan bpl = {bcast_i(pl.lo, s), bcast_i(pl.hi, s), bcast_i(pl.c0, s), bcast_i(pl.M, s)};
+        const float2 bp = make_float2(bcast_f(b.p.x, s), bcast_f(b.p.y, s));
+        NnPlan bpl = {bcast_i(b.pl.lo, s), bcast_i(b.pl.hi, s), bcast_i(b.pl.c0, s), bcast_i(b.pl.M, s)};
         float cb = 1000000.0f;
         int cj = 0x7fffffff;
         int done = bpl.lo - 1, s0, e0;
@@ -242,19 +282,25 @@ __device__ __forceinline__ void nn_chunk(const DevParam& P, const Lds& L, int ba
         if (cj != 0x7fffffff) atomicMin(slot, ((unsigned long long)f2u(cb) << 32) | (unsigned)cj);
         wave_sync();
         const unsigned long long res = *slot;
-        if (lane == s && res != ~0ull) { best = u2f((uint32_t)(res >> 32)); best_j = (int)(uint32_t)res; }
+        if (lane == s && res != ~0ull) { b.best = u2f((uint32_t)(res >> 32)); b.best_j = (int)(uint32_t)res; }
         wave_sync();
     }
-    jprev = live && best_j != 0x7fffffff ? best_j : -1;
+}
+
+// record of beam i into L.key[i] (:1811-1816), returns the match for next iteration's seed
+__device__ __forceinline__ int nn_store(const Lds& L, int N, int i, const NnBeam& b)
+{
+    const bool found = b.live && b.best_j != 0x7fffffff;
     if (i < N) {
         float rd = -1.0f;
         int bj = 0;
-        if (live && best_j != 0x7fffffff) {
-            const float sd = sqrtf(best);
-            if (sd < LSA_MAX_ERROR) { rd = sd; bj = best_j; }                  // :1811
+        if (found) {
+            const float sd = sqrtf(b.best);
+            if (sd < LSA_MAX_ERROR) { rd = sd; bj = b.best_j; }
         }
         L.key[i] = pack_rec(rd, (uint32_t)i | ((uint32_t)bj << 16));
     }
+    return found ? b.best_j : -1;
 }
 
 // ---------------------------------------------------------------------------
@@ -457,11 +503,10 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
         float dx = 0, dy = 0, dth = 0;
         int small = 0, status = LSA_ST_OK, n = 0, drop = 0, keep = 0;
         float co = 1.0f, si = 0.0f, pax = 0.0f, pay = 0.0f;
-        int jprev[5] = {-1, -1, -1, -1, -1};       // last iteration's match of this thread's beams (search seed)
         __syncthreads();
 #ifdef LSA_PHASE_STAMPS
-        unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        unsigned long long t_last = __builtin_readcyclecounter();
+        unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long t_last = __builtin_readcyclecounter(), t_sub = t_last;
 #endif
 
         int iter = -1;
@@ -472,21 +517,45 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
             scan_project(P, L, ax, ay, ath);                                    // flags only, :1750
             co = cosf_(ath); si = sinf_(ath);                                   // :1753-1754
             STAMP(0);
+#ifdef LSA_PHASE_STAMPS
+            t_sub = t_last;
+#endif
 
             {
-                // points of this wave's beams first (global loads in flight together), then the search
-                float2 pts[5];
-                bool lv[5];
-                #pragma unroll
-                for (int r = 0; r < 5; ++r) {
-                    const int i = wave * WAVE + r * ICP_THREADS + lane;
-                    lv[r] = i < N && key_bad(L.key[i < N ? i : 0]) == 0;
-                    pts[r] = lv[r] ? cur_point(P, L.g_act_r, i, co, si, ax, ay) : make_float2(0.0f, 0.0f);
-                }
-                #pragma unroll
-                for (int r = 0; r < 5; ++r) {
-                    const int base = wave * WAVE + r * ICP_THREADS;
-                    if (base < N) nn_chunk(P, L, base, pts[r], lv[r], (unsigned long long*)(L.misc + 32) + wave, jprev[r]);
+                // this wave's beams, two chunks of 64 at a time so that the two searches' dependency
+                // chains (LDS reads, bounds) overlap; the seed matches live in LDS between iterations
+                const int T = (int)rintf(6.2831853f / P.dfi);
+                const float inv_dfi = 1.0f / P.dfi;
+                unsigned long long* slot = (unsigned long long*)(L.misc + 32) + wave;
+                for (int base = wave * WAVE; base < N; base += 2 * ICP_THREADS) {
+                    const int i0 = base + lane, i1 = base + ICP_THREADS + lane;
+                    const bool lv0 = i0 < N && key_bad(L.key[i0 < N ? i0 : 0]) == 0;
+                    const bool lv1 = i1 < N && key_bad(L.key[i1 < N ? i1 : 0]) == 0;
+                    const float2 p0 = cur_point(P, L.g_act_r, i0 < N ? i0 : N - 1, co, si, ax, ay);
+                    const float2 p1 = cur_point(P, L.g_act_r, i1 < N ? i1 : N - 1, co, si, ax, ay);
+                    const int jp0 = iter > 0 && i0 < N ? (int)L.jprev[i0] - 1 : -1;
+                    const int jp1 = iter > 0 && i1 < N ? (int)L.jprev[i1] - 1 : -1;
+                    NnBeam b0, b1;
+                    SUBSTAMP(8, p0.x + p1.x);
+                    nn_plan(P, L, i0, lv0, p0, jp0, T, inv_dfi, b0);
+                    nn_plan(P, L, i1, lv1, p1, jp1, T, inv_dfi, b1);
+                    SUBSTAMP(9, (float)(b0.len + b1.len));
+#if !defined(LSA_EXP) || LSA_EXP != 2
+                    nn_flat(L, N, b0);
+                    nn_flat(L, N, b1);
+                    SUBSTAMP(10, b0.best + b1.best);
+#endif
+#if !defined(LSA_EXP) || LSA_EXP != 1
+                    if (__ballot((b0.live && !b0.flat) || (b1.live && !b1.flat))) {
+                        nn_general(P, L, T, b0, slot);
+                        nn_general(P, L, T, b1, slot);
+                    }
+#endif
+                    SUBSTAMP(11, b0.best + b1.best);
+                    const int m0 = nn_store(L, N, i0, b0), m1 = nn_store(L, N, i1, b1);
+                    if (i0 < N) L.jprev[i0] = (uint16_t)(m0 + 1);
+                    if (i1 < N) L.jprev[i1] = (uint16_t)(m1 + 1);
+                    SUBSTAMP(12, (float)(m0 + m1));
                 }
             }
             __syncthreads();
@@ -562,7 +631,7 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
             STAMP(7);
         }
 #ifdef LSA_PHASE_STAMPS
-        if (tid == 0) for (int s_ = 0; s_ < 8; ++s_) atomicAdd(&lsa_phase_cycles[s_], ph[s_]);
+        if (tid == 0) for (int s_ = 0; s_ < 16; ++s_) atomicAdd(&lsa_phase_cycles[s_], ph[s_]);
 #endif
 
         // :2012-2020.  The returned value averages the residuals of the first `drop`

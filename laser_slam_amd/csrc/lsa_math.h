@@ -210,5 +210,87 @@ LSA_HD float atan2f_(float y, float x)
     }
 }
 
+// ---- straight-line variants for the kernels' inner loops ---------------------
+// Same results bit for bit (tests/native/math_bits_check.cpp), but without data
+// dependent branches on the common path, so that the compiler can interleave the
+// evaluation for several beams.  Rare inputs fall back to the functions above.
+
+LSA_HD float cos_poly_pos(double x2)
+{
+    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5,
+                 C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
+    double x4 = x2 * x2;
+    double t2 = __builtin_fma(x2, C4, C3);
+    double t1 = __builtin_fma(x2, C1, C0);
+    double x6 = x4 * x2;
+    double c = __builtin_fma(x4, C2, t1);
+    return (float)__builtin_fma(x6, t2, c);
+}
+
+// `special` is set when the caller must use sincosf_ instead (|y| >= 120, NaN)
+LSA_HD void sincosf_core(float y, float& sn, float& cs, bool& special)
+{
+    special = !(abstop12(y) < abstop12(120.0f));
+    double x = special ? 0.0 : (double)y;
+    const double r = x * LSA_HPI_INV;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    x = __builtin_fma(-(double)n, LSA_HPI, x);
+    const double sgn = ((n + 1) & 2) ? -1.0 : 1.0;           // quadrants 1,2
+    const double x2 = x * x;
+    const float a = sin_poly(x * sgn, x2);
+    float b = cos_poly_pos(x2);
+    b = (n & 2) ? -b : b;                                    // the negated-cosine table, exactly
+    const bool tiny = abstop12(y) < abstop12(0x1p-12f);     // keeps sin(-0) = -0
+    sn = tiny ? y : ((n & 1) ? b : a);
+    cs = tiny ? 1.0f : ((n & 1) ? a : b);
+}
+
+LSA_HD void sincosf_fast(float y, float& sn, float& cs)
+{
+    bool special;
+    sincosf_core(y, sn, cs, special);
+    if (special) sincosf_(y, sn, cs);
+}
+
+// `special` is set when the caller must use atan2f_ instead (zeros, infinities, NaN, extreme ratios)
+LSA_HD float atan2f_core(float y, float x, bool& special)
+{
+    const int32_t hx = (int32_t)f2u(x), hy = (int32_t)f2u(y);
+    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    const float v = fabsf_(y / x);
+    const int32_t iv = (int32_t)f2u(v);
+    const int32_t k = (iy - ix) >> 23;
+    special = iy == 0 || ix == 0 || ix >= 0x7f800000 || iy >= 0x7f800000 || k > 60 || k < -60 ||
+              iv >= 0x4c000000 || iv < 0x31000000;
+    // argument reduction of atanf, as selects
+    const int id = iv < 0x3ee00000 ? -1 : iv < 0x3f300000 ? 0 : iv < 0x3f980000 ? 1 : iv < 0x401c0000 ? 2 : 3;
+    const float num = id < 0 ? v : id == 0 ? 2.0f * v - 1.0f : id == 1 ? v - 1.0f : id == 2 ? v - 1.5f : -1.0f;
+    const float den = id < 0 ? 1.0f : id == 0 ? 2.0f + v : id == 1 ? v + 1.0f : id == 2 ? 1.0f + 1.5f * v : v;
+    const float xr = num / den;
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
+                aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
+                aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+    const float z = xr * xr;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    const float hi = id == 0 ? 4.6364760399e-01f : id == 1 ? 7.8539812565e-01f : id == 2 ? 9.8279368877e-01f : 1.5707962513e+00f;
+    const float lo = id == 0 ? 5.0121582440e-09f : id == 1 ? 3.7748947079e-08f : id == 2 ? 3.4473217170e-08f : 7.5497894159e-08f;
+    const float r_small = xr - xr * (s1 + s2);
+    const float r_big = hi - ((xr * (s1 + s2) - lo) - xr);
+    const float zt = id < 0 ? r_small : r_big;
+    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    const float q0 = zt, q1 = u2f(f2u(zt) ^ 0x80000000u), q2 = pi - (zt - pi_lo), q3 = (zt - pi_lo) - pi;
+    return m == 0 ? q0 : m == 1 ? q1 : m == 2 ? q2 : q3;
+}
+
+LSA_HD float atan2f_fast(float y, float x)
+{
+    bool special;
+    const float a = atan2f_core(y, x, special);
+    return special ? atan2f_(y, x) : a;
+}
+
 } // namespace lsa
 #endif

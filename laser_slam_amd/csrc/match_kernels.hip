@@ -59,6 +59,7 @@ struct Lds {
     unsigned long long* poolB;
     unsigned long long* evict;
     float* misc;               // broadcast slots
+    uint16_t* jprev;           // ICP: last iteration's match per beam
 };
 
 __device__ __forceinline__ Lds carve_psm(char* base, int Np)
@@ -93,40 +94,76 @@ __device__ __forceinline__ int key_bad(unsigned long long k) { return k == KEY_I
 // pm_scan_project (:1356-1479).  Pass 1 is per beam; pass 2 is a scatter-min of
 // the interpolated ranges onto the reference bearings, done with 64-bit LDS
 // atomic-min keys so that its outcome equals the sequential loop's.
+// one beam of pass 1, straight-line (the rare special inputs are redone by the caller)
+__device__ __forceinline__ void project_beam(float d, float rr, float ax, float ay, float& pr, float& pf, bool& special)
+{
+    float sd, cd;
+    bool s1, s2;
+    sincosf_core(d, sd, cd, s1);
+    const float x = rr * cd + ax;
+    const float y = rr * sd + ay;
+    pr = sqrtf(x * x + y * y);
+    float a = atan2f_core(y, x, s2);
+    if (x < 0 && y < 0) a = (float)((double)a + 2.0 * LSA_ZPI);
+    pf = a;
+    special = s1 || s2;
+}
+
+__device__ __noinline__ void project_beam_slow(float d, float rr, float ax, float ay, float& pr, float& pf)
+{
+    float sd, cd;
+    sincosf_(d, sd, cd);
+    const float x = rr * cd + ax;
+    const float y = rr * sd + ay;
+    pr = sqrtf(x * x + y * y);
+    float a = atan2f_(y, x);
+    if (x < 0 && y < 0) a = (float)((double)a + 2.0 * LSA_ZPI);
+    pf = a;
+}
+
+// interpolation of one consecutive beam pair (i-1, i) onto the reference bearings, :1390-1465
+__device__ __forceinline__ void scatter_pair(const DevParam& P, const Lds& L, int i)
+{
+    const int N = P.n;
+    const float fc = L.pf[i], fp = L.pf[i - 1];
+    if ((double)fabsf_(fc - fp) >= LSA_ZPI) return;
+    float a0, a1, r0, r1;
+    int occ;
+    if (fc > fp) { occ = 0; a0 = fp; a1 = fc; r0 = L.pr[i - 1]; r1 = L.pr[i]; }
+    else         { occ = 1; a0 = fc; a1 = fp; r0 = L.pr[i]; r1 = L.pr[i - 1]; }
+    int j0 = (int)ceil((double)((a0 - P.fi_min) / P.dfi));
+    int j1 = (int)floor((double)((a1 - P.fi_min) / P.dfi));
+    if (j0 < 0) j0 = 0;                 // out-of-range bearings are never written (:1443)
+    if (j1 > N - 1) j1 = N - 1;
+    for (int j = j0; j <= j1; ++j) {
+        float ri = (r1 - r0) / (a1 - a0) * (((float)j * P.dfi + P.fi_min) - a0) + r0;
+        if (ri < 10000.0f) atomicMin(&L.key[j], make_key(ri, i, occ));
+    }
+}
+
 __device__ void scan_project(const DevParam& P, const Lds& L, float ax, float ay, float ath)
 {
     const int N = P.n, tid = threadIdx.x, nth = blockDim.x;
-    for (int i = tid; i < N; i += nth) {
-        float d = ath + P.fi[i];
-        float rr = L.act_r ? L.act_r[i] : L.g_act_r[i];
-        float sd, cd;
-        sincosf_(d, sd, cd);
-        float x = rr * cd + ax;
-        float y = rr * sd + ay;
-        L.pr[i] = sqrtf(x * x + y * y);
-        float a = atan2f_(y, x);
-        if (x < 0 && y < 0) a = (float)((double)a + 2.0 * LSA_ZPI);
-        L.pf[i] = a;
-        L.key[i] = KEY_INIT;
+    // two beams per trip so that their (long, independent) dependency chains overlap
+    for (int i0 = tid; i0 < N; i0 += 2 * nth) {
+        const int i1 = i0 + nth;
+        const bool has1 = i1 < N;
+        const int j1 = has1 ? i1 : i0;
+        const float d0 = ath + P.fi[i0], d1 = ath + P.fi[j1];
+        const float r0 = L.act_r ? L.act_r[i0] : L.g_act_r[i0];
+        const float r1 = L.act_r ? L.act_r[j1] : L.g_act_r[j1];
+        float pr0, pf0, pr1, pf1;
+        bool sp0, sp1;
+        project_beam(d0, r0, ax, ay, pr0, pf0, sp0);
+        project_beam(d1, r1, ax, ay, pr1, pf1, sp1);
+        if (sp0) project_beam_slow(d0, r0, ax, ay, pr0, pf0);
+        if (sp1) project_beam_slow(d1, r1, ax, ay, pr1, pf1);
+        L.pr[i0] = pr0; L.pf[i0] = pf0; L.key[i0] = KEY_INIT;
+        if (has1) { L.pr[i1] = pr1; L.pf[i1] = pf1; L.key[i1] = KEY_INIT; }
     }
     __syncthreads();
-    for (int i = tid; i < N; i += nth) {
-        if (!L.pair_ok[i]) continue;
-        float fc = L.pf[i], fp = L.pf[i - 1];
-        if ((double)fabsf_(fc - fp) >= LSA_ZPI) continue;
-        float a0, a1, r0, r1;
-        int occ;
-        if (fc > fp) { occ = 0; a0 = fp; a1 = fc; r0 = L.pr[i - 1]; r1 = L.pr[i]; }
-        else         { occ = 1; a0 = fc; a1 = fp; r0 = L.pr[i]; r1 = L.pr[i - 1]; }
-        int j0 = (int)ceil((double)((a0 - P.fi_min) / P.dfi));
-        int j1 = (int)floor((double)((a1 - P.fi_min) / P.dfi));
-        if (j0 < 0) j0 = 0;                 // out-of-range bearings are never written (:1443)
-        if (j1 > N - 1) j1 = N - 1;
-        for (int j = j0; j <= j1; ++j) {
-            float ri = (r1 - r0) / (a1 - a0) * (((float)j * P.dfi + P.fi_min) - a0) + r0;
-            if (ri < 10000.0f) atomicMin(&L.key[j], make_key(ri, i, occ));
-        }
-    }
+    for (int i = tid; i < N; i += nth)
+        if (L.pair_ok[i]) scatter_pair(P, L, i);
     __syncthreads();
 }
 

@@ -33,12 +33,14 @@ int main(int argc, char** argv)
                 for (uint32_t sign = 0; sign < 2; ++sign) {
                     float x = lsa::u2f((uint32_t)u | (sign << 31));
                     if (!same(lsa::sinf_(x), sinf(x))) { if (bs < 3) fprintf(stderr, "sin %a: %a vs %a\n", x, lsa::sinf_(x), sinf(x)); ++bs; }
+                    { float sn, cs; lsa::sincosf_fast(x, sn, cs); if (!same(sn, sinf(x)) || !same(cs, cosf(x))) { if (bs < 3) fprintf(stderr, "sincos_fast %a\n", x); ++bs; } }
                     { float sn, cs; lsa::sincosf_(x, sn, cs); if (!same(sn, sinf(x)) || !same(cs, cosf(x))) { if (bs < 3) fprintf(stderr, "sincos %a\n", x); ++bs; } }
                     if (!same(lsa::cosf_(x), cosf(x))) { if (bc < 3) fprintf(stderr, "cos %a: %a vs %a\n", x, lsa::cosf_(x), cosf(x)); ++bc; }
                 }
             }
             for (uint64_t u = t * (uint64_t)stride; u < 0x100000000ull; u += (uint64_t)nthr * stride) {
                 float x = lsa::u2f((uint32_t)u);
+                if (!same(lsa::atan2f_fast(x, 1.0f), atan2f(x, 1.0f))) { if (b2 < 3) fprintf(stderr, "atan2_fast(%a,1)\n", x); ++b2; }
                 if (!same(lsa::atanf_(x), atanf(x))) { if (ba < 3) fprintf(stderr, "atan %a: %a vs %a\n", x, lsa::atanf_(x), atanf(x)); ++ba; }
             }
             // atan2f: xorshift over (y,x) bit patterns, plus a structured sweep of
@@ -49,10 +51,12 @@ int main(int argc, char** argv)
                 s ^= s << 13; s ^= s >> 7; s ^= s << 17;
                 float y = lsa::u2f((uint32_t)s), x = lsa::u2f((uint32_t)(s >> 32));
                 if (!same(lsa::atan2f_(y, x), atan2f(y, x))) { if (b2 < 3) fprintf(stderr, "atan2 %a %a: %a vs %a\n", y, x, lsa::atan2f_(y, x), atan2f(y, x)); ++b2; }
+                if (!same(lsa::atan2f_fast(y, x), atan2f(y, x))) { if (b2 < 3) fprintf(stderr, "atan2_fast %a %a\n", y, x); ++b2; }
                 // scan-like: exponents 117..140
                 uint32_t ey = 117 + (uint32_t)((s >> 3) % 24), ex = 117 + (uint32_t)((s >> 11) % 24);
                 y = lsa::u2f(((uint32_t)s & 0x807fffffu) | (ey << 23));
                 x = lsa::u2f(((uint32_t)(s >> 32) & 0x807fffffu) | (ex << 23));
+                if (!same(lsa::atan2f_fast(y, x), atan2f(y, x))) { if (b2 < 3) fprintf(stderr, "atan2_fast %a %a\n", y, x); ++b2; }
                 if (!same(lsa::atan2f_(y, x), atan2f(y, x))) { if (b2 < 3) fprintf(stderr, "atan2 %a %a: %a vs %a\n", y, x, lsa::atan2f_(y, x), atan2f(y, x)); ++b2; }
             }
             bad_sin += bs; bad_cos += bc; bad_atan += ba; bad_atan2 += b2;

@@ -8,7 +8,9 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
 out = os.path.join(ROOT, "gpurun_out", "liblsa_core_stamps.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.check_call(["hipcc"] + ge.HIP_FLAGS + ["-DLSA_PHASE_STAMPS", "-o", out,
+EXP = [a for a in sys.argv[1:] if a.startswith("-D")]
+sys.argv = [a for a in sys.argv if not a.startswith("-D")]
+subprocess.check_call(["hipcc"] + ge.HIP_FLAGS + ["-DLSA_PHASE_STAMPS"] + EXP + ["-o", out,
                       os.path.join(ge.CSRC, "core.hip"), os.path.join(ge.CSRC, "carmen.cpp")])
 from laser_slam_amd import capi, synth
 capi.LIB_PATH = out
@@ -26,13 +28,18 @@ idx = idx[(idx % 200) != 199]
 B = len(idx)
 ri = torch.from_numpy(idx.astype(np.int32)).cuda(); ai = ri + 1
 pose = torch.zeros(B, 3, device="cuda")
+its = torch.zeros(B, dtype=torch.int32, device="cuda")
 ctx.match_batch(1, B, d_r, d_bad, d_seg, ri, ai, pose); ctx.sync()
 buf = (C.c_ulonglong * 16)()
 capi.lib().lsa_debug_phase_cycles(buf)
-ctx.match_batch(1, B, d_r, d_bad, d_seg, ri, ai, pose); ctx.sync()
+ctx.match_batch(1, B, d_r, d_bad, d_seg, ri, ai, pose, d_iters=its); ctx.sync()
 capi.lib().lsa_debug_phase_cycles(buf)
+mean_it = float(its.float().mean())
 v = np.array(list(buf)[:8], np.float64)
 names = ["project+scatter", "nn search", "compaction", "trim (bubble)", "owner+interp -> V", "sum means", "products+sum cov", "pose update"]
 for nm, x in zip(names, v):
     print("%-22s %6.2f %%   %10.0f cycles/pair" % (nm, 100 * x / v.sum(), x / B))
-print("total cycles/pair %.0f" % (v.sum() / B))
+print("total cycles/pair %.0f  mean iterations %.2f  cycles/iteration %.0f" % (v.sum() / B, mean_it, v.sum() / B / mean_it))
+sub = np.array(list(buf)[8:13], np.float64) / B / mean_it
+print("nn sub-phases (wave 0, per iteration): loads+points=%.0f plan=%.0f flat=%.0f general=%.0f store=%.0f" % tuple(sub))
+print("per-iteration:", " ".join("%s=%.0f" % (nm.split()[0], x / B / mean_it) for nm, x in zip(names, v)))
