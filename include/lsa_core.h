@@ -203,6 +203,33 @@ int lsa_grid_device_ptrs(lsa_grid* g, uint32_t** d_hit, uint32_t** d_sum, float*
 int lsa_grid_cloud(lsa_grid* g, float prob_thre, float* h_x, float* h_y, int cap, int* n);
 int lsa_grid_cell(const lsa_grid* g, float px, float py, int* ix, int* iy);   /* mapPosfromPoint :100-117 */
 
+/* ---- pose scoring / particle filter (PARITY UNPINNED: Qt4/Boost/MRPT sources cannot be built) ----
+ * Likelihood field of CVPmap::obsLikelyhood3 (src/localization/VPmap.cpp:336-452) precomputed per
+ * cell; map cell value = reflection probability [x][y], 0.5 = unknown (VPmap.cpp:23-59). */
+typedef struct lsa_field lsa_field;
+int lsa_field_create(lsa_field** out, lsa_ctx* c, int size_x, int size_y, int center_x, int center_y,
+                     float off_x, float off_y, double resolution);
+void lsa_field_destroy(lsa_field* f);
+/* globaldef.cpp:7-13 defaults: max_corr_dist 1.0 m, free_thr 0.3, unknown 0.5 */
+int lsa_field_build(lsa_field* f, const float* d_prob, float max_corr_dist, float free_thr, float unknown_value);
+int lsa_field_build_from_grid(lsa_field* f, lsa_grid* g, float max_corr_dist, float free_thr, float unknown_value);
+int lsa_field_download(lsa_field* f, int what /*0 lik, 1 log lik*/, float* h_out);
+/* obsLikelyhood3 for P poses [P][3] (x, y [m], theta [rad]) of one scan given as laser-frame points
+ * [m]; every `decimation`-th point is used (g_scan_decimation = 3, globaldef.cpp:13) */
+int lsa_score_poses(lsa_field* f, const float* d_scan_x, const float* d_scan_y, int n_points, int decimation,
+                    const float* d_poses, int n_poses, float* d_score);
+/* best of the scored poses: threadLocalization::globalization + topK(1), localization.cpp:126-149,483-540 */
+int lsa_pose_argmax(lsa_ctx* c, const float* d_score, int n_poses, float* h_max, int32_t* h_index);
+/* particle weights w = exp(score - max_score) with their sum and sum of squares
+ * (CParticles::neff, particles.cpp:155-171) */
+int lsa_pf_weights(lsa_ctx* c, const float* d_score, int n, float max_score, float* d_w,
+                   double* h_sum, double* h_sumsq);
+/* Systematic_resampler (src/sensorFusion/SIRFlt.cpp:118-191): parents of offspring
+ * first..first+M-1 out of n_total, grid offset u0 in [0,1) */
+int lsa_pf_resample(lsa_ctx* c, const float* d_w, int n, double u0, int n_total, int first, int M,
+                    int32_t* d_parent);
+int lsa_gather_poses(lsa_ctx* c, const float* d_src, const int32_t* d_parent, int M, float* d_dst);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,17 @@ def lib():
     L.lsa_grid_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.lsa_grid_cloud.argtypes = [vp, C.c_float, vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.lsa_grid_cell.argtypes = [vp, C.c_float, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.lsa_field_create.argtypes = [C.POINTER(vp), vp] + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_double]
+    L.lsa_field_destroy.argtypes = [vp]
+    L.lsa_field_destroy.restype = None
+    L.lsa_field_build.argtypes = [vp, vp, C.c_float, C.c_float, C.c_float]
+    L.lsa_field_build_from_grid.argtypes = [vp, vp, C.c_float, C.c_float, C.c_float]
+    L.lsa_field_download.argtypes = [vp, C.c_int, vp]
+    L.lsa_score_poses.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp]
+    L.lsa_pose_argmax.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    L.lsa_pf_weights.argtypes = [vp, vp, C.c_int, C.c_float, vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.lsa_pf_resample.argtypes = [vp, vp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, vp]
+    L.lsa_gather_poses.argtypes = [vp, vp, vp, C.c_int, vp]
     _lib = L
     return L
 
@@ -334,3 +345,60 @@ class Grid:
         ix, iy = C.c_int(0), C.c_int(0)
         check(self.L.lsa_grid_cell(self.h, px, py, C.byref(ix), C.byref(iy)), "lsa_grid_cell")
         return ix.value, iy.value
+
+
+class Field:
+    """Likelihood field of a grid map (CVPmap::obsLikelyhood3) resident in HBM."""
+
+    def __init__(self, ctx, sx, sy, cx, cy, offx, offy, res):
+        self.L = lib()
+        self.ctx = ctx
+        self.shape = (sx, sy)
+        self.h = vp()
+        check(self.L.lsa_field_create(C.byref(self.h), ctx.h, sx, sy, cx, cy, offx, offy, res), "lsa_field_create")
+
+    def close(self):
+        if self.h:
+            self.L.lsa_field_destroy(self.h)
+            self.h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def build(self, d_prob, max_corr=1.0, free_thr=0.3, unknown=0.5):
+        check(self.L.lsa_field_build(self.h, _dp(d_prob), max_corr, free_thr, unknown), "lsa_field_build")
+
+    def build_from_grid(self, grid, max_corr=1.0, free_thr=0.3, unknown=0.5):
+        check(self.L.lsa_field_build_from_grid(self.h, grid.h, max_corr, free_thr, unknown), "lsa_field_build_from_grid")
+
+    def download(self, what=0):
+        out = np.zeros(self.shape, np.float32)
+        check(self.L.lsa_field_download(self.h, what, _hp(out)), "lsa_field_download")
+        return out
+
+    def score_poses(self, d_scan_x, d_scan_y, n_points, decimation, d_poses, P, d_score):
+        check(self.L.lsa_score_poses(self.h, _dp(d_scan_x), _dp(d_scan_y), n_points, decimation, _dp(d_poses), P,
+                                     _dp(d_score)), "lsa_score_poses")
+
+
+def pose_argmax(ctx, d_score, P):
+    m, i = C.c_float(0), C.c_int32(0)
+    check(lib().lsa_pose_argmax(ctx.h, _dp(d_score), P, C.byref(m), C.byref(i)), "lsa_pose_argmax")
+    return m.value, i.value
+
+
+def pf_weights(ctx, d_score, P, max_score, d_w):
+    s, s2 = C.c_double(0), C.c_double(0)
+    check(lib().lsa_pf_weights(ctx.h, _dp(d_score), P, max_score, _dp(d_w), C.byref(s), C.byref(s2)), "lsa_pf_weights")
+    return s.value, s2.value
+
+
+def pf_resample(ctx, d_w, P, u0, n_total, first, M, d_parent):
+    check(lib().lsa_pf_resample(ctx.h, _dp(d_w), P, u0, n_total, first, M, _dp(d_parent)), "lsa_pf_resample")
+
+
+def gather_poses(ctx, d_src, d_parent, M, d_dst):
+    check(lib().lsa_gather_poses(ctx.h, _dp(d_src), _dp(d_parent), M, _dp(d_dst)), "lsa_gather_poses")

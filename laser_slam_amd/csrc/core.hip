@@ -12,6 +12,7 @@
 
 #include "match_kernels.hip"
 #include "grid_kernels.hip"
+#include "pose_kernels.hip"
 
 static thread_local std::string g_err;
 
@@ -698,6 +699,173 @@ int lsa_grid_cell(const lsa_grid* g, float px, float py, int* ix, int* iy)
     if (!g || !ix || !iy) return fail(LSA_E_ARG, "null argument");
     *ix = lsa::grid_cell1(px, g->G.off_x, g->G.center_x, g->G.res);
     *iy = lsa::grid_cell1(py, g->G.off_y, g->G.center_y, g->G.res);
+    return LSA_OK;
+}
+
+
+// ---- pose scoring / particle filter ---------------------------------------------------
+struct lsa_field {
+    lsa_ctx* c = nullptr;
+    lsa::FieldParam F{};
+    float* d_lik = nullptr;
+    float* d_loglik = nullptr;
+    uint16_t* d_col = nullptr;
+    size_t cells = 0;
+};
+
+int lsa_field_create(lsa_field** out, lsa_ctx* c, int sx, int sy, int cx, int cy, float offx, float offy, double res)
+{
+    if (!out || !c) return fail(LSA_E_ARG, "null argument");
+    if (sx <= 1 || sy <= 1 || !(res > 0)) return fail(LSA_E_ARG, "bad field geometry");
+    HIP_TRY(hipSetDevice(c->device));
+    lsa_field* f = new lsa_field;
+    f->c = c;
+    f->F.size_x = sx; f->F.size_y = sy; f->F.center_x = cx; f->F.center_y = cy;
+    f->F.off_x = offx; f->F.off_y = offy; f->F.res = res;
+    f->F.max_corr = 1.0f; f->F.free_thr = 0.3f; f->F.unknown = 0.5f;      // globaldef.cpp:7-13
+    f->F.K = (int)ceil((double)f->F.max_corr / res);
+    f->cells = (size_t)sx * sy;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&f->d_lik, f->cells * 4)) != hipSuccess ||
+        (e = hipMalloc((void**)&f->d_loglik, f->cells * 4)) != hipSuccess ||
+        (e = hipMalloc((void**)&f->d_col, f->cells * 2)) != hipSuccess) {
+        lsa_field_destroy(f);
+        return fail(LSA_E_NOMEM, "hipMalloc(field)", e);
+    }
+    *out = f;
+    return LSA_OK;
+}
+
+void lsa_field_destroy(lsa_field* f)
+{
+    if (!f) return;
+    hipSetDevice(f->c->device);
+    hipStreamSynchronize(f->c->stream);
+    hipFree(f->d_lik); hipFree(f->d_loglik); hipFree(f->d_col);
+    delete f;
+}
+
+int lsa_field_build(lsa_field* f, const float* d_prob, float max_corr_dist, float free_thr, float unknown_value)
+{
+    if (!f || !d_prob) return fail(LSA_E_ARG, "null argument");
+    if (!(max_corr_dist > 0)) return fail(LSA_E_ARG, "max_corr_dist must be positive");
+    HIP_TRY(hipSetDevice(f->c->device));
+    f->F.max_corr = max_corr_dist; f->F.free_thr = free_thr; f->F.unknown = unknown_value;
+    f->F.K = (int)ceil((double)max_corr_dist / f->F.res);
+    if (f->F.K > 60000) return fail(LSA_E_ARG, "correspondence window too large for the map resolution");
+    const int blocks = blocks_for(f->cells, 256);
+    hipLaunchKernelGGL(lsa::field_col_kernel, dim3(blocks), dim3(256), 0, f->c->stream, f->F, d_prob, f->d_col);
+    hipLaunchKernelGGL(lsa::field_row_kernel, dim3(blocks), dim3(256), 0, f->c->stream, f->F, f->d_col, f->d_lik, f->d_loglik);
+    HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+
+int lsa_field_build_from_grid(lsa_field* f, lsa_grid* g, float max_corr_dist, float free_thr, float unknown_value)
+{
+    if (!f || !g) return fail(LSA_E_ARG, "null argument");
+    if (g->G.size_x != f->F.size_x || g->G.size_y != f->F.size_y) return fail(LSA_E_ARG, "grid / field size mismatch");
+    return lsa_field_build(f, g->d_prob, max_corr_dist, free_thr, unknown_value);
+}
+
+int lsa_field_download(lsa_field* f, int what, float* h_out)
+{
+    if (!f || !h_out || what < 0 || what > 1) return fail(LSA_E_ARG, "bad argument");
+    HIP_TRY(hipMemcpyAsync(h_out, what == 0 ? f->d_lik : f->d_loglik, f->cells * 4, hipMemcpyDeviceToHost, f->c->stream));
+    HIP_TRY(hipStreamSynchronize(f->c->stream));
+    return LSA_OK;
+}
+
+int lsa_score_poses(lsa_field* f, const float* d_scan_x, const float* d_scan_y, int n_points, int decimation,
+                    const float* d_poses, int P, float* d_score)
+{
+    if (!f || !d_scan_x || !d_scan_y || !d_poses || !d_score) return fail(LSA_E_ARG, "null argument");
+    if (n_points <= 0 || decimation <= 0) return fail(LSA_E_ARG, "bad scan size / decimation");
+    if (P <= 0) return LSA_OK;
+    HIP_TRY(hipSetDevice(f->c->device));
+    const int nb = (n_points + decimation - 1) / decimation;
+    if (nb * 8 > 64 * 1024) return fail(LSA_E_ARG, "too many scan points for the LDS stage");
+    hipLaunchKernelGGL(lsa::score_poses_kernel, dim3(blocks_for((size_t)P, 256)), dim3(256), nb * 8, f->c->stream,
+                       f->F, f->d_loglik, d_scan_x, d_scan_y, n_points, decimation, d_poses, P, d_score);
+    HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+
+// best pose of a score array: max score and its index (smallest index among equal scores)
+int lsa_pose_argmax(lsa_ctx* c, const float* d_score, int P, float* h_max, int32_t* h_index)
+{
+    if (!c || !d_score || !h_max || !h_index || P <= 0) return fail(LSA_E_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_staging(c); if (rc) return rc;
+    unsigned long long* key = (unsigned long long*)(c->d_small + 12);      // 8-byte aligned slot
+    HIP_TRY(hipMemsetAsync(key, 0, 8, c->stream));
+    hipLaunchKernelGGL(lsa::argmax_kernel, dim3(blocks_for((size_t)P, 256, 1024)), dim3(256), 0, c->stream, d_score, P, key);
+    HIP_TRY(hipGetLastError());
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, key, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint32_t o = (uint32_t)(h >> 32);
+    const uint32_t bits = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    memcpy(h_max, &bits, 4);
+    *h_index = (int32_t)(0xffffffffu - (uint32_t)h);
+    return LSA_OK;
+}
+
+// w = exp(score - max_score); returns sum w and sum w^2 (for neff and the global normaliser)
+int lsa_pf_weights(lsa_ctx* c, const float* d_score, int P, float max_score, float* d_w, double* h_sum, double* h_sumsq)
+{
+    if (!c || !d_score || !d_w || !h_sum || !h_sumsq || P <= 0) return fail(LSA_E_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const int blocks = blocks_for((size_t)P, 256, 512);
+    double* d_part = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_part, sizeof(double) * 2 * blocks));
+    hipLaunchKernelGGL(lsa::weights_kernel, dim3(blocks), dim3(256), 0, c->stream, d_score, P, max_score, d_w, d_part);
+    std::vector<double> part(2 * (size_t)blocks);
+    hipError_t e = hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_part);
+    if (e != hipSuccess) return fail(LSA_E_HIP, "lsa_pf_weights", e);
+    double s = 0, s2 = 0;
+    for (int b = 0; b < blocks; ++b) { s += part[2 * b]; s2 += part[2 * b + 1]; }
+    *h_sum = s; *h_sumsq = s2;
+    return LSA_OK;
+}
+
+// Systematic resampling over P weights: offspring first..first+M-1 of n_total, one uniform u0
+int lsa_pf_resample(lsa_ctx* c, const float* d_w, int P, double u0, int n_total, int first, int M, int32_t* d_parent)
+{
+    if (!c || !d_w || !d_parent || P <= 0 || M < 0 || n_total <= 0) return fail(LSA_E_ARG, "bad argument");
+    if (!(u0 >= 0.0 && u0 < 1.0)) return fail(LSA_E_ARG, "u0 must be in [0,1)");
+    if (M == 0) return LSA_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const int per = lsa::SCAN_BLOCK * lsa::SCAN_ITEMS, nb = (P + per - 1) / per;
+    double *d_cum = nullptr, *d_bs = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_cum, sizeof(double) * (size_t)P));
+    hipError_t e = hipMalloc((void**)&d_bs, sizeof(double) * (size_t)(nb + 1));
+    if (e != hipSuccess) { hipFree(d_cum); return fail(LSA_E_NOMEM, "hipMalloc", e); }
+    hipLaunchKernelGGL(lsa::scan_block_kernel, dim3(nb), dim3(lsa::SCAN_BLOCK), 0, c->stream, d_w, P, d_cum, d_bs);
+    hipLaunchKernelGGL(lsa::scan_sums_kernel, dim3(1), dim3(64), 0, c->stream, d_bs, nb);
+    hipLaunchKernelGGL(lsa::scan_apply_kernel, dim3(nb), dim3(lsa::SCAN_BLOCK), 0, c->stream, d_cum, P, d_bs);
+    double total = 0;
+    e = hipMemcpyAsync(&total, d_cum + (P - 1), sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && total > 0) {
+        hipLaunchKernelGGL(lsa::resample_kernel, dim3(blocks_for((size_t)M, 256)), dim3(256), 0, c->stream,
+                           d_cum, P, total, u0, n_total, first, M, d_parent);
+        e = hipStreamSynchronize(c->stream);
+    }
+    hipFree(d_cum); hipFree(d_bs);
+    if (e != hipSuccess) return fail(LSA_E_HIP, "lsa_pf_resample", e);
+    if (!(total > 0)) return fail(LSA_E_ARG, "total likelihood zero");          // SIRFlt.cpp:150-152
+    return LSA_OK;
+}
+
+int lsa_gather_poses(lsa_ctx* c, const float* d_src, const int32_t* d_parent, int M, float* d_dst)
+{
+    if (!c || !d_src || !d_parent || !d_dst) return fail(LSA_E_ARG, "null argument");
+    if (M <= 0) return LSA_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(lsa::gather_poses_kernel, dim3(blocks_for((size_t)M, 256)), dim3(256), 0, c->stream, d_src, d_parent, M, d_dst);
+    HIP_TRY(hipGetLastError());
     return LSA_OK;
 }
 

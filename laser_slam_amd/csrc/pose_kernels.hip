@@ -1,0 +1,227 @@
+// Pose scoring against a grid map and the particle-filter step built on it (gfx950).
+//
+// Reference semantics (sources readable, not compilable here: Qt4/Boost/MRPT absent, so
+// this block is "parity unpinned" - SURVEY.md §8c; the checker is oracle/pose_oracle.c):
+//   CVPmap::obsLikelyhood3      src/localization/VPmap.cpp:336-452   likelihood field scorer
+//   CVPmap::x2idx / idx2x       src/localization/VPmap.cpp:98-111
+//   threadLocalization::globalization / topK   src/localization/localization.cpp:483-540, 126-149
+//   CParticles::neff / update   src/localization/particles.cpp:155-171, 321-387
+//   Systematic_resampler        src/sensorFusion/SIRFlt.cpp:118-191
+//
+// The reference fills a per-cell cache lazily with zRandom/50 + 0.95 exp(-d^2/(2 0.35^2)), d =
+// distance from *the beam endpoint that first touched the cell* to the nearest occupied cell
+// within K cells (VPmap.cpp:394-446).  A value that depends on evaluation order cannot be
+// reproduced by a parallel scorer, so the field is precomputed per cell from the cell's own
+// origin (exact windowed Euclidean distance transform); the two differ by less than one cell
+// (2 cm against sigma = 35 cm).
+#include "lsa_device.h"
+
+namespace lsa {
+
+struct FieldParam {
+    int size_x, size_y, center_x, center_y;
+    float off_x, off_y;
+    double res;
+    int K;                    // window half width in cells = ceil(max_corr / res)
+    float max_corr;           // g_maxCorrDistance
+    float free_thr;           // g_free_threshold (0.3)
+    float unknown;            // g_unknown_value (0.5)
+};
+
+// pass A: vertical distance (in cells, <= K, else K+1) to the nearest occupied cell of the same x
+__global__ __launch_bounds__(256) void field_col_kernel(FieldParam F, const float* __restrict__ prob,
+                                                        uint16_t* __restrict__ g)
+{
+    const size_t cells = (size_t)F.size_x * F.size_y;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(c / F.size_y), y = (int)(c - (size_t)x * F.size_y);
+        int best = F.K + 1;
+        for (int dy = 0; dy <= F.K && best > F.K; ++dy) {
+            bool hit = false;
+            if (y + dy < F.size_y) {
+                const float p = prob[(size_t)x * F.size_y + y + dy];
+                hit = p > F.free_thr && fabsf(p - F.unknown) > 0.1f;          // VPmap.cpp:408
+            }
+            if (!hit && y - dy >= 0) {
+                const float p = prob[(size_t)x * F.size_y + y - dy];
+                hit = p > F.free_thr && fabsf(p - F.unknown) > 0.1f;
+            }
+            if (hit) best = dy;
+        }
+        g[c] = (uint16_t)best;
+    }
+}
+
+// pass B: min over dx of dx^2 + g^2 -> likelihood and its logarithm
+__global__ __launch_bounds__(256) void field_row_kernel(FieldParam F, const uint16_t* __restrict__ g,
+                                                        float* __restrict__ lik, float* __restrict__ loglik)
+{
+    const size_t cells = (size_t)F.size_x * F.size_y;
+    const double max_sq = (double)F.max_corr * (double)F.max_corr;
+    const double Q = -0.5 / (0.35 * 0.35);                                    // VPmap.cpp:344,350
+    const double z_rand = (double)(0.05f / 50.0f), z_hit = (double)0.95f;     // :345-348
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(c / F.size_y), y = (int)(c - (size_t)x * F.size_y);
+        int best = 0x7fffffff;
+        const int x0 = x - F.K < 0 ? 0 : x - F.K, x1 = x + F.K > F.size_x - 1 ? F.size_x - 1 : x + F.K;
+        for (int xx = x0; xx <= x1; ++xx) {
+            const int gy = g[(size_t)xx * F.size_y + y];
+            if (gy <= F.K) {
+                const int d = (xx - x) * (xx - x) + gy * gy;
+                best = d < best ? d : best;
+            }
+        }
+        double dmin = max_sq * 10.0;                                          // :374
+        if (best != 0x7fffffff) {
+            const double d = (double)best * F.res * F.res;
+            dmin = d < dmin ? d : dmin;
+        }
+        const float l = (float)(z_rand + z_hit * exp(Q * dmin));               // :444 (cached as float)
+        lik[c] = l;
+        loglik[c] = (float)log((double)l);
+    }
+}
+
+// One thread per pose; scan points staged in LDS; log-likelihoods summed in beam order in double.
+__global__ __launch_bounds__(256) void score_poses_kernel(
+    FieldParam F, const float* __restrict__ loglik, const float* __restrict__ sx, const float* __restrict__ sy,
+    int n_points, int decim, const float* __restrict__ poses, int P, float* __restrict__ score)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* pts = (float2*)smem;
+    const int nb = (n_points + decim - 1) / decim;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) pts[k] = make_float2(sx[k * decim], sy[k * decim]);
+    __syncthreads();
+    const double max_sq = (double)F.max_corr * (double)F.max_corr;
+    const double min_lik = (double)(0.05f / 50.0f) + (double)0.95f * exp(-0.5 / (0.35 * 0.35) * max_sq);   // :364
+    const double log_min = log(min_lik);
+    const unsigned sx1 = (unsigned)(F.size_x - 1), sy1 = (unsigned)(F.size_y - 1);
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const double px = poses[3 * (size_t)p], py = poses[3 * (size_t)p + 1];
+        // th = normAngle(theta - M_PI/2, -M_PI), :366.  VPmap.cpp includes PolarParameter.h, so M_PI is
+        // 3.141592654 there, while normAngle (point.cpp:72-78) wraps with the true 2 pi.
+        double th = (double)poses[3 * (size_t)p + 2] - LSA_ZPI / 2.0;
+        while (th >= -LSA_ZPI + 6.28318530717958647692) th -= 6.28318530717958647692;
+        while (th < -LSA_ZPI) th += 6.28318530717958647692;
+        float cs, sn;
+        sincosf_fast((float)th, sn, cs);
+        double acc = 0.0;
+        for (int k = 0; k < nb; ++k) {
+            const float2 q = pts[k];
+            const float gx = (float)((double)(cs * q.x - sn * q.y) + px);      // :380
+            const float gy = (float)((double)(-cs * q.y - sn * q.x) + py);     // :381
+            const int cx = (int)((double)F.center_x + ((double)(gx - F.off_x) + 0.0005) / F.res);   // x2idx :102-104
+            const int cy = (int)((double)F.center_y + ((double)(gy - F.off_y) + 0.0005) / F.res);
+            if ((unsigned)cx >= sx1 || (unsigned)cy >= sy1) acc += log_min;   // :388-392
+            else acc += (double)loglik[(size_t)cx * F.size_y + cy];
+        }
+        score[p] = (float)acc;
+    }
+}
+
+// ---- reductions / weights / resampling ----------------------------------------------
+// out[0] = max score, out[1] = arg max (as int bits); grid-stride + one atomic per block on a packed key
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ score, int P, unsigned long long* __restrict__ key)
+{
+    unsigned long long best = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        // larger score first; among equal scores the smaller index (topK scans from the front)
+        const unsigned long long k = ((unsigned long long)f_ord(score[p]) << 32) | (unsigned)(0xffffffffu - (unsigned)p);
+        best = k > best ? k : best;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+    }
+    if (lane_id() == 0) atomicMax(key, best);
+}
+
+// w = exp(score - max); block partial sums of w and w^2 (double) -> sums[2*block]
+__global__ __launch_bounds__(256) void weights_kernel(const float* __restrict__ score, int P, float max_score,
+                                                      float* __restrict__ w, double* __restrict__ sums)
+{
+    __shared__ double sh[2][4];
+    double s = 0, s2 = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const float v = expf(score[p] - max_score);
+        w[p] = v;
+        s += v; s2 += (double)v * v;
+    }
+    for (int off = 32; off >= 1; off >>= 1) { s += __shfl_xor(s, off); s2 += __shfl_xor(s2, off); }
+    if (lane_id() == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sums[2 * blockIdx.x] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        sums[2 * blockIdx.x + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    }
+}
+
+// inclusive cumulative sum of w in double, three passes (block sums, scan of block sums, apply)
+constexpr int SCAN_BLOCK = 256, SCAN_ITEMS = 8;
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_block_kernel(const float* __restrict__ w, int P, double* __restrict__ cum,
+                                                                double* __restrict__ block_sum)
+{
+    __shared__ double sh[SCAN_BLOCK];
+    const int base = (blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
+    double v[SCAN_ITEMS], run = 0;
+    #pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { run += base + k < P ? (double)w[base + k] : 0.0; v[k] = run; }
+    sh[threadIdx.x] = run;
+    __syncthreads();
+    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+        const double t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0.0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    const double before = sh[threadIdx.x] - run;
+    #pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < P) cum[base + k] = before + v[k];
+    if (threadIdx.x == SCAN_BLOCK - 1) block_sum[blockIdx.x] = sh[threadIdx.x];
+}
+
+__global__ void scan_sums_kernel(double* __restrict__ block_sum, int nblocks)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double run = 0;
+        for (int b = 0; b < nblocks; ++b) { const double t = block_sum[b]; block_sum[b] = run; run += t; }
+    }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(double* __restrict__ cum, int P, const double* __restrict__ block_off)
+{
+    const int base = (blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
+    const double o = block_off[blockIdx.x];
+    #pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < P) cum[base + k] += o;
+}
+
+// Systematic resampling (SIRFlt.cpp:118-191): offspring m in [first, first + M) sits at
+// s = (u0 + m) * total / n_total on the cumulative weights; its parent is the first particle
+// whose cumulative weight exceeds s.
+__global__ __launch_bounds__(256) void resample_kernel(const double* __restrict__ cum, int P, double total, double u0,
+                                                       int n_total, int first, int M, int* __restrict__ parent)
+{
+    const double step = total / (double)n_total;
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+        const double s = (u0 + (double)(first + m)) * step;
+        int lo = 0, hi = P - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s < cum[mid]) hi = mid; else lo = mid + 1;
+        }
+        parent[m] = lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_poses_kernel(const float* __restrict__ src, const int* __restrict__ parent, int M,
+                                                           float* __restrict__ dst)
+{
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+        const size_t s = 3 * (size_t)parent[m];
+        dst[3 * (size_t)m] = src[s]; dst[3 * (size_t)m + 1] = src[s + 1]; dst[3 * (size_t)m + 2] = src[s + 2];
+    }
+}
+
+} // namespace lsa

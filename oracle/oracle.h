@@ -117,6 +117,16 @@ void orc_pmap_update(orc_pmap* m, const float* gx, const float* gy, int n, float
 void orc_pmap_compute(orc_pmap* m);
 int  orc_pmap_cloud(const orc_pmap* m, float thre, float* x, float* y, int cap);
 
+/* ---- pose scoring / particle filter (src/localization, src/sensorFusion): PARITY UNPINNED,
+ *      see pose_oracle.c ---- */
+void orc_likelihood_field(const float* prob, int sx, int sy, double res, float max_corr,
+                          float free_thr, float unknown, float* lik);
+void orc_score_poses(const float* lik, int sx, int sy, int cx0, int cy0, float offx, float offy, double res,
+                     float max_corr, const float* scan_x, const float* scan_y, int n_points, int decim,
+                     const float* poses, int P, float* score);
+void orc_systematic_resample(const float* w, int P, double u0, int n_out, int* parent);
+double orc_neff(const float* w, int P);
+
 #ifdef __cplusplus
 }
 #endif

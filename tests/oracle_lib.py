@@ -249,6 +249,46 @@ def grid_line(sx, sy, ex, ey, lib=None, fn="orc_grid_line"):
     return np.stack([xs[:n], ys[:n]], 1)
 
 
+def likelihood_field(prob, res, max_corr=1.0, free_thr=0.3, unknown=0.5):
+    if Oracle._L is None:
+        Oracle._L = _load_oracle()
+    prob = np.ascontiguousarray(prob, f32)
+    out = np.zeros_like(prob)
+    Oracle._L.orc_likelihood_field(_p(prob), prob.shape[0], prob.shape[1], C.c_double(res), C.c_float(max_corr),
+                                   C.c_float(free_thr), C.c_float(unknown), _p(out))
+    return out
+
+
+def score_poses(lik, cx, cy, offx, offy, res, scan_x, scan_y, decim, poses, max_corr=1.0):
+    if Oracle._L is None:
+        Oracle._L = _load_oracle()
+    lik = np.ascontiguousarray(lik, f32)
+    sx_, sy_ = np.ascontiguousarray(scan_x, f32), np.ascontiguousarray(scan_y, f32)
+    poses = np.ascontiguousarray(poses, f32)
+    out = np.zeros(len(poses), f32)
+    Oracle._L.orc_score_poses(_p(lik), lik.shape[0], lik.shape[1], cx, cy, C.c_float(offx), C.c_float(offy),
+                              C.c_double(res), C.c_float(max_corr), _p(sx_), _p(sy_), len(sx_), decim, _p(poses),
+                              len(poses), _p(out))
+    return out
+
+
+def systematic_resample(w, u0, n_out):
+    if Oracle._L is None:
+        Oracle._L = _load_oracle()
+    w = np.ascontiguousarray(w, f32)
+    parent = np.zeros(n_out, i32)
+    Oracle._L.orc_systematic_resample(_p(w), len(w), C.c_double(u0), n_out, _p(parent))
+    return parent
+
+
+def neff(w):
+    if Oracle._L is None:
+        Oracle._L = _load_oracle()
+    w = np.ascontiguousarray(w, f32)
+    Oracle._L.orc_neff.restype = C.c_double
+    return Oracle._L.orc_neff(_p(w), len(w))
+
+
 # ---------------------------------------------------------------------------
 # reference built in place (only in the build container / when _ref travelled)
 

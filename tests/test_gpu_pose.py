@@ -1,0 +1,126 @@
+"""GPU: likelihood field, pose scoring, arg-max, weights and systematic resampling against
+oracle/pose_oracle.c.  PARITY UNPINNED (the reference's localization module needs Qt4 / Boost /
+MRPT and cannot be built): the oracle restates the readable source; tolerances cover exp/log
+implementation differences only."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world():
+    import torch
+    from laser_slam_amd import capi, synth
+    assert torch.cuda.is_available()
+    rng = np.random.default_rng(0)
+    sx, sy, res = 260, 200, 0.05
+    prob = np.full((sx, sy), 0.1, np.float32)              # free space
+    prob[:, :3] = 0.9; prob[:, -3:] = 0.9; prob[:3, :] = 0.9; prob[-3:, :] = 0.9     # walls
+    prob[100:104, 60:140] = 0.95                                                     # a wall segment
+    prob[180:200, 20:40] = 0.5                                                       # unknown block
+    prob[40:60, 150:170] = 0.45                                                      # "unknown-ish" (|p-0.5| <= 0.1)
+    prob += rng.uniform(0, 0.02, prob.shape).astype(np.float32)
+    ctx = capi.Context(capi.param_preset("LMS151"))
+    fld = capi.Field(ctx, sx, sy, 0, 0, 0.0, 0.0, res)
+    d_prob = torch.from_numpy(prob).cuda()
+    fld.build(d_prob, 1.0, 0.3, 0.5)
+    return dict(torch=torch, capi=capi, ctx=ctx, fld=fld, prob=prob, res=res, rng=rng)
+
+
+def test_field_matches_oracle(world):
+    from oracle_lib import likelihood_field
+    lik_o = likelihood_field(world["prob"], world["res"])
+    lik_g = world["fld"].download(0)
+    assert np.allclose(lik_g, lik_o, rtol=2e-6, atol=1e-9)
+    # exact where it matters: the windowed distance transform picks the same nearest cell
+    assert np.array_equal(lik_g == lik_g.max(), lik_o == lik_o.max())
+    log_g = world["fld"].download(1)
+    assert np.allclose(log_g, np.log(lik_o.astype(np.float64)), rtol=0, atol=2e-6)
+
+
+def test_scores_argmax_weights_resample(world):
+    torch, capi, ctx, fld = world["torch"], world["capi"], world["ctx"], world["fld"]
+    from oracle_lib import likelihood_field, neff, score_poses, systematic_resample
+    rng = world["rng"]
+    n = 541
+    ang = np.linspace(-0.75 * np.pi, 0.75 * np.pi, n)
+    rr = rng.uniform(0.5, 6.0, n)
+    scan_x = (rr * np.cos(ang)).astype(np.float32); scan_y = (rr * np.sin(ang)).astype(np.float32)
+    P = 5000
+    poses = np.stack([rng.uniform(-1, 14, P), rng.uniform(-1, 11, P), rng.uniform(-7, 7, P)], 1).astype(np.float32)
+    d_x, d_y, d_p = (torch.from_numpy(a).cuda() for a in (scan_x, scan_y, poses))
+    d_s = torch.zeros(P, device="cuda")
+    fld.score_poses(d_x, d_y, n, 3, d_p, P, d_s)
+    ctx.sync()
+    got = d_s.cpu().numpy()
+    lik_o = likelihood_field(world["prob"], world["res"])
+    want = score_poses(lik_o, 0, 0, 0.0, 0.0, world["res"], scan_x, scan_y, 3, poses)
+    assert np.allclose(got, want, rtol=1e-5, atol=2e-3), np.abs(got - want).max()
+    # decimation 1 (np < 100 rule of the reference is the caller's choice here)
+    fld.score_poses(d_x, d_y, 90, 1, d_p, 64, d_s)
+    ctx.sync()
+    want1 = score_poses(lik_o, 0, 0, 0.0, 0.0, world["res"], scan_x[:90], scan_y[:90], 1, poses[:64])
+    assert np.allclose(d_s.cpu().numpy()[:64], want1, rtol=1e-5, atol=1e-3)
+    fld.score_poses(d_x, d_y, n, 3, d_p, P, d_s)
+    ctx.sync()
+    m, i = capi.pose_argmax(ctx, d_s, P)
+    assert m == got.max() and i == int(np.argmax(got))
+    # weights / neff
+    d_w = torch.zeros(P, device="cuda")
+    s, s2 = capi.pf_weights(ctx, d_s, P, m, d_w)
+    w = d_w.cpu().numpy()
+    assert np.allclose(w, np.exp(got - m), rtol=2e-6, atol=1e-30)
+    assert abs(s - w.astype(np.float64).sum()) < 1e-9 * s and abs(s2 - (w.astype(np.float64) ** 2).sum()) < 1e-9 * s2
+    assert abs(1.0 / (1.0 + s2 / (s * s)) - neff(w)) < 1e-9
+    # systematic resampling: all offspring, and a shard of them
+    d_par = torch.zeros(P, dtype=torch.int32, device="cuda")
+    capi.pf_resample(ctx, d_w, P, 0.6180339, P, 0, P, d_par)
+    par_o = systematic_resample(w, 0.6180339, P)
+    par_g = d_par.cpu().numpy()
+    # plain vs Kahan cumulative sums can move a boundary by one particle at most, and only
+    # where an offspring lands within rounding of a cumulative weight
+    assert (par_g != par_o).mean() < 1e-3 and np.abs(par_g - par_o).max() <= 1
+    capi.pf_resample(ctx, d_w, P, 0.6180339, P, 1234, 777, d_par)
+    assert np.array_equal(d_par.cpu().numpy()[:777], par_g[1234:1234 + 777])
+    d_new = torch.zeros(P, 3, device="cuda")
+    capi.pf_resample(ctx, d_w, P, 0.6180339, P, 0, P, d_par)
+    capi.gather_poses(ctx, d_p, d_par, P, d_new)
+    ctx.sync()
+    assert np.array_equal(d_new.cpu().numpy(), poses[par_g])
+
+
+def test_sharded_filter_single_gpu(world):
+    """ShardedParticleFilter wired to the HIP entry points (world size 1)."""
+    torch, capi, ctx, fld = world["torch"], world["capi"], world["ctx"], world["fld"]
+    from laser_slam_amd import pf
+    rng = np.random.default_rng(4)
+    n = 361
+    ang = np.linspace(-np.pi / 2, np.pi / 2, n)
+    scan_x = (3.0 * np.cos(ang)).astype(np.float32); scan_y = (3.0 * np.sin(ang)).astype(np.float32)
+    d_x, d_y = torch.from_numpy(scan_x).cuda(), torch.from_numpy(scan_y).cuda()
+    P = 20000
+    poses = torch.from_numpy(np.stack([rng.uniform(1, 12, P), rng.uniform(1, 9, P), rng.uniform(-3, 3, P)], 1).astype(np.float32)).cuda()
+
+    def score(p):
+        s = torch.zeros(p.shape[0], device="cuda"); fld.score_poses(d_x, d_y, n, 3, p, p.shape[0], s); return s
+
+    def argmax(s):
+        return capi.pose_argmax(ctx, s, s.shape[0])
+
+    def weights(s, gmax):
+        w = torch.zeros_like(s); a, b = capi.pf_weights(ctx, s, s.shape[0], gmax, w); return w, a, b
+
+    def resample(all_w, u0, first, M):
+        par = torch.zeros(M, dtype=torch.int32, device="cuda")
+        capi.pf_resample(ctx, all_w, all_w.shape[0], u0, all_w.shape[0], first, M, par); return par
+
+    def gather(all_p, par):
+        out = torch.zeros(par.shape[0], 3, device="cuda"); capi.gather_poses(ctx, all_p, par, par.shape[0], out); return out
+
+    f = pf.ShardedParticleFilter(P, score, argmax, weights, resample, gather, device="cuda")
+    new, info = f.step(poses, 0.25)
+    ctx.sync()
+    assert info["resampled"] and new.shape == (P, 3)
+    # resampling concentrates the particles on high-score poses
+    assert float(score(new).mean()) > float(score(poses).mean())
