@@ -213,6 +213,23 @@ def extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p):
     res["grid_update_GBps_algorithmic"] = nb * n * (cells * 8 + 16) / (ms * 1e-3) / 1e9
     ms = timed(lambda: grid.compute_prob(), reps=3)
     res["grid_prob_GBps"] = 12 * 4096 * 4096 / (ms * 1e-3) / 1e9
+    # pose scoring (likelihood field of the map just built): 1 M poses around the path, 1081-beam scan / 3
+    fld = capi.Field(ctx, 4096, 4096, 1024, 1024, 0.0, 0.0, 0.05)
+    t0 = time.perf_counter()
+    fld.build_from_grid(grid); ctx.sync()
+    res["field_build_ms_4096sq"] = (time.perf_counter() - t0) * 1e3
+    P = 1 << 20
+    rng = np.random.default_rng(1)
+    pp = np.stack([10 + rng.normal(0, 1.0, P), 7.5 + rng.normal(0, 1.0, P), rng.normal(0, 0.3, P)], 1).astype(np.float32)
+    d_p = torch.from_numpy(pp).cuda()
+    sxy = (rr[0][:, None] * np.stack([np.cos(fi), np.sin(fi)], 1)).astype(np.float32)
+    d_sx, d_sy = torch.from_numpy(np.ascontiguousarray(sxy[:, 0])).cuda(), torch.from_numpy(np.ascontiguousarray(sxy[:, 1])).cuda()
+    d_sc = torch.zeros(P, device="cuda")
+    torch.cuda.synchronize()
+    ms = timed(lambda: fld.score_poses(d_sx, d_sy, n, 3, d_p, P, d_sc), reps=3)
+    res["score_poses_per_s"] = P / (ms * 1e-3)
+    res["score_gather_GBps"] = P * ((n + 2) // 3) * 4 / (ms * 1e-3) / 1e9
+    fld.close()
     grid.close()
     return res
 

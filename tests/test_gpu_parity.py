@@ -50,6 +50,7 @@ def run_match(torch, ctx, which, r, bad, seg, ref_idx, act_idx, init=None, want_
     na = torch.zeros(B, dtype=torch.int32, device="cuda") if want_err else None
     st = torch.zeros(B, dtype=torch.int32, device="cuda")
     it = torch.zeros(B, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()          # the context launches on its own stream: fills must have landed
     ctx.match_batch(which, B, d_r, d_bad, d_seg, d_ri, d_ai, pose, d_init, ret, exy, na, st, it)
     ctx.sync()
     out = dict(pose=pose.cpu().numpy(), ret=ret.cpu().numpy(), status=st.cpu().numpy(), iters=it.cpu().numpy())
@@ -81,6 +82,7 @@ def test_preprocess(name, torch_mod):
     S = g["raw_r"].shape[0]
     d_r = dev(torch, g["raw_r"], np.float32); d_bad = dev(torch, g["raw_bad"], np.uint8)
     d_seg = torch.zeros(g["raw_r"].shape, dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
     ctx.preprocess_batch(S, d_r, d_bad, d_seg)
     ctx.sync()
     assert same_bits(d_r.cpu().numpy(), g["pre_r"])
@@ -102,6 +104,7 @@ def test_scan_project(name, torch_mod):
     d_seg = dev(torch, g["pre_seg"][idx], np.int16); d_pose = dev(torch, g["stage_pose"], np.float32)
     nr = torch.zeros(d_r.shape, dtype=torch.float32, device="cuda")
     nb = torch.zeros(d_r.shape, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
     ctx.scan_project_batch(len(idx), d_r, d_bad, d_seg, d_pose, nr, nb)
     ctx.sync()
     assert same_bits(nr.cpu().numpy(), g["stage_new_r"])
@@ -229,7 +232,9 @@ def test_failure_status_codes(torch_mod):
     r = np.full((2, n), p.max_range + 1, np.float32)          # nothing in range
     d_r = dev(torch, r, np.float32); d_bad = torch.zeros(2, n, dtype=torch.uint8, device="cuda")
     d_seg = torch.zeros(2, n, dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
     ctx.preprocess_batch(2, d_r, d_bad, d_seg)
+    ctx.sync()
     out_p = run_match(torch, ctx, 0, d_r.cpu().numpy(), d_bad.cpu().numpy(), d_seg.cpu().numpy(), [0], [1])
     out_i = run_match(torch, ctx, 1, d_r.cpu().numpy(), d_bad.cpu().numpy(), d_seg.cpu().numpy(), [0], [1])
     assert out_p["status"][0] == capi.ST_NO_ORIENT

@@ -24,7 +24,9 @@ def world():
     ctx = capi.Context(capi.param_preset("LMS151"))
     fld = capi.Field(ctx, sx, sy, 0, 0, 0.0, 0.0, res)
     d_prob = torch.from_numpy(prob).cuda()
+    torch.cuda.synchronize()
     fld.build(d_prob, 1.0, 0.3, 0.5)
+    ctx.sync()
     return dict(torch=torch, capi=capi, ctx=ctx, fld=fld, prob=prob, res=res, rng=rng)
 
 
@@ -51,6 +53,7 @@ def test_scores_argmax_weights_resample(world):
     poses = np.stack([rng.uniform(-1, 14, P), rng.uniform(-1, 11, P), rng.uniform(-7, 7, P)], 1).astype(np.float32)
     d_x, d_y, d_p = (torch.from_numpy(a).cuda() for a in (scan_x, scan_y, poses))
     d_s = torch.zeros(P, device="cuda")
+    torch.cuda.synchronize()          # the context launches on its own stream
     fld.score_poses(d_x, d_y, n, 3, d_p, P, d_s)
     ctx.sync()
     got = d_s.cpu().numpy()
@@ -68,6 +71,7 @@ def test_scores_argmax_weights_resample(world):
     assert m == got.max() and i == int(np.argmax(got))
     # weights / neff
     d_w = torch.zeros(P, device="cuda")
+    torch.cuda.synchronize()
     s, s2 = capi.pf_weights(ctx, d_s, P, m, d_w)
     w = d_w.cpu().numpy()
     assert np.allclose(w, np.exp(got - m), rtol=2e-6, atol=1e-30)
@@ -75,6 +79,7 @@ def test_scores_argmax_weights_resample(world):
     assert abs(1.0 / (1.0 + s2 / (s * s)) - neff(w)) < 1e-9
     # systematic resampling: all offspring, and a shard of them
     d_par = torch.zeros(P, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
     capi.pf_resample(ctx, d_w, P, 0.6180339, P, 0, P, d_par)
     par_o = systematic_resample(w, 0.6180339, P)
     par_g = d_par.cpu().numpy()
@@ -84,6 +89,7 @@ def test_scores_argmax_weights_resample(world):
     capi.pf_resample(ctx, d_w, P, 0.6180339, P, 1234, 777, d_par)
     assert np.array_equal(d_par.cpu().numpy()[:777], par_g[1234:1234 + 777])
     d_new = torch.zeros(P, 3, device="cuda")
+    torch.cuda.synchronize()
     capi.pf_resample(ctx, d_w, P, 0.6180339, P, 0, P, d_par)
     capi.gather_poses(ctx, d_p, d_par, P, d_new)
     ctx.sync()
@@ -102,21 +108,24 @@ def test_sharded_filter_single_gpu(world):
     P = 20000
     poses = torch.from_numpy(np.stack([rng.uniform(1, 12, P), rng.uniform(1, 9, P), rng.uniform(-3, 3, P)], 1).astype(np.float32)).cuda()
 
+    # the context launches on its own HIP stream: hand results back to torch only after a sync
     def score(p):
-        s = torch.zeros(p.shape[0], device="cuda"); fld.score_poses(d_x, d_y, n, 3, p, p.shape[0], s); return s
+        s = torch.zeros(p.shape[0], device="cuda"); torch.cuda.synchronize()
+        fld.score_poses(d_x, d_y, n, 3, p, p.shape[0], s); ctx.sync(); return s
 
     def argmax(s):
         return capi.pose_argmax(ctx, s, s.shape[0])
 
     def weights(s, gmax):
-        w = torch.zeros_like(s); a, b = capi.pf_weights(ctx, s, s.shape[0], gmax, w); return w, a, b
+        w = torch.zeros_like(s); torch.cuda.synchronize(); a, b = capi.pf_weights(ctx, s, s.shape[0], gmax, w); return w, a, b
 
     def resample(all_w, u0, first, M):
-        par = torch.zeros(M, dtype=torch.int32, device="cuda")
+        par = torch.zeros(M, dtype=torch.int32, device="cuda"); torch.cuda.synchronize()
         capi.pf_resample(ctx, all_w, all_w.shape[0], u0, all_w.shape[0], first, M, par); return par
 
     def gather(all_p, par):
-        out = torch.zeros(par.shape[0], 3, device="cuda"); capi.gather_poses(ctx, all_p, par, par.shape[0], out); return out
+        out = torch.zeros(par.shape[0], 3, device="cuda"); torch.cuda.synchronize()
+        capi.gather_poses(ctx, all_p, par, par.shape[0], out); ctx.sync(); return out
 
     f = pf.ShardedParticleFilter(P, score, argmax, weights, resample, gather, device="cuda")
     new, info = f.step(poses, 0.25)
