@@ -230,6 +230,27 @@ int lsa_pf_resample(lsa_ctx* c, const float* d_w, int n, double u0, int n_total,
                     int32_t* d_parent);
 int lsa_gather_poses(lsa_ctx* c, const float* d_src, const int32_t* d_parent, int M, float* d_dst);
 
+/* ---- point-to-point ICP on 2D point clouds: CICPWarpper, src/zhicp/ZHIcp_Warpper.{h,cpp}
+ *      (forwards to MRPT 0.9.6 CICP::Align, icpClassic — third-party, PARITY UNPINNED) ---- */
+typedef struct lsa_p2p_options {
+    int32_t max_iterations;            /* 100   ZHIcp_Warpper.cpp:46 */
+    float   threshold_dist;            /* 0.75 m            :48 */
+    float   threshold_ang;             /* 10 deg in rad     :47 */
+    float   alfa;                      /* 0.5               :49 */
+    float   smallest_threshold_dist;   /* 0.05 m            :50 */
+} lsa_p2p_options;
+int lsa_p2p_options_default(lsa_p2p_options* o);
+/* B problems; clouds are concatenated with offset arrays [B+1] (metres); init pose [B][3] doubles.
+ * d_out16 [B][16] doubles: x, y, phi, goodness, mean sq. residual, iterations, pairs,
+ * cov xx xy xphi yy yphi phiphi, 3 unused. */
+int lsa_p2p_icp_batch(lsa_ctx* c, int n_problems, const float* d_ref_x, const float* d_ref_y,
+                      const int32_t* d_ref_off, const float* d_cur_x, const float* d_cur_y,
+                      const int32_t* d_cur_off, int n_ref_total, int n_cur_total,
+                      const double* d_init_pose, const lsa_p2p_options* opt, double* d_out16);
+int lsa_p2p_icp_host(lsa_ctx* c, const float* h_ref_x, const float* h_ref_y, int n_ref,
+                     const float* h_cur_x, const float* h_cur_y, int n_cur, const double h_init_pose[3],
+                     const lsa_p2p_options* opt, double h_out16[16]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,8 @@ def lib():
     L.lsa_pf_weights.argtypes = [vp, vp, C.c_int, C.c_float, vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.lsa_pf_resample.argtypes = [vp, vp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, vp]
     L.lsa_gather_poses.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.lsa_p2p_icp_host.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp]
+    L.lsa_p2p_icp_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     _lib = L
     return L
 
@@ -402,3 +404,14 @@ def pf_resample(ctx, d_w, P, u0, n_total, first, M, d_parent):
 
 def gather_poses(ctx, d_src, d_parent, M, d_dst):
     check(lib().lsa_gather_poses(ctx.h, _dp(d_src), _dp(d_parent), M, _dp(d_dst)), "lsa_gather_poses")
+
+
+def p2p_icp_host(ctx, ref_x, ref_y, cur_x, cur_y, init_pose):
+    """CICPWarpper::ICPMatch with the reference's options; returns the 16-double result record."""
+    rx, ry = np.ascontiguousarray(ref_x, np.float32), np.ascontiguousarray(ref_y, np.float32)
+    cx, cy = np.ascontiguousarray(cur_x, np.float32), np.ascontiguousarray(cur_y, np.float32)
+    init = np.ascontiguousarray(init_pose, np.float64)
+    out = np.zeros(16, np.float64)
+    check(lib().lsa_p2p_icp_host(ctx.h, _hp(rx), _hp(ry), len(rx), _hp(cx), _hp(cy), len(cx), _hp(init), None, _hp(out)),
+          "lsa_p2p_icp_host")
+    return out

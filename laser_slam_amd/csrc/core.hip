@@ -13,6 +13,7 @@
 #include "match_kernels.hip"
 #include "grid_kernels.hip"
 #include "pose_kernels.hip"
+#include "p2p_kernels.hip"
 
 static thread_local std::string g_err;
 
@@ -867,6 +868,81 @@ int lsa_gather_poses(lsa_ctx* c, const float* d_src, const int32_t* d_parent, in
     hipLaunchKernelGGL(lsa::gather_poses_kernel, dim3(blocks_for((size_t)M, 256)), dim3(256), 0, c->stream, d_src, d_parent, M, d_dst);
     HIP_TRY(hipGetLastError());
     return LSA_OK;
+}
+
+
+// ---- point-to-point ICP on point clouds (CICPWarpper) ----------------------------------
+int lsa_p2p_options_default(lsa_p2p_options* o)
+{
+    if (!o) return fail(LSA_E_ARG, "null argument");
+    o->max_iterations = 100;                 // ZHIcp_Warpper.cpp:46-51
+    o->threshold_dist = 0.75f;
+    o->threshold_ang = (float)(10.0 * 3.14159265358979323846 / 180.0);
+    o->alfa = 0.5f;
+    o->smallest_threshold_dist = 0.05f;
+    return LSA_OK;
+}
+
+int lsa_p2p_icp_batch(lsa_ctx* c, int B, const float* d_ref_x, const float* d_ref_y, const int32_t* d_ref_off,
+                      const float* d_cur_x, const float* d_cur_y, const int32_t* d_cur_off, int n_ref_total,
+                      int n_cur_total, const double* d_init_pose, const lsa_p2p_options* opt, double* d_out16)
+{
+    if (!c || !d_ref_x || !d_ref_y || !d_ref_off || !d_cur_x || !d_cur_y || !d_cur_off || !d_init_pose || !d_out16)
+        return fail(LSA_E_ARG, "null argument");
+    if (B <= 0) return LSA_OK;
+    lsa_p2p_options o;
+    if (opt) o = *opt; else lsa_p2p_options_default(&o);
+    if (o.max_iterations < 1 || !(o.alfa > 0 && o.alfa < 1) || !(o.threshold_dist > 0))
+        return fail(LSA_E_ARG, "bad ICP options");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long* d_owner = nullptr;
+    int* d_match = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_owner, sizeof(unsigned long long) * (size_t)(n_ref_total > 0 ? n_ref_total : 1)));
+    hipError_t e = hipMalloc((void**)&d_match, sizeof(int) * (size_t)(n_cur_total > 0 ? n_cur_total : 1));
+    if (e != hipSuccess) { hipFree(d_owner); return fail(LSA_E_NOMEM, "hipMalloc", e); }
+    lsa::P2PParam P = {o.max_iterations, o.threshold_dist, o.threshold_ang, o.alfa, o.smallest_threshold_dist};
+    hipLaunchKernelGGL(lsa::p2p_icp_kernel, dim3(B), dim3(lsa::P2P_THREADS), 0, c->stream, P, B, d_ref_x, d_ref_y,
+                       d_ref_off, d_cur_x, d_cur_y, d_cur_off, d_init_pose, d_owner, d_match, d_out16);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_owner); hipFree(d_match);
+    if (e != hipSuccess) return fail(LSA_E_HIP, "p2p_icp_kernel", e);
+    return LSA_OK;
+}
+
+// CICPWarpper::ICPMatch for one host problem (ZHIcp_Warpper.cpp:125-176)
+int lsa_p2p_icp_host(lsa_ctx* c, const float* ref_x, const float* ref_y, int n_ref, const float* cur_x,
+                     const float* cur_y, int n_cur, const double init_pose[3], const lsa_p2p_options* opt,
+                     double out16[16])
+{
+    if (!c || !init_pose || !out16 || n_ref < 0 || n_cur < 0) return fail(LSA_E_ARG, "bad argument");
+    if ((n_ref > 0 && (!ref_x || !ref_y)) || (n_cur > 0 && (!cur_x || !cur_y))) return fail(LSA_E_ARG, "null cloud");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t fb = sizeof(float) * (size_t)(2 * n_ref + 2 * n_cur + 4);
+    char* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, fb + 4 * sizeof(int32_t) + 3 * sizeof(double) + 16 * sizeof(double) + 64));
+    float* d_rx = (float*)d; float* d_ry = d_rx + n_ref; float* d_cx = d_ry + n_ref; float* d_cy = d_cx + n_cur;
+    char* q = d + ((fb + 7) & ~(size_t)7);
+    double* d_init = (double*)q; double* d_out = d_init + 3; int32_t* d_off = (int32_t*)(d_out + 16);
+    const int32_t off[4] = {0, n_ref, 0, n_cur};
+    hipStream_t st = c->stream;
+    hipError_t e = hipSuccess;
+    if (n_ref) { e = hipMemcpyAsync(d_rx, ref_x, sizeof(float) * n_ref, hipMemcpyHostToDevice, st);
+                 if (e == hipSuccess) e = hipMemcpyAsync(d_ry, ref_y, sizeof(float) * n_ref, hipMemcpyHostToDevice, st); }
+    if (e == hipSuccess && n_cur) { e = hipMemcpyAsync(d_cx, cur_x, sizeof(float) * n_cur, hipMemcpyHostToDevice, st);
+                 if (e == hipSuccess) e = hipMemcpyAsync(d_cy, cur_y, sizeof(float) * n_cur, hipMemcpyHostToDevice, st); }
+    if (e == hipSuccess) e = hipMemcpyAsync(d_init, init_pose, 24, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    int rc = LSA_OK;
+    if (e != hipSuccess) rc = fail(LSA_E_HIP, "lsa_p2p_icp_host upload", e);
+    if (rc == LSA_OK) rc = lsa_p2p_icp_batch(c, 1, d_rx, d_ry, d_off, d_cx, d_cy, d_off + 2, n_ref, n_cur, d_init, opt, d_out);
+    if (rc == LSA_OK) {
+        e = hipMemcpy(out16, d_out, 16 * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(LSA_E_HIP, "lsa_p2p_icp_host download", e);
+    }
+    hipFree(d);
+    return rc;
 }
 
 } // extern "C"

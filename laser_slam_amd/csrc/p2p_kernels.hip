@@ -1,0 +1,166 @@
+// Point-to-point ICP between two 2D point clouds on gfx950 — the arithmetic behind the
+// reference's CICPWarpper (src/zhicp/ZHIcp_Warpper.{h,cpp}), which forwards to MRPT 0.9.6
+// `mrpt::slam::CICP::Align` with icpClassic and the options of ZHIcp_Warpper.cpp:43-53:
+//   maxIterations 100, thresholdDist 0.75 m, thresholdAng 10 deg, ALFA 0.5,
+//   smallestThresholdDist 0.05 m, doRANSAC false.
+// MRPT is an un-vendored third-party library (src/CMakeLists.txt:33) => PARITY UNPINNED.
+// This restates the published classic-ICP scheme those options parameterise:
+//   repeat: every point of the second map, moved by the current pose, is paired with its
+//           nearest neighbour of the first map if closer than thresholdDist + thresholdAng *
+//           (distance to the pose origin); each first-map point keeps only its closest
+//           partner; closed-form 2D rigid fit on the pairs; when the pose stops moving
+//           (1e-6) both thresholds shrink by ALFA until thresholdDist < smallestThresholdDist.
+//   goodness = paired fraction of the second map (what CICPWarpper::ICPMatch returns).
+//
+// One 256-thread workgroup per problem; the first map is streamed through LDS in tiles and
+// every lane scans it for its own points (brute force: the clouds are a few hundred to a
+// few thousand points, src/zhicp/data/*.log).  Sums use a fixed-order tree in double, so the
+// result does not depend on scheduling.
+#include "lsa_device.h"
+
+namespace lsa {
+
+struct P2PParam {
+    int max_iter;
+    float thr_dist, thr_ang, alfa, smallest_thr;
+};
+
+constexpr int P2P_THREADS = 256, P2P_TILE = 2048;
+
+// deterministic block sum of `v` (double); result valid in every thread
+__device__ __forceinline__ double block_sum(double v, double* sh)
+{
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if (lane_id() == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// problem b: ref cloud [ref_off[b], ref_off[b+1]), cur cloud [cur_off[b], cur_off[b+1])
+// out[b*16 ..]: x, y, phi, goodness, quality(mean sq. residual), iterations, n_pairs, cov(xx,xy,xphi,yy,yphi,phiphi)
+__global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
+    P2PParam O, int B, const float* __restrict__ ref_x, const float* __restrict__ ref_y, const int* __restrict__ ref_off,
+    const float* __restrict__ cur_x, const float* __restrict__ cur_y, const int* __restrict__ cur_off,
+    const double* __restrict__ init_pose, unsigned long long* __restrict__ owner, int* __restrict__ match,
+    double* __restrict__ out)
+{
+    __shared__ float2 tile[P2P_TILE];
+    __shared__ double sh[8];
+    const int tid = threadIdx.x;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const int r0 = ref_off[b], n1 = ref_off[b + 1] - r0, c0 = cur_off[b], n2 = cur_off[b + 1] - c0;
+        double qx = init_pose[3 * b], qy = init_pose[3 * b + 1], qphi = init_pose[3 * b + 2];
+        float thr_d = O.thr_dist, thr_a = O.thr_ang;
+        int iter = 0, n_pairs = 0;
+        double mse = 0.0, cov[6] = {0, 0, 0, 0, 0, 0};
+        bool keep = n1 > 0 && n2 > 0;
+        while (keep && iter < O.max_iter) {
+            const float cphi = (float)cos(qphi), sphi = (float)sin(qphi);
+            for (int j = tid; j < n1; j += P2P_THREADS) owner[r0 + j] = ~0ull;
+            __syncthreads();
+            // nearest first-map point of every second-map point
+            for (int base = 0; base < n2; base += P2P_THREADS) {
+                const int i = base + tid;
+                float gx = 0, gy = 0, best = 3.0e38f;
+                int bj = -1;
+                if (i < n2) {
+                    const float px = cur_x[c0 + i], py = cur_y[c0 + i];
+                    gx = (float)qx + cphi * px - sphi * py;
+                    gy = (float)qy + sphi * px + cphi * py;
+                }
+                for (int t0 = 0; t0 < n1; t0 += P2P_TILE) {
+                    const int tn = n1 - t0 < P2P_TILE ? n1 - t0 : P2P_TILE;
+                    __syncthreads();
+                    for (int k = tid; k < tn; k += P2P_THREADS) tile[k] = make_float2(ref_x[r0 + t0 + k], ref_y[r0 + t0 + k]);
+                    __syncthreads();
+                    if (i < n2)
+                        for (int k = 0; k < tn; ++k) {
+                            const float ex = gx - tile[k].x, ey = gy - tile[k].y;
+                            const float d = ex * ex + ey * ey;
+                            if (d < best) { best = d; bj = t0 + k; }
+                        }
+                }
+                int mj = -1;
+                if (i < n2 && bj >= 0) {
+                    const float pivot = sqrtf((gx - (float)qx) * (gx - (float)qx) + (gy - (float)qy) * (gy - (float)qy));
+                    const float lim = thr_d + thr_a * pivot;
+                    if (best < lim * lim) {
+                        mj = bj;
+                        // the first-map point keeps its closest partner (ties: smaller index)
+                        atomicMin(&owner[r0 + bj], ((unsigned long long)f2u(best) << 32) | (unsigned)i);
+                    }
+                }
+                if (i < n2) match[c0 + i] = mj;
+            }
+            __syncthreads();
+            // sums over the surviving pairs (a = first map, b = second map in its own frame)
+            double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // n, xa, ya, xb, yb, xaxb, yayb, xayb, yaxb
+            double sq = 0;
+            for (int i = tid; i < n2; i += P2P_THREADS) {
+                const int j = match[c0 + i];
+                if (j >= 0 && (unsigned)owner[r0 + j] == (unsigned)i) {
+                    const double xa = ref_x[r0 + j], ya = ref_y[r0 + j], xb = cur_x[c0 + i], yb = cur_y[c0 + i];
+                    s[0] += 1; s[1] += xa; s[2] += ya; s[3] += xb; s[4] += yb;
+                    s[5] += xa * xb; s[6] += ya * yb; s[7] += xa * yb; s[8] += ya * xb;
+                    sq += (double)u2f((uint32_t)(owner[r0 + j] >> 32));
+                }
+            }
+            for (int k = 0; k < 9; ++k) s[k] = block_sum(s[k], sh);
+            sq = block_sum(sq, sh);
+            n_pairs = (int)s[0];
+            if (n_pairs == 0) { keep = false; break; }
+            mse = sq / s[0];
+            // closed-form least-squares rigid transformation of the pairs
+            const double N = s[0];
+            const double Ax = N * (s[5] + s[6]) - s[1] * s[3] - s[2] * s[4];
+            const double Ay = s[1] * s[4] + N * (s[8] - s[7]) - s[3] * s[2];
+            const double nphi = (Ax == 0 && Ay == 0) ? 0.0 : atan2(Ay, Ax);
+            const double cc = cos(nphi), ss = sin(nphi);
+            const double nx = (s[1] - cc * s[3] + ss * s[4]) / N;
+            const double ny = (s[2] - ss * s[3] - cc * s[4]) / N;
+            const bool still = fabs(nx - qx) < 1e-6 && fabs(ny - qy) < 1e-6 && fabs(nphi - qphi) < 1e-6;
+            qx = nx; qy = ny; qphi = nphi;
+            if (still) {
+                thr_d *= O.alfa; thr_a *= O.alfa;
+                if (thr_d < O.smallest_thr) keep = false;
+            }
+            ++iter;
+        }
+        // covariance: sigma^2 (J^T J)^-1 of the pair residuals at the solution,
+        // J_i = [1 0 -(s xb + c yb); 0 1 (c xb - s yb)]
+        if (n_pairs >= 2) {
+            const double cc = cos(qphi), ss = sin(qphi);
+            double h[4] = {0, 0, 0, 0};     // sum jx, sum jy, sum (jx^2 + jy^2), (n comes from n_pairs)
+            for (int i = tid; i < n2; i += P2P_THREADS) {
+                const int j = match[c0 + i];
+                if (j >= 0 && (unsigned)owner[r0 + j] == (unsigned)i) {
+                    const double xb = cur_x[c0 + i], yb = cur_y[c0 + i];
+                    const double jx = -(ss * xb + cc * yb), jy = cc * xb - ss * yb;
+                    h[0] += jx; h[1] += jy; h[2] += jx * jx + jy * jy;
+                }
+            }
+            for (int k = 0; k < 3; ++k) h[k] = block_sum(h[k], sh);
+            // H = [[n,0,a],[0,n,b],[a,b,c]] -> inverse in closed form
+            const double n = n_pairs, a = h[0], bb = h[1], c = h[2];
+            const double det = n * (n * c - a * a - bb * bb);
+            if (fabs(det) > 1e-12) {
+                const double sig2 = mse > 1e-12 ? mse : 1e-12;
+                const double k0 = sig2 / det;
+                cov[0] = k0 * (n * c - bb * bb); cov[1] = k0 * (a * bb); cov[2] = k0 * (-n * a);
+                cov[3] = k0 * (n * c - a * a);   cov[4] = k0 * (-n * bb);
+                cov[5] = k0 * (n * n);
+            }
+        }
+        if (tid == 0) {
+            double* o = out + 16 * (size_t)b;
+            o[0] = qx; o[1] = qy; o[2] = qphi;
+            o[3] = n2 > 0 ? (double)n_pairs / (double)n2 : 0.0;
+            o[4] = mse; o[5] = iter; o[6] = n_pairs;
+            for (int k = 0; k < 6; ++k) o[7 + k] = cov[k];
+        }
+        __syncthreads();
+    }
+}
+
+} // namespace lsa

@@ -127,6 +127,11 @@ void orc_score_poses(const float* lik, int sx, int sy, int cx0, int cy0, float o
 void orc_systematic_resample(const float* w, int P, double u0, int n_out, int* parent);
 double orc_neff(const float* w, int P);
 
+/* classic point-to-point ICP with CICPWarpper's options (MRPT absent: PARITY UNPINNED), p2p_oracle.c */
+void orc_p2p_icp(const float* rx, const float* ry, int n1, const float* cx, const float* cy, int n2,
+                 const double init[3], int max_iter, float thr_d, float thr_a, float alfa, float smallest,
+                 double out[16]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -281,6 +281,17 @@ def systematic_resample(w, u0, n_out):
     return parent
 
 
+def p2p_icp(rx, ry, cx, cy, init, max_iter=100, thr_d=0.75, thr_a=np.deg2rad(10.0), alfa=0.5, smallest=0.05):
+    if Oracle._L is None:
+        Oracle._L = _load_oracle()
+    rx, ry, cx, cy = (np.ascontiguousarray(a, f32) for a in (rx, ry, cx, cy))
+    init = np.ascontiguousarray(init, np.float64)
+    out = np.zeros(16, np.float64)
+    Oracle._L.orc_p2p_icp(_p(rx), _p(ry), len(rx), _p(cx), _p(cy), len(cx), _p(init), int(max_iter),
+                          C.c_float(thr_d), C.c_float(np.float32(thr_a)), C.c_float(alfa), C.c_float(smallest), _p(out))
+    return out
+
+
 def neff(w):
     if Oracle._L is None:
         Oracle._L = _load_oracle()
