@@ -197,10 +197,10 @@ def extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p):
     res["preprocess_scans_per_s"] = S / (ms * 1e-3)
     # grid update: 4096^2 @ 5 cm, scans inserted at their true poses
     fi = capi.param_tables(p)[0]
-    nb = 256
+    nb = 2048
     _, poses = synth.make_scans(1)
     poses = synth.path_pose(np.arange(nb))
-    rr = raw[:nb] / 100.0
+    rr = np.concatenate([raw, raw])[:nb] / 100.0
     gx = (poses[:, 0:1] + rr * np.cos(poses[:, 2:3] + fi[None])).astype(np.float32)
     gy = (poses[:, 1:2] + rr * np.sin(poses[:, 2:3] + fi[None])).astype(np.float32)
     grid = capi.Grid(ctx, 4096, 4096, 1024, 1024, 0.0, 0.0, 0.05)

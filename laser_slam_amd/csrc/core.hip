@@ -607,8 +607,12 @@ int lsa_grid_update_batch(lsa_grid* g, int S, int n_beams, const float* d_gx, co
     if (!g || !d_gx || !d_gy || !d_robot_xy) return fail(LSA_E_ARG, "null argument");
     if (S <= 0 || n_beams <= 0) return LSA_OK;
     HIP_TRY(hipSetDevice(g->c->device));
-    hipLaunchKernelGGL(lsa::grid_update_kernel, dim3(blocks_for((size_t)S * n_beams, 256)), dim3(256), 0,
-                       g->c->stream, g->G, S, n_beams, d_gx, d_gy, d_robot_xy, d_n_valid, g->d_hit, g->d_sum);
+    if (n_beams < 65536)    // per-scan increments fit the packed u16 tile counters
+        hipLaunchKernelGGL(lsa::grid_update_tile_kernel, dim3(S < 4096 ? S : 4096), dim3(256), 0,
+                           g->c->stream, g->G, S, n_beams, d_gx, d_gy, d_robot_xy, d_n_valid, g->d_hit, g->d_sum);
+    else
+        hipLaunchKernelGGL(lsa::grid_update_kernel, dim3(blocks_for((size_t)S * n_beams, 256)), dim3(256), 0,
+                           g->c->stream, g->G, S, n_beams, d_gx, d_gy, d_robot_xy, d_n_valid, g->d_hit, g->d_sum);
     HIP_TRY(hipGetLastError());
     return LSA_OK;
 }

@@ -81,6 +81,84 @@ __global__ __launch_bounds__(256) void grid_update_kernel(
     }
 }
 
+// Same update, one workgroup per scan with the robot's neighbourhood staged in LDS.
+// Every ray of a scan starts in the robot cell, so the cells around it are hit by hundreds of
+// rays: their increments are accumulated in an LDS tile (packed u16 hit | u16 visit, a scan
+// contributes < 65536 to either) and flushed once with row-contiguous atomics; only the part
+// of a ray that leaves the tile goes to global atomics directly.  Counts are additive, so the
+// totals are identical to the per-cell version.
+constexpr int GRID_TILE = 128;          // cells per tile side (64 KiB of LDS)
+
+__global__ __launch_bounds__(256) void grid_update_tile_kernel(
+    GridParam G, int S, int n_beams, const float* __restrict__ gx, const float* __restrict__ gy,
+    const float* __restrict__ robot_xy, const int* __restrict__ n_valid,
+    uint32_t* __restrict__ hit, uint32_t* __restrict__ sum)
+{
+    __shared__ uint32_t tile[GRID_TILE * GRID_TILE];
+    for (int s = blockIdx.x; s < S; s += gridDim.x) {
+        for (int k = threadIdx.x; k < GRID_TILE * GRID_TILE; k += blockDim.x) tile[k] = 0;
+        const int sx = grid_cell1(robot_xy[2 * s], G.off_x, G.center_x, G.res);
+        const int sy = grid_cell1(robot_xy[2 * s + 1], G.off_y, G.center_y, G.res);
+        const int ox = sx - GRID_TILE / 2, oy = sy - GRID_TILE / 2;
+        const int nb = n_valid ? n_valid[s] : n_beams;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+            const size_t t = (size_t)s * n_beams + i;
+            const int ex = grid_cell1(gx[t], G.off_x, G.center_x, G.res);
+            const int ey = grid_cell1(gy[t], G.off_y, G.center_y, G.res);
+            if (inb(G, ex, ey)) {                                                     // :72-75
+                const unsigned tx = (unsigned)(ex - ox), ty = (unsigned)(ey - oy);
+                if (tx < GRID_TILE && ty < GRID_TILE) atomicAdd(&tile[tx * GRID_TILE + ty], 1u << 16);
+                else atomicAdd(&hit[(size_t)ex * G.size_y + ey], 1u);
+            }
+            const int dx = abs(ex - sx), dy = abs(ey - sy);
+            int x, y, len, d, inc_keep, inc_step, minor_step;
+            const bool x_major = dy <= dx;
+            if (x_major) {                                                            // line.cpp:17-58
+                d = 2 * dy - dx; inc_keep = 2 * dy; inc_step = 2 * (dy - dx);
+                int flag;
+                if (sx > ex) { x = ex; y = ey; flag = -1; } else { x = sx; y = sy; flag = 1; }
+                minor_step = ((ey - sy) * flag) > 0 ? 1 : -1;
+                len = dx;
+            } else {                                                                  // line.cpp:59-101
+                d = 2 * dx - dy; inc_keep = 2 * dx; inc_step = 2 * (dx - dy);
+                int flag;
+                if (sy > ey) { y = ey; x = ex; flag = -1; } else { y = sy; x = sx; flag = 1; }
+                minor_step = ((ex - sx) * flag) > 0 ? 1 : -1;
+                len = dy;
+            }
+            for (int k = 0; k <= len; ++k) {
+                if (k > 0) {
+                    if (x_major) { x++; if (d < 0) d += inc_keep; else { y += minor_step; d += inc_step; } }
+                    else         { y++; if (d < 0) d += inc_keep; else { x += minor_step; d += inc_step; } }
+                }
+                if (inb(G, x, y)) {
+                    const unsigned tx = (unsigned)(x - ox), ty = (unsigned)(y - oy);
+                    const uint32_t inc = (k == len ? (1u << 16) : 0u) + 1u;           // last cell: hit too (:84-87)
+                    if (tx < GRID_TILE && ty < GRID_TILE) atomicAdd(&tile[tx * GRID_TILE + ty], inc);
+                    else {
+                        const size_t c = (size_t)x * G.size_y + y;
+                        if (k == len) atomicAdd(&hit[c], 1u);
+                        atomicAdd(&sum[c], 1u);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // flush: consecutive lanes -> consecutive y of one x row (contiguous in the [x][y] layers)
+        for (int k = threadIdx.x; k < GRID_TILE * GRID_TILE; k += blockDim.x) {
+            const uint32_t v = tile[k];
+            if (v) {
+                const int x = ox + k / GRID_TILE, y = oy + k % GRID_TILE;      // in bounds: only in-bounds cells were counted
+                const size_t c = (size_t)x * G.size_y + y;
+                if (v & 0xffffu) atomicAdd(&sum[c], v & 0xffffu);
+                if (v >> 16) atomicAdd(&hit[c], v >> 16);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // computeProbsOfMap: prob = hit / (double) sum clipped to 1, unseen cells 0.3.
 // Counts are converted to float first (the reference stores them as float).
 __global__ __launch_bounds__(256) void grid_prob_kernel(
