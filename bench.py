@@ -77,8 +77,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # one process per GPU over RCCL ("nccl" is RCCL on ROCm).  LSA_DIST_BACKEND=gloo lets the
+        # multi-rank path be rehearsed on a box with fewer GPUs than ranks (ranks then share devices).
+        backend = os.environ.get("LSA_DIST_BACKEND", "nccl")
+        ndev = max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank % ndev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % ndev))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev_index = torch.cuda.current_device()
@@ -131,7 +138,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -522,40 +522,26 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
 #endif
 
             {
-                // this wave's beams, two chunks of 64 at a time so that the two searches' dependency
-                // chains (LDS reads, bounds) overlap; the seed matches live in LDS between iterations
+                // this wave's beams, 64 at a time; the seed matches live in LDS between iterations
                 const int T = (int)rintf(6.2831853f / P.dfi);
                 const float inv_dfi = 1.0f / P.dfi;
                 unsigned long long* slot = (unsigned long long*)(L.misc + 32) + wave;
-                for (int base = wave * WAVE; base < N; base += 2 * ICP_THREADS) {
-                    const int i0 = base + lane, i1 = base + ICP_THREADS + lane;
+                for (int base = wave * WAVE; base < N; base += ICP_THREADS) {
+                    const int i0 = base + lane;
                     const bool lv0 = i0 < N && key_bad(L.key[i0 < N ? i0 : 0]) == 0;
-                    const bool lv1 = i1 < N && key_bad(L.key[i1 < N ? i1 : 0]) == 0;
                     const float2 p0 = cur_point(P, L.g_act_r, i0 < N ? i0 : N - 1, co, si, ax, ay);
-                    const float2 p1 = cur_point(P, L.g_act_r, i1 < N ? i1 : N - 1, co, si, ax, ay);
                     const int jp0 = iter > 0 && i0 < N ? (int)L.jprev[i0] - 1 : -1;
-                    const int jp1 = iter > 0 && i1 < N ? (int)L.jprev[i1] - 1 : -1;
-                    NnBeam b0, b1;
-                    SUBSTAMP(8, p0.x + p1.x);
+                    NnBeam b0;
+                    SUBSTAMP(8, p0.x);
                     nn_plan(P, L, i0, lv0, p0, jp0, T, inv_dfi, b0);
-                    nn_plan(P, L, i1, lv1, p1, jp1, T, inv_dfi, b1);
-                    SUBSTAMP(9, (float)(b0.len + b1.len));
-#if !defined(LSA_EXP) || LSA_EXP != 2
+                    SUBSTAMP(9, (float)b0.len);
                     nn_flat(L, N, b0);
-                    nn_flat(L, N, b1);
-                    SUBSTAMP(10, b0.best + b1.best);
-#endif
-#if !defined(LSA_EXP) || LSA_EXP != 1
-                    if (__ballot((b0.live && !b0.flat) || (b1.live && !b1.flat))) {
-                        nn_general(P, L, T, b0, slot);
-                        nn_general(P, L, T, b1, slot);
-                    }
-#endif
-                    SUBSTAMP(11, b0.best + b1.best);
-                    const int m0 = nn_store(L, N, i0, b0), m1 = nn_store(L, N, i1, b1);
+                    SUBSTAMP(10, b0.best);
+                    if (__ballot(b0.live && !b0.flat)) nn_general(P, L, T, b0, slot);
+                    SUBSTAMP(11, b0.best);
+                    const int m0 = nn_store(L, N, i0, b0);
                     if (i0 < N) L.jprev[i0] = (uint16_t)(m0 + 1);
-                    if (i1 < N) L.jprev[i1] = (uint16_t)(m1 + 1);
-                    SUBSTAMP(12, (float)(m0 + m1));
+                    SUBSTAMP(12, (float)m0);
                 }
             }
             __syncthreads();

