@@ -159,7 +159,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthetic 1081-beam scans (270 deg, W=200), consecutive pairs, zero initial guess, "
-                                   "pm_%s batched one wave per pair" % args.matcher,
+                                   "pm_%s batched, one 256-thread workgroup per pair" % args.matcher,
                        "pairs_per_step_per_gpu": B, "beams": n, "matcher": "pm_" + args.matcher,
                        "mean_iterations": mean_iters, "failed_fraction": fail_frac, "parallelism": "pairs sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -177,8 +177,14 @@ __device__ __forceinline__ void nn_eval4(const Lds& L, float2 p, int j, float& b
     ex = p.x - r3.x; ey = p.y - r3.y; d = ex * ex + ey * ey; if (b3 == 0 && d < best) { best = d; best_j = j + 3; }
 }
 
-constexpr int NN_SHORT = 32;      // candidate counts above this are searched by the whole wave
-constexpr int NN_FLAT = 8;        // candidate counts up to this are evaluated straight-line
+#ifndef LSA_NN_SHORT
+#define LSA_NN_SHORT 256
+#endif
+constexpr int NN_SHORT = LSA_NN_SHORT;   // candidate counts above this are searched by the whole wave
+#ifndef LSA_NN_FLAT
+#define LSA_NN_FLAT 8
+#endif
+constexpr int NN_FLAT = LSA_NN_FLAT;   // candidate counts up to this are evaluated straight-line
 
 // per-beam search state
 struct NnBeam {
@@ -341,7 +347,9 @@ __device__ __forceinline__ int count_split(const float* row, int cnt, float d, i
     const int t1 = (int)f2u(d), t2 = t1 - 1;
     const int nq = (cnt + 3) >> 2, qa = limit >> 2;      // quads [0,qa) lie entirely below `limit`
     int c = 0, qd = 0;
+#ifndef LSA_NO_UNROLL
     #pragma unroll 4
+#endif
     for (; qd < qa; ++qd) {
         const int4 v = r4[qd];
         c += (v.x > t1) + (v.y > t1) + (v.z > t1) + (v.w > t1);
@@ -355,7 +363,9 @@ __device__ __forceinline__ int count_split(const float* row, int cnt, float d, i
         c += (p + 3 < cnt && v.w > (p + 3 < limit ? t1 : t2)) ? 1 : 0;
         ++qd;
     }
+#ifndef LSA_NO_UNROLL
     #pragma unroll 4
+#endif
     for (; qd < nq; ++qd) {
         const int4 v = r4[qd];
         c += (v.x > t2) + (v.y > t2) + (v.z > t2) + (v.w > t2);
@@ -363,7 +373,11 @@ __device__ __forceinline__ int count_split(const float* row, int cnt, float d, i
     return c;
 }
 
+#ifdef LSA_TRIM_NOINLINE
+__device__ __noinline__ void trim_worst(const Lds& L, int n, int k, volatile int* wcnt)
+#else
 __device__ void trim_worst(const Lds& L, int n, int k, volatile int* wcnt)
+#endif
 {
     const int tid = threadIdx.x;
     unsigned long long* A = L.key;

@@ -10,7 +10,7 @@ out = os.path.join(ROOT, "gpurun_out", "liblsa_core_stamps.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 EXP = [a for a in sys.argv[1:] if a.startswith("-D")]
 sys.argv = [a for a in sys.argv if not a.startswith("-D")]
-subprocess.check_call(["hipcc"] + ge.HIP_FLAGS + ["-DLSA_PHASE_STAMPS"] + EXP + ["-o", out,
+subprocess.check_call(["hipcc"] + ge.HIP_FLAGS + ([] if "-DNOSTAMPS" in EXP else ["-DLSA_PHASE_STAMPS"]) + [e for e in EXP if e != "-DNOSTAMPS"] + ["-o", out,
                       os.path.join(ge.CSRC, "core.hip"), os.path.join(ge.CSRC, "carmen.cpp")])
 from laser_slam_amd import capi, synth
 capi.LIB_PATH = out
