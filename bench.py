@@ -170,6 +170,8 @@ def main():
                          "fp32_vector_frac": flops_pair * B / (kernel_ms * 1e-3) / (FP32_PEAK_TFLOPS * 1e12),
                          "flops_per_pair_model": flops_pair},
         }
+        out["secondary"] = secondary(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, which)
+        out["roofline"]["traffic"] = pmc_traffic(args.matcher, B)
         if args.extras:
             out["extras"] = extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p)
         if not args.no_cpu:
@@ -179,6 +181,32 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def secondary(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, which):
+    """The other matcher of the path on the same batch (one timed launch), for the record."""
+    other = capi.MATCH_PSM if which == capi.MATCH_ICP else capi.MATCH_ICP
+    pose = torch.zeros(B, 3, device="cuda")
+    ctx.match_batch(other, B, d_r, d_bad, d_seg, d_ri, d_ai, pose)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); ctx.match_batch(other, B, d_r, d_bad, d_seg, d_ri, d_ai, pose); b.record()
+    torch.cuda.synchronize()
+    return {("pm_psm" if other == capi.MATCH_PSM else "pm_icp") + "_matches_per_s": B / (a.elapsed_time(b) * 1e-3)}
+
+
+def pmc_traffic(matcher, B):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs at
+    32768 pairs per launch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled to
+    this batch size.  None when the profile file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    try:
+        rec = json.load(open(path))["lsa::%s_kernel" % matcher]
+        per_pair = (2.0 * rec["FETCH_SIZE_KB_per_launch"] + rec["WRITE_SIZE_KB_per_launch"]) * 1024.0 / rec.get("pairs_per_launch", 32768)
+        return per_pair * B
+    except Exception:
+        return None
 
 
 def extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p):

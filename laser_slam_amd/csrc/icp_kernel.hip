@@ -177,10 +177,6 @@ __device__ __forceinline__ void nn_eval4(const Lds& L, float2 p, int j, float& b
     ex = p.x - r3.x; ey = p.y - r3.y; d = ex * ex + ey * ey; if (b3 == 0 && d < best) { best = d; best_j = j + 3; }
 }
 
-#ifndef LSA_NN_SHORT
-#define LSA_NN_SHORT 256
-#endif
-constexpr int NN_SHORT = LSA_NN_SHORT;   // candidate counts above this are searched by the whole wave
 #ifndef LSA_NN_FLAT
 #define LSA_NN_FLAT 8
 #endif
@@ -253,12 +249,12 @@ __device__ __forceinline__ void nn_flat(const Lds& L, int N, NnBeam& b)
     for (int o = 0; o < NN_FLAT; ++o) nn_eval_pred(L, N, b.p, b.s0 + o, b.flat && b.s0 + o <= b.e0, b.best, b.best_j);
 }
 
-// the general path: lists of up to NN_SHORT rays serially per lane, longer ones by the whole wave
-__device__ __forceinline__ void nn_general(const DevParam& P, const Lds& L, int T, NnBeam& b, unsigned long long* slot)
+// the general path: candidate lists that are longer than NN_FLAT or span several images, per lane.
+// (A wave-cooperative scan of the rare long lists was measured slower than letting the lane loop:
+// its LDS hand-offs stall the whole wave.)
+__device__ __forceinline__ void nn_general(const DevParam& P, const Lds& L, int T, NnBeam& b)
 {
-    const int lane = lane_id();
-    const bool serial = b.live && !b.flat && b.len <= NN_SHORT;
-    if (serial) {
+    if (b.live && !b.flat) {
         int done = b.pl.lo - 1, s0, e0;
         #pragma unroll
         for (int im = -1; im <= 1; ++im) {
@@ -267,29 +263,6 @@ __device__ __forceinline__ void nn_general(const DevParam& P, const Lds& L, int 
             for (; j + 3 <= e0; j += 4) nn_eval4(L, b.p, j, b.best, b.best_j);
             for (; j <= e0; ++j) nn_eval(L, b.p, j, b.best, b.best_j);
         }
-    }
-    const bool is_long = b.live && !b.flat && b.len > NN_SHORT;
-    for (unsigned long long m = __ballot(is_long); m; m &= m - 1) {
-        const int s = __builtin_ctzll(m);
-        const float2 bp = make_float2(bcast_f(b.p.x, s), bcast_f(b.p.y, s));
-        NnPlan bpl = {bcast_i(b.pl.lo, s), bcast_i(b.pl.hi, s), bcast_i(b.pl.c0, s), bcast_i(b.pl.M, s)};
-        float cb = 1000000.0f;
-        int cj = 0x7fffffff;
-        int done = bpl.lo - 1, s0, e0;
-        #pragma unroll
-        for (int im = -1; im <= 1; ++im) {
-            nn_range(bpl, T, im, done, s0, e0);
-            for (int j = s0 + lane; j <= e0; j += WAVE) nn_eval(L, bp, j, cb, cj);
-        }
-        // wave minimum of (distance, ray) through one LDS atomic (distances are >= 0, so the
-        // IEEE bit pattern orders like the value; ties resolve to the smaller ray index)
-        if (lane == 0) *slot = ~0ull;
-        wave_sync();
-        if (cj != 0x7fffffff) atomicMin(slot, ((unsigned long long)f2u(cb) << 32) | (unsigned)cj);
-        wave_sync();
-        const unsigned long long res = *slot;
-        if (lane == s && res != ~0ull) { b.best = u2f((uint32_t)(res >> 32)); b.best_j = (int)(uint32_t)res; }
-        wave_sync();
     }
 }
 
@@ -324,17 +297,20 @@ __device__ __forceinline__ int nn_store(const Lds& L, int N, int i, const NnBeam
 // insertion); only the kept prefix out[0..n-k) is produced - the reference never reads
 // the dropped tail either.
 
-// index of this thread's flag among the set flags of the workgroup (thread order), and the total
-__device__ __forceinline__ int block_rank(bool flag, int& total, volatile int* wcnt)
+// index of this thread's flag among the set flags of the workgroup (thread order), and the total.
+// One barrier per call: consecutive calls alternate between two sets of per-wave slots, and a
+// slot set is rewritten only two calls (hence at least one barrier) after it was last read.
+__device__ __forceinline__ int block_rank(bool flag, int& total, int* wcnt, int& phase)
 {
     const unsigned long long mask = __ballot(flag);
     const int wave = threadIdx.x >> 6;
-    if (lane_id() == 0) wcnt[wave] = __popcll(mask);
+    int* slot = wcnt + 4 * (phase & 1);
+    phase++;
+    if (lane_id() == 0) slot[wave] = __popcll(mask);
     __syncthreads();
-    const int c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+    const int c0 = slot[0], c1 = slot[1], c2 = slot[2], c3 = slot[3];
     total = c0 + c1 + c2 + c3;
     const int off = (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
-    __syncthreads();
     return off + prefix_popc(mask);
 }
 
@@ -374,9 +350,13 @@ __device__ __forceinline__ int count_split(const float* row, int cnt, float d, i
 }
 
 #ifdef LSA_TRIM_NOINLINE
-__device__ __noinline__ void trim_worst(const Lds& L, int n, int k, volatile int* wcnt)
+__device__ __noinline__ void trim_worst(const Lds& L, int n, int k, int* wcnt)
 #else
-__device__ void trim_worst(const Lds& L, int n, int k, volatile int* wcnt)
+__device__ void trim_worst(const Lds& L, int n, int k, int* wcnt
+#ifdef LSA_PHASE_STAMPS
+                           , unsigned long long* ph, unsigned long long& t_sub
+#endif
+                           )
 #endif
 {
     const int tid = threadIdx.x;
@@ -386,6 +366,7 @@ __device__ void trim_worst(const Lds& L, int n, int k, volatile int* wcnt)
     float* cd = L.pool_d;                            // candidates' distances (arrival order)
     float* ce = L.pool_d + TRIM_CHUNK;               // entering records' distances (arrival order)
     float* se = L.pool_d + 2 * TRIM_CHUNK;           // entering records' distances, descending
+    int phase = 0;
     // the first k records (k <= TRIM_CHUNK, host-checked): rank sort, descending by (distance, arrival)
     {
         const unsigned long long rec = tid < k ? A[tid] : 0ull;
@@ -395,6 +376,7 @@ __device__ void trim_worst(const Lds& L, int n, int k, volatile int* wcnt)
         __syncthreads();
         if (tid < k) Pc[count_split(cd, k, d, tid + 1)] = rec;
         __syncthreads();
+        SUBSTAMP(13, 0.0f);
     }
     for (int t0 = k; t0 < n; t0 += TRIM_CHUNK) {
         const int t = t0 + tid;
@@ -404,7 +386,8 @@ __device__ void trim_worst(const Lds& L, int n, int k, volatile int* wcnt)
         const float theta = rec_d(Pc[k - 1]);
         const bool cand = valid && d >= theta;
         int q;
-        const int cpos = block_rank(cand, q, wcnt);
+        const int cpos = block_rank(cand, q, wcnt, phase);
+        SUBSTAMP(14, (float)cpos);
         if (q == 0) { if (valid) A[t - k] = rec; continue; }
         if (cand) cd[cpos] = d;
         if (tid < 4 && q + tid < ((q + 3) & ~3)) cd[q + tid] = -1.0f;      // pad the row
@@ -418,17 +401,20 @@ __device__ void trim_worst(const Lds& L, int n, int k, volatile int* wcnt)
             g1 = lo;
         }
         __syncthreads();
+        SUBSTAMP(15, (float)g1);
         // earlier records of this step that are strictly greater (later ones never count)
         const int g2 = cand ? count_split(cd, cpos, d, cpos) : 0;
         const bool ent = cand && (g1 + g2 < k);
         int E;
-        const int epos = block_rank(ent, E, wcnt);
+        const int epos = block_rank(ent, E, wcnt, phase);
+        SUBSTAMP(8, (float)epos);
         if (valid && !ent) A[t - k] = rec;           // passes straight through
         if (E == 0) continue;
         if (ent) ce[epos] = d;
         if (tid < 4 && E + tid < ((E + 3) & ~3)) ce[E + tid] = -1.0f;
+        const unsigned long long pv = tid < k ? Pc[tid] : 0ull;            // this thread's pool record
         __syncthreads();
-        // entering records with a greater key
+        // rank of this thread's record among the entering ones (greater key first) ...
         const int h = ent ? count_split(ce, E, d, epos + 1) : 0;
         if (ent) se[h] = d;
         __syncthreads();
@@ -437,20 +423,23 @@ __device__ void trim_worst(const Lds& L, int n, int k, volatile int* wcnt)
             const int pos = g1 + h;
             if (pos < k) Pn[pos] = rec; else L.evict[top - pos] = rec;
         }
-        for (int i = tid; i < k; i += ICP_THREADS) {
-            const unsigned long long pv = Pc[i];
+        if (tid < k) {
+            // ... and how far the entering records push this thread's pool record down:
+            // the number of entering records with distance >= its own (se is descending)
             const float pd = rec_d(pv);
-            int lo = 0, hi = E;                      // entering records with distance >= pd
+            int lo = 0, hi = E;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if (se[mid] >= pd) lo = mid + 1; else hi = mid;
             }
-            const int ni = i + lo;
+            const int ni = tid + lo;
             if (ni < k) Pn[ni] = pv; else L.evict[top - ni] = pv;
         }
         __syncthreads();
+        SUBSTAMP(9, (float)h);
         if (ent) A[t - k] = L.evict[epos];           // evictions come out in ascending order
         __syncthreads();
+        SUBSTAMP(10, 0.0f);
         unsigned long long* sw = Pc; Pc = Pn; Pn = sw;
     }
 }
@@ -488,8 +477,8 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = P.n, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     Lds L = carve_icp(smem, N);
-    volatile int* imisc = (volatile int*)L.misc;              // [0] n
-    volatile float* fmisc = (volatile float*)L.misc + 8;      // [0..3] means  [4..7] covariances
+    int* imisc = (int*)L.misc;              // [0] n
+    float* fmisc = L.misc + 8;      // [0..3] means  [4..7] covariances
     // ordered value lists (SoA, padded): nx | ny | ix | iy, later the four product lists
     const int VS = icp_v_bytes(N) / 16;                       // floats per list (multiple of 4, + slack)
     float* const V0 = (float*)L.V;
@@ -539,23 +528,17 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
                 // this wave's beams, 64 at a time; the seed matches live in LDS between iterations
                 const int T = (int)rintf(6.2831853f / P.dfi);
                 const float inv_dfi = 1.0f / P.dfi;
-                unsigned long long* slot = (unsigned long long*)(L.misc + 32) + wave;
                 for (int base = wave * WAVE; base < N; base += ICP_THREADS) {
                     const int i0 = base + lane;
                     const bool lv0 = i0 < N && key_bad(L.key[i0 < N ? i0 : 0]) == 0;
                     const float2 p0 = cur_point(P, L.g_act_r, i0 < N ? i0 : N - 1, co, si, ax, ay);
                     const int jp0 = iter > 0 && i0 < N ? (int)L.jprev[i0] - 1 : -1;
                     NnBeam b0;
-                    SUBSTAMP(8, p0.x);
                     nn_plan(P, L, i0, lv0, p0, jp0, T, inv_dfi, b0);
-                    SUBSTAMP(9, (float)b0.len);
                     nn_flat(L, N, b0);
-                    SUBSTAMP(10, b0.best);
-                    if (__ballot(b0.live && !b0.flat)) nn_general(P, L, T, b0, slot);
-                    SUBSTAMP(11, b0.best);
+                    if (__ballot(b0.live && !b0.flat)) nn_general(P, L, T, b0);
                     const int m0 = nn_store(L, N, i0, b0);
                     if (i0 < N) L.jprev[i0] = (uint16_t)(m0 + 1);
-                    SUBSTAMP(12, (float)m0);
                 }
             }
             __syncthreads();
@@ -580,7 +563,12 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
             if (n < P.min_valid) { status = LSA_ST_FEW_POINTS; break; }                  // :1825-1832
             drop = (int)((double)n * 0.2);                                              // :1836
             keep = n - drop;
-            trim_worst(L, n, drop, imisc + 2);                                          // :1839-1857
+#ifdef LSA_PHASE_STAMPS
+            t_sub = __builtin_readcyclecounter();
+            trim_worst(L, n, drop, imisc + 40, ph, t_sub);
+#else
+            trim_worst(L, n, drop, imisc + 40);
+#endif                                          // :1839-1857
             __syncthreads();
             STAMP(3);
 

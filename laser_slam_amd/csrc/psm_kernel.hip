@@ -35,7 +35,7 @@ __device__ __forceinline__ void build_masked_rows(const DevParam& P, const Lds& 
 
 // pm_orientation_search (:1152-1261) on L.new_r/new_bad vs L.ref_r/ref_bad.  Whole
 // workgroup; returns the status, dth by reference.  Uses pr/pf/key as scratch.
-__device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, volatile float* bc)
+__device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, float* bc)
 {
     const int N = P.n, W = P.window, K = 2 * W + 1, tid = threadIdx.x;
     float* nrm = L.pr;                 // N floats (the pr row)
@@ -78,10 +78,10 @@ __device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, v
             const bool take = (ok >= 0) && (bk < 0 || om < bm || (om == bm && ok < bk));
             if (take) { bm = om; bk = ok; }
         }
-        if (tid == 0) ((volatile int*)bc)[0] = bk;
+        if (tid == 0) ((int*)bc)[0] = bk;
     }
     __syncthreads();
-    const int imin = ((volatile int*)bc)[0];
+    const int imin = ((int*)bc)[0];
     if (imin < 0 || err[imin] >= 10000.0f) return LSA_ST_NO_ORIENT;                    // :1236-1240
     dth = (float)(imin - W) * P.dfi;                                                  // :1241
     if (imin >= 1 && imin < K - 1) {                                                  // :1244-1254
@@ -98,7 +98,7 @@ __device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, v
 // Per-beam terms in parallel (zero when the beam is gated out: adding +0.0f leaves an
 // ordered FP32 sum unchanged), then six ordered sums.  Destroys new_r and err.
 __device__ int translation_estimation(const DevParam& P, const Lds& L, float C, float& dx, float& dy, float& avg,
-                                      volatile float* bc)
+                                      float* bc)
 {
     const int N = P.n, Np = (N + 63) & ~63, tid = threadIdx.x;
     float* const term[6] = {L.pr, L.pf, (float*)L.key, (float*)L.key + Np, L.err, L.new_r};
@@ -126,11 +126,16 @@ __device__ int translation_estimation(const DevParam& P, const Lds& L, float C, 
     int wsum = mine;
     #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) wsum += __shfl_xor(wsum, off);
-    if (lane_id() == 0) ((volatile int*)bc)[8 + wave] = wsum;
+    if (lane_id() == 0) ((int*)bc)[8 + wave] = wsum;
     __syncthreads();
     int cnt = 0;
-    for (unsigned w = 0; w < (blockDim.x >> 6); ++w) cnt += ((volatile int*)bc)[8 + w];
-    if (tid < 6) bc[tid] = ordered_sum(term[tid], N);
+    for (unsigned w = 0; w < (blockDim.x >> 6); ++w) cnt += ((int*)bc)[8 + w];
+    if (tid < 6) {
+        // (a select chain, not an indexed pointer table: keeps the LDS address space, i.e. ds_read)
+        const float* tp = tid == 0 ? term[0] : tid == 1 ? term[1] : tid == 2 ? term[2]
+                        : tid == 3 ? term[3] : tid == 4 ? term[4] : term[5];
+        bc[tid] = ordered_sum(tp, N);
+    }
     __syncthreads();
     const float hw1 = bc[0], hw2 = bc[1], h11 = bc[2], h12 = bc[3], h22 = bc[4], abs_err = bc[5];
     __syncthreads();
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(PSM_THREADS, 4) void psm_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = P.n, Np = (N + 63) & ~63, tid = threadIdx.x;
     const Lds L = carve_psm(smem, Np);
-    volatile float* bc = (volatile float*)(smem + 35 * Np);
+    float* bc = (float*)(smem + 35 * Np);
 
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const size_t ro = (size_t)ref_idx[b] * N, ao = (size_t)act_idx[b] * N;
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(PSM_THREADS, 4) void psm_stage_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = P.n, Np = (N + 63) & ~63, tid = threadIdx.x;
     const Lds L = carve_psm(smem, Np);
-    volatile float* bc = (volatile float*)(smem + 35 * Np);
+    float* bc = (float*)(smem + 35 * Np);
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const size_t o = (size_t)b * N;
         __syncthreads();

@@ -40,6 +40,7 @@ names = ["project+scatter", "nn search", "compaction", "trim (bubble)", "owner+i
 for nm, x in zip(names, v):
     print("%-22s %6.2f %%   %10.0f cycles/pair" % (nm, 100 * x / v.sum(), x / B))
 print("total cycles/pair %.0f  mean iterations %.2f  cycles/iteration %.0f" % (v.sum() / B, mean_it, v.sum() / B / mean_it))
-sub = np.array(list(buf)[8:13], np.float64) / B / mean_it
-print("nn sub-phases (wave 0, per iteration): loads+points=%.0f plan=%.0f flat=%.0f general=%.0f store=%.0f" % tuple(sub))
+sub = np.array(list(buf)[8:16], np.float64) / B / mean_it
+print("trim sub-phases (per iteration): first-k sort=%.0f | rank cand=%.0f bsearch=%.0f count g2+rank ent=%.0f count h/push+writes=%.0f emit=%.0f"
+      % (sub[5], sub[6], sub[7], sub[0], sub[1], sub[2]))
 print("per-iteration:", " ".join("%s=%.0f" % (nm.split()[0], x / B / mean_it) for nm, x in zip(names, v)))
