@@ -109,16 +109,16 @@ __device__ __forceinline__ void project_beam(float d, float rr, float ax, float 
     special = s1 || s2;
 }
 
-__device__ __noinline__ void project_beam_slow(float d, float rr, float ax, float ay, float& pr, float& pf)
+// returns (pr, pf) by value: reference outputs of a non-inlined function would live in scratch memory
+__device__ __noinline__ float2 project_beam_slow(float d, float rr, float ax, float ay)
 {
     float sd, cd;
     sincosf_(d, sd, cd);
     const float x = rr * cd + ax;
     const float y = rr * sd + ay;
-    pr = sqrtf(x * x + y * y);
     float a = atan2f_(y, x);
     if (x < 0 && y < 0) a = (float)((double)a + 2.0 * LSA_ZPI);
-    pf = a;
+    return make_float2(sqrtf(x * x + y * y), a);
 }
 
 // interpolation of one consecutive beam pair (i-1, i) onto the reference bearings, :1390-1465
@@ -156,8 +156,8 @@ __device__ void scan_project(const DevParam& P, const Lds& L, float ax, float ay
         bool sp0, sp1;
         project_beam(d0, r0, ax, ay, pr0, pf0, sp0);
         project_beam(d1, r1, ax, ay, pr1, pf1, sp1);
-        if (sp0) project_beam_slow(d0, r0, ax, ay, pr0, pf0);
-        if (sp1) project_beam_slow(d1, r1, ax, ay, pr1, pf1);
+        if (sp0) { const float2 q = project_beam_slow(d0, r0, ax, ay); pr0 = q.x; pf0 = q.y; }
+        if (sp1) { const float2 q = project_beam_slow(d1, r1, ax, ay); pr1 = q.x; pf1 = q.y; }
         L.pr[i0] = pr0; L.pf[i0] = pf0; L.key[i0] = KEY_INIT;
         if (has1) { L.pr[i1] = pr1; L.pf[i1] = pf1; L.key[i1] = KEY_INIT; }
     }
