@@ -86,6 +86,17 @@ int lsa_debug_phase_cycles(unsigned long long* out16)
 }
 #endif
 
+#ifdef LSA_NN_STATS
+int lsa_debug_nn_stats(unsigned long long* out8 /* 24 entries */)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(lsa::lsa_nn_stats), sizeof(unsigned long long) * 24));
+    unsigned long long z[24] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lsa::lsa_nn_stats), z, sizeof z));
+    return LSA_OK;
+}
+#endif
+
 const char* lsa_version(void) { return "laser_slam_amd 0.1 (gfx950)"; }
 
 const char* lsa_last_error(void) { return g_err.c_str(); }

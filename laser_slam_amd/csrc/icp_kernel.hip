@@ -23,6 +23,13 @@ constexpr int ICP_THREADS = 256;
 
 // Diagnostic build only (-DLSA_PHASE_STAMPS): per-phase cycle shares, accumulated by
 // thread 0 of each workgroup into lsa_phase_cycles[] (never compiled into the product).
+#ifdef LSA_NN_STATS
+// diagnostic build only: candidate-list statistics of the NN search, per 64-beam block
+__device__ unsigned long long lsa_nn_stats[24];
+__device__ __forceinline__ int nn_bucket(int len) { return len <= 8 ? 0 : len <= 16 ? 1 : len <= 32 ? 2 : len <= 64 ? 3 : len <= 128 ? 4 : 5; }
+__device__ __forceinline__ int wave_max_i(int v) { for (int o = 32; o; o >>= 1) { int w = __shfl_xor(v, o); v = w > v ? w : v; } return v; }
+__device__ __forceinline__ int wave_sum_i(int v) { for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o); return v; }
+#endif
 #ifdef LSA_PHASE_STAMPS
 __device__ unsigned long long lsa_phase_cycles[16];
 #define STAMP(slot) do { if (tid == 0) { unsigned long long t_ = __builtin_readcyclecounter(); ph[slot] += t_ - t_last; t_last = t_; } } while (0)
@@ -483,6 +490,10 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
     const int VS = icp_v_bytes(N) / 16;                       // floats per list (multiple of 4, + slack)
     float* const V0 = (float*)L.V;
 
+#ifndef LSA_SERIAL_WAVE
+#define LSA_SERIAL_WAVE 0
+#endif
+    const int sw = (LSA_SERIAL_WAVE);       // the wave that runs the order-bound single-wave phases
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const size_t ro = (size_t)ref_idx[b] * N, ao = (size_t)act_idx[b] * N;
         L.g_act_r = g_r + ao;
@@ -505,6 +516,7 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
         const float ath0 = init_pose ? init_pose[6 * (size_t)b + 5] : 0.0f;
         float dx = 0, dy = 0, dth = 0;
         int small = 0, status = LSA_ST_OK, n = 0, drop = 0, keep = 0;
+        float nco = cosf_(ath), nsi = sinf_(ath);       // :1753-1754 for the coming iteration, refreshed with every pose update
         float co = 1.0f, si = 0.0f, pax = 0.0f, pay = 0.0f;
         __syncthreads();
 #ifdef LSA_PHASE_STAMPS
@@ -513,12 +525,19 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
 #endif
 
         int iter = -1;
+#ifdef LSA_FIXED_ITERS      // diagnostics: data-independent trip count, so that skip-a-phase variants are comparable
+        while (++iter < LSA_FIXED_ITERS) {
+#else
         while (++iter < LSA_ITER_ICP && small < 3) {
+#endif
             if (((double)(fabsf_(dx) + fabsf_(dy)) + (double)fabsf_(dth) * LSA_ZR2D) < LSA_STOP_ICP) small++;
             else small = 0;                                                     // :1728
 
+            co = nco; si = nsi;
             scan_project(P, L, ax, ay, ath);                                    // flags only, :1750
-            co = cosf_(ath); si = sinf_(ath);                                   // :1753-1754
+#ifdef LSA_DUP_PROJ      // diagnostics: an idempotent phase run twice; its instruction count = the PMC delta
+            scan_project(P, L, ax, ay, ath);
+#endif
             STAMP(0);
 #ifdef LSA_PHASE_STAMPS
             t_sub = t_last;
@@ -528,6 +547,9 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
                 // this wave's beams, 64 at a time; the seed matches live in LDS between iterations
                 const int T = (int)rintf(6.2831853f / P.dfi);
                 const float inv_dfi = 1.0f / P.dfi;
+#ifdef LSA_DUP_NN
+                for (int rep = 0; rep < 2; ++rep)
+#endif
                 for (int base = wave * WAVE; base < N; base += ICP_THREADS) {
                     const int i0 = base + lane;
                     const bool lv0 = i0 < N && key_bad(L.key[i0 < N ? i0 : 0]) == 0;
@@ -535,8 +557,42 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
                     const int jp0 = iter > 0 && i0 < N ? (int)L.jprev[i0] - 1 : -1;
                     NnBeam b0;
                     nn_plan(P, L, i0, lv0, p0, jp0, T, inv_dfi, b0);
+#ifdef LSA_NN_STATS
+                    {
+                        const bool nf = b0.live && !b0.flat;
+                        const int mx = wave_max_i(nf ? b0.len : 0), sm = wave_sum_i(b0.len), lv = wave_sum_i(b0.live ? 1 : 0), nfc = wave_sum_i(nf ? 1 : 0);
+                        const int nfs = wave_sum_i(nf ? b0.len : 0), fmx = wave_max_i(b0.flat ? b0.len : 0);
+                        if (lane == 0) {
+                            atomicAdd(&lsa_nn_stats[0], 1ull); atomicAdd(&lsa_nn_stats[1], (unsigned long long)sm);
+                            atomicAdd(&lsa_nn_stats[2], mx > 0 ? 1ull : 0ull); atomicAdd(&lsa_nn_stats[3], (unsigned long long)mx);
+                            atomicAdd(&lsa_nn_stats[4], (unsigned long long)lv); atomicAdd(&lsa_nn_stats[5], (unsigned long long)nfc);
+                            atomicAdd(&lsa_nn_stats[6], (unsigned long long)nfs); atomicAdd(&lsa_nn_stats[7], (unsigned long long)fmx);
+                            atomicAdd(&lsa_nn_stats[16 + nn_bucket(mx)], 1ull);
+                        }
+                        if (b0.live) atomicAdd(&lsa_nn_stats[8 + nn_bucket(b0.len)], 1ull);
+                        if (b0.live && b0.pl.M < 0) atomicAdd(&lsa_nn_stats[14], 1ull);
+                    }
+#endif
                     nn_flat(L, N, b0);
+#if defined(LSA_DUP_NN) && defined(LSA_DUP_NN_PLANFLAT)
+                    if (rep == 1) { if (b0.best_j == 12345678) L.jprev[0] = 0; continue; }
+#endif
                     if (__ballot(b0.live && !b0.flat)) nn_general(P, L, T, b0);
+#if defined(LSA_DUP_NN) && defined(LSA_DUP_NN_NOSTORE)
+                    if (rep == 1) { if (b0.best_j == 12345678) L.jprev[0] = 0; continue; }
+#endif
+#ifdef LSA_NN_STATS
+                    {   // list length the final best distance would have allowed
+                        const float rho = L.pr[i0 < N ? i0 : N - 1] * 0.999f - 0.01f;
+                        const float tc = b0.best < NN_CAP ? b0.best : NN_CAP;
+                        const float t = __builtin_amdgcn_sqrtf(tc) * 1.001f * __builtin_amdgcn_rcpf(rho > 1e-3f ? rho : 1e-3f);
+                        int ls = 2 * P.window;
+                        if (b0.best < 1000000.0f && rho > 0.0f && t < 1.0f) { int M = (int)((t + 0.5708f * t * t * t) * inv_dfi) + 2; ls = 2 * M + 1 < ls ? 2 * M + 1 : ls; }
+                        if (!b0.live) ls = 0;
+                        const int sm = wave_sum_i(ls), mx = wave_max_i(ls > 8 ? ls : 0);
+                        if (lane == 0) { atomicAdd(&lsa_nn_stats[15], (unsigned long long)sm); atomicAdd(&lsa_nn_stats[22], (unsigned long long)mx); }
+                    }
+#endif
                     const int m0 = nn_store(L, N, i0, b0);
                     if (i0 < N) L.jprev[i0] = (uint16_t)(m0 + 1);
                 }
@@ -545,7 +601,7 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
             STAMP(1);
 
             // ---- wave 0: compaction in beam order ------------------------------------
-            if (wave == 0) {
+            if (wave == sw) {
                 int m = 0;
                 for (int base = 0; base < N; base += WAVE) {
                     const int i = base + lane;
@@ -563,7 +619,8 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
             if (n < P.min_valid) { status = LSA_ST_FEW_POINTS; break; }                  // :1825-1832
             drop = (int)((double)n * 0.2);                                              // :1836
             keep = n - drop;
-#ifdef LSA_PHASE_STAMPS
+#ifdef LSA_SKIP_TRIM
+#elif defined(LSA_PHASE_STAMPS)
             t_sub = __builtin_readcyclecounter();
             trim_worst(L, n, drop, imisc + 40, ph, t_sub);
 #else
@@ -575,6 +632,9 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
             // ---- interpolation of the reference side, :1867-1926 ---------------------
             // ix/iy are indexed by the reference beam and later pairs overwrite earlier
             // ones: the pair with the largest list position owns the beam.
+#ifdef LSA_DUP_OWNER
+            for (int rep = 0; rep < 2; ++rep) {
+#endif
             for (int i = tid; i < N; i += ICP_THREADS) L.owner[i] = 0;                   // (aliases the trim pool)
             __syncthreads();
             for (int k = tid; k < keep; k += ICP_THREADS)
@@ -591,11 +651,18 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
                 V0[k] = p.x; V0[VS + k] = p.y; V0[2 * VS + k] = q.x; V0[3 * VS + k] = q.y;
             }
             __syncthreads();
+#ifdef LSA_DUP_OWNER
+            }
+#endif
             STAMP(4);
 
             // ---- closed-form rigid fit, :1936-1986: ordered sums, one lane per sum -------
-            if (tid < 4) fmisc[tid] = ordered_sum(V0 + tid * VS, keep) / (float)keep;
+            if (wave == sw && lane < 4) fmisc[lane] = ordered_sum(V0 + lane * VS, keep) / (float)keep;
             __syncthreads();
+#ifdef LSA_DUP_SUM
+            if (wave == sw && lane < 4) fmisc[lane] = ordered_sum(V0 + lane * VS, keep) / (float)keep;
+            __syncthreads();
+#endif
             STAMP(5);
             const float mpx = fmisc[0], mpy = fmisc[1], mqx = fmisc[2], mqy = fmisc[3];
             for (int k = tid; k < keep; k += ICP_THREADS) {
@@ -603,19 +670,29 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
                 V0[k] = a * e; V0[VS + k] = a * f; V0[2 * VS + k] = c * e; V0[3 * VS + k] = c * f;   // sxx sxy syx syy
             }
             __syncthreads();
-            if (tid < 4) fmisc[4 + tid] = ordered_sum(V0 + tid * VS, keep);
+            // the covariance sums, then the pose update (:1984-1999) and next iteration's cos/sin
+            // (:1753-1754), by the one wave that holds the sums: the other waves only read the result
+            if (wave == sw) {
+                const float sum = lane < 4 ? ordered_sum(V0 + lane * VS, keep) : 0.0f;
+                const float sxx = bcast_f(sum, 0), sxy = bcast_f(sum, 1), syx = bcast_f(sum, 2), syy = bcast_f(sum, 3);
+                const float ndth = atan2f_(sxy - syx, sxx + syy);                // :1984
+                const float cd = cosf_(ndth), sd = sinf_(ndth);
+                const float ndx = mqx - ax - (cd * (mpx - ax) - sd * (mpy - ay));
+                const float ndy = mqy - ay - (sd * (mpx - ax) + cd * (mpy - ay));
+                const float nath = norm_a(ath + ndth);
+                if (lane == 0) {
+                    fmisc[8] = ndx; fmisc[9] = ndy; fmisc[10] = ndth; fmisc[11] = nath;
+                    fmisc[12] = cosf_(nath); fmisc[13] = sinf_(nath);
+                }
+            }
             __syncthreads();
             STAMP(6);
-            const float sxx = fmisc[4], sxy = fmisc[5], syx = fmisc[6], syy = fmisc[7];
-            dth = atan2f_(sxy - syx, sxx + syy);                                // :1984
-            dx = mqx - ax - (cosf_(dth) * (mpx - ax) - sinf_(dth) * (mpy - ay));
-            dy = mqy - ay - (sinf_(dth) * (mpx - ax) + cosf_(dth) * (mpy - ay));
+            dx = fmisc[8]; dy = fmisc[9]; dth = fmisc[10];
             pax = ax; pay = ay;          // (co, si, pax, pay): this iteration's frame, for :2015-2020
             ax += dx;
             ay += dy;
-            ath += dth;
-            ath = norm_a(ath);
-            __syncthreads();
+            ath = fmisc[11];
+            nco = fmisc[12]; nsi = fmisc[13];
             STAMP(7);
         }
 #ifdef LSA_PHASE_STAMPS

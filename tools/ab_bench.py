@@ -6,9 +6,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
 flags = [a for a in sys.argv[1:] if a.startswith("-D")]
-out = os.path.join(ROOT, "gpurun_out", "liblsa_core_ab.so")
-os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.check_call(["hipcc"] + ge.HIP_FLAGS + flags + ["-o", out, os.path.join(ge.CSRC, "core.hip"), os.path.join(ge.CSRC, "carmen.cpp")])
+libs = [a[6:] for a in sys.argv[1:] if a.startswith("--lib=")]      # prebuilt variant (tools/build_variants.py)
+if libs:
+    out = os.path.abspath(libs[0]); flags = [os.path.basename(out)]
+else:
+    out = os.path.join(ROOT, "gpurun_out", "liblsa_core_ab.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call(["hipcc"] + ge.HIP_FLAGS + flags + ["-o", out, os.path.join(ge.CSRC, "core.hip"), os.path.join(ge.CSRC, "carmen.cpp")])
 from laser_slam_amd import capi, synth
 capi.LIB_PATH = out
 import torch
