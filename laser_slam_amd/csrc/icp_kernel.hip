@@ -17,6 +17,7 @@
 //   [.. , +4Np)   owner    u32 per reference beam
 //   [.. , +4Np)   ref_bad, pair_ok bytes; jprev u16 (last match per beam, the NN seed)
 //   [.. , +256)   broadcast slots
+//   [.. , +Np/8)  good: one bit per reference ray (ref_bad == 0)
 // The current scan's ranges stay in HBM/L2 (read coalesced once per phase).
 
 constexpr int ICP_THREADS = 256;
@@ -64,7 +65,7 @@ __host__ __device__ inline int icp_o_bytes(int n)
 __host__ __device__ inline int icp_lds_bytes(int n)
 {
     int Np = (n + 63) & ~63;
-    return 16 * Np + icp_v_bytes(n) + icp_o_bytes(n) + 4 * Np + 256;
+    return 16 * Np + icp_v_bytes(n) + icp_o_bytes(n) + 4 * Np + 256 + ((Np / 8 + 15) & ~15);
 }
 
 __device__ __forceinline__ Lds carve_icp(char* base, int n)
@@ -90,6 +91,7 @@ __device__ __forceinline__ Lds carve_icp(char* base, int n)
     L.pair_ok = (uint8_t*)(f + Np);
     L.jprev = (uint16_t*)(f + 2 * Np);          // last iteration's match per beam (+1; 0 = none)
     L.misc = (float*)(f + 4 * Np);
+    L.good = (uint32_t*)(f + 4 * Np + 256);     // Np / 32 words
     return L;
 }
 
@@ -233,10 +235,33 @@ __device__ __forceinline__ void nn_plan(const DevParam& P, const Lds& L, int i, 
     int bj1 = 0x7fffffff;
     nn_eval_pred(L, N, p, c, true, b1, bj1);
     nn_eval_pred(L, N, p, jprev, jprev >= b.pl.lo && jprev < b.pl.hi, b1, bj1);
+    // neither seed usable (the ray at the bearing is bad and there is no previous match): take the
+    // usable rays nearest to the bearing on either side from the bit mask, so that the search
+    // stays bounded; a window without any usable ray has no match at all
+    const bool unseeded = live && b1 >= 1000000.0f;
+    bool nothing = false;
+    if (__ballot(unseeded)) {
+        int jl = -1, jr = -1;
+        if (unseeded) {
+            const int wmin = b.pl.lo >> 5, wmax = (b.pl.hi - 1) >> 5;
+            int w = c >> 5;
+            uint32_t m = L.good[w] & (0xffffffffu << (c & 31));
+            while (m == 0 && w < wmax) m = L.good[++w];
+            if (m) { const int j = (w << 5) + __builtin_ctz(m); if (j < b.pl.hi) jr = j; }
+            w = c >> 5;
+            m = L.good[w] & (0xffffffffu >> (31 - (c & 31)));
+            while (m == 0 && w > wmin) m = L.good[--w];
+            if (m) { const int j = (w << 5) + 31 - __builtin_clz(m); if (j >= b.pl.lo) jl = j; }
+        }
+        nn_eval_pred(L, N, p, jl, unseeded && jl >= 0, b1, bj1);
+        nn_eval_pred(L, N, p, jr, unseeded && jr >= 0, b1, bj1);
+        nothing = unseeded && jl < 0 && jr < 0;
+    }
     // planning only (conservative margins absorb the approximate sqrt / reciprocal)
     const float tcap = b1 < NN_CAP ? b1 : NN_CAP;
     const float t = __builtin_amdgcn_sqrtf(tcap) * 1.001f * __builtin_amdgcn_rcpf(rho > 1e-3f ? rho : 1e-3f);
-    const bool bounded = b1 < 1000000.0f && rho > 0.0f && t < 1.0f;
+    // (without any seed the radius is that of NN_CAP: a match farther than 100 cm is rejected anyway, :1811)
+    const bool bounded = rho > 0.0f && t < 1.0f;
     b.pl.M = bounded ? (int)((t + 0.5708f * t * t * t) * inv_dfi) + 2 : -1;
     int done = b.pl.lo - 1, s0, e0, len = 0, l0 = 0;
     nn_range(b.pl, T, -1, done, s0, e0); len += e0 >= s0 ? e0 - s0 + 1 : 0;
@@ -246,6 +271,7 @@ __device__ __forceinline__ void nn_plan(const DevParam& P, const Lds& L, int i, 
     nn_range(b.pl, T, 1, done, s0, e0); len += e0 >= s0 ? e0 - s0 + 1 : 0;
     b.len = live ? len : 0;
     b.flat = live && len == l0 && len <= NN_FLAT;
+    if (nothing) { b.len = 0; b.flat = true; b.s0 = 0; b.e0 = -1; }
     b.best = 1000000.0f;
     b.best_j = 0x7fffffff;
 }
@@ -501,7 +527,10 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
         for (int i = tid; i < N; i += ICP_THREADS) {
             float rr = g_r[ro + i];
             L.ref_xy[i] = make_float2(rr * P.co[i], rr * P.si[i]);      // :1710-1711
-            L.ref_bad[i] = g_bad[ro + i];
+            const uint8_t rb = g_bad[ro + i];
+            L.ref_bad[i] = rb;
+            const unsigned long long gm = __ballot(rb == 0);           // lanes past N are inactive here: their bits are 0
+            if (lane == 0) { L.good[(i >> 5)] = (uint32_t)gm; L.good[(i >> 5) + 1] = (uint32_t)(gm >> 32); }
             uint8_t ok = 0;
             if (i >= 1) {
                 uint16_t s1 = g_seg[ao + i], s0 = g_seg[ao + i - 1];

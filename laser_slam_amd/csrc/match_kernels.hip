@@ -60,6 +60,7 @@ struct Lds {
     unsigned long long* evict;
     float* misc;               // broadcast slots
     uint16_t* jprev;           // ICP: last iteration's match per beam
+    uint32_t* good;            // ICP: bit j set = reference ray j is usable (ref_bad == 0)
 };
 
 __device__ __forceinline__ Lds carve_psm(char* base, int Np)
