@@ -382,6 +382,33 @@ __device__ __forceinline__ int count_split(const float* row, int cnt, float d, i
     return c;
 }
 
+// #{from <= p < cnt : row[p] >= d} for d >= 0 (rows are padded to a multiple of 4 with -1)
+__device__ __forceinline__ int count_ge_from(const float* row, int cnt, float d, int from)
+{
+    const int4* r4 = (const int4*)row;
+    const int t2 = (int)f2u(d) - 1;
+    const int nq = (cnt + 3) >> 2;
+    int qd = from >> 2, c = 0;
+    if (qd < nq && (from & 3)) {                         // the quad that straddles `from`
+        const int4 v = r4[qd];
+        const int p = qd * 4;
+        c += (p + 1 >= from && v.y > t2) ? 1 : 0;
+        c += (p + 2 >= from && v.z > t2) ? 1 : 0;
+        c += (p + 3 >= from && v.w > t2) ? 1 : 0;
+        ++qd;
+    }
+#ifndef LSA_NO_UNROLL
+    #pragma unroll 4
+#endif
+    for (; qd < nq; ++qd) {
+        const int4 v = r4[qd];
+        c += (v.x > t2) + (v.y > t2) + (v.z > t2) + (v.w > t2);
+    }
+    return c;
+}
+
+// diagnostics: the same pure computation once more (opaque to CSE), results averaged
+#define LSA_TWICE(flag, var, expr_with_dd) do { float dd = d; asm volatile("" : "+v"(dd)); const int v2_ = (expr_with_dd); var = (var + v2_) >> 1; } while (0)
 #ifdef LSA_TRIM_NOINLINE
 __device__ __noinline__ void trim_worst(const Lds& L, int n, int k, int* wcnt)
 #else
@@ -407,7 +434,13 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt
         if (tid < k) cd[tid] = d;
         if (tid < 4 && k + tid < ((k + 3) & ~3)) cd[k + tid] = -1.0f;
         __syncthreads();
-        if (tid < k) Pc[count_split(cd, k, d, tid + 1)] = rec;
+        {
+            int r0 = tid < k ? count_split(cd, k, d, tid + 1) : 0;
+#ifdef LSA_DUP_FIRSTK
+            LSA_TWICE(0, r0, tid < k ? count_split(cd, k, dd, tid + 1) : 0);
+#endif
+            if (tid < k) Pc[r0] = rec;
+        }
         __syncthreads();
         SUBSTAMP(13, 0.0f);
     }
@@ -436,7 +469,10 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt
         __syncthreads();
         SUBSTAMP(15, (float)g1);
         // earlier records of this step that are strictly greater (later ones never count)
-        const int g2 = cand ? count_split(cd, cpos, d, cpos) : 0;
+        int g2 = cand ? count_split(cd, cpos, d, cpos) : 0;
+#ifdef LSA_DUP_G2
+        LSA_TWICE(0, g2, cand ? count_split(cd, cpos, dd, cpos) : 0);
+#endif
         const bool ent = cand && (g1 + g2 < k);
         int E;
         const int epos = block_rank(ent, E, wcnt, phase);
@@ -448,7 +484,13 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt
         const unsigned long long pv = tid < k ? Pc[tid] : 0ull;            // this thread's pool record
         __syncthreads();
         // rank of this thread's record among the entering ones (greater key first) ...
-        const int h = ent ? count_split(ce, E, d, epos + 1) : 0;
+        // Every earlier candidate that is strictly greater than an entering record has entered
+        // itself (its count of greater predecessors is no larger), so the entering records ahead
+        // of this one number g2 plus the later ones that are greater or equal.
+        int h = ent ? g2 + count_ge_from(ce, E, d, epos + 1) : 0;
+#ifdef LSA_DUP_H
+        LSA_TWICE(0, h, ent ? g2 + count_ge_from(ce, E, dd, epos + 1) : 0);
+#endif
         if (ent) se[h] = d;
         __syncthreads();
         const int top = k + E - 1;
