@@ -57,7 +57,16 @@ static lsa::DevParam dev_param(const lsa_ctx* c)
     return P;
 }
 
+#ifdef LSA_LDS_PAD      // diagnostics: extra dynamic LDS to lower the number of resident workgroups per CU
+static int icp_lds(int n)
+{
+    static bool once = false;
+    if (!once) { once = true; (void)hipFuncSetAttribute((const void*)lsa::icp_kernel<1081>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+    return lsa::icp_lds_bytes(n) + (LSA_LDS_PAD);
+}
+#else
 static int icp_lds(int n) { return lsa::icp_lds_bytes(n); }
+#endif
 static int psm_lds(int n) { return lsa::psm_lds_bytes(n); }
 static int pre_lds(int n) { int Np = (n + 63) & ~63; return 12 * Np; }
 
@@ -322,10 +331,18 @@ int lsa_match_batch(lsa_ctx* c, int which, int B,
     if (B <= 0) return LSA_OK;
     HIP_TRY(hipSetDevice(c->device));
     const lsa::DevParam P = dev_param(c);
-    if (which == LSA_MATCH_ICP)
-        hipLaunchKernelGGL(lsa::icp_kernel, dim3(B), dim3(lsa::ICP_THREADS), icp_lds(P.n), c->stream, P, B, d_r, d_bad, d_seg,
-                           d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters);
-    else
+    if (which == LSA_MATCH_ICP) {
+#define LSA_LAUNCH_ICP(NC) hipLaunchKernelGGL(lsa::icp_kernel<NC>, dim3(B), dim3(lsa::ICP_THREADS), icp_lds(P.n), c->stream, P, B, d_r, \
+                           d_bad, d_seg, d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters)
+        switch (P.n) {          // the reference's presets (PolarParameter.h:75-83) and the 1081-beam benchmark sensor
+        case 181:  LSA_LAUNCH_ICP(181); break;
+        case 361:  LSA_LAUNCH_ICP(361); break;
+        case 541:  LSA_LAUNCH_ICP(541); break;
+        case 1081: LSA_LAUNCH_ICP(1081); break;
+        default:   LSA_LAUNCH_ICP(0); break;
+        }
+#undef LSA_LAUNCH_ICP
+    } else
         hipLaunchKernelGGL(lsa::psm_kernel, dim3(B), dim3(lsa::PSM_THREADS), psm_lds(P.n), c->stream, P, B, d_r, d_bad, d_seg,
                            d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters);
     HIP_TRY(hipGetLastError());

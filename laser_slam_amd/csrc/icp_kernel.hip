@@ -8,17 +8,18 @@
 //    sums of the rigid fit) run in wave 0 while the other waves of the pair wait at
 //    a barrier and the CU's other pairs fill the SIMDs.
 //
-// LDS (bytes, Np = N rounded up to 64; 38.3 KiB at N = 1081 -> 4 pairs per CU):
+// LDS (bytes, Np = N rounded up to 64; 31.1 KiB at N = 1081 -> 5 pairs per CU):
 //   [ 0   , 8Np)  ref_xy   float2 (reference scan, Cartesian; ranges for the error index)
 //   [ 8Np ,16Np)  K        u64 scatter-min keys -> per-beam NN record -> match list (in place)
 //   [16Np ,16Np+VB) D      pr,pf of the projection (NN reads them as search centre)
 //                          -> V: ordered (nx,ny,ix,iy) float4 list -> W: the four products
 //                          (the trim pools and scratch also live here, between NN and V)
-//   [.. , +4Np)   owner    u32 per reference beam
-//   [.. , +4Np)   ref_bad, pair_ok bytes; jprev u16 (last match per beam, the NN seed)
+//                          -> owner (u32 per reference beam) between the trim and the value lists
 //   [.. , +256)   broadcast slots
 //   [.. , +Np/8)  good: one bit per reference ray (ref_bad == 0)
-// The current scan's ranges stay in HBM/L2 (read coalesced once per phase).
+//   [.. , +Np/8)  pair_mask: one bit per beam (beams i-1,i form a valid pair)
+// Last iteration's match per beam (the NN seed) lives in registers: a thread always handles the
+// same beams.  The current scan's ranges stay in HBM/L2 (read coalesced once per phase).
 
 constexpr int ICP_THREADS = 256;
 
@@ -56,16 +57,19 @@ __host__ __device__ inline int icp_v_bytes(int n)
     if (vb < tb) vb = tb;
     return (vb + 63) & ~63;
 }
-// owner array: u32 per reference beam
-__host__ __device__ inline int icp_o_bytes(int n)
+// The owner array (u32 per reference beam) is needed only between the trim and the value lists,
+// so it aliases the D region; each thread then holds the owners of its (at most 4) pairs in
+// registers while the lists overwrite it.  Longer lists get an array of their own.
+__host__ __device__ inline bool icp_owner_separate(int n) { return n - (int)((double)n * 0.2) + 2 > 4 * ICP_THREADS; }
+__host__ __device__ inline int icp_mask_bytes(int n)
 {
     int Np = (n + 63) & ~63;
-    return 4 * Np;
+    return (Np / 8 + 8 + 15) & ~15;            // one bit per ray + one spare word for two-word windows
 }
 __host__ __device__ inline int icp_lds_bytes(int n)
 {
     int Np = (n + 63) & ~63;
-    return 16 * Np + icp_v_bytes(n) + icp_o_bytes(n) + 4 * Np + 256 + ((Np / 8 + 15) & ~15);
+    return 16 * Np + icp_v_bytes(n) + (icp_owner_separate(n) ? 4 * Np : 0) + 256 + 2 * icp_mask_bytes(n);
 }
 
 __device__ __forceinline__ Lds carve_icp(char* base, int n)
@@ -79,20 +83,18 @@ __device__ __forceinline__ Lds carve_icp(char* base, int n)
     L.pr = (float*)d;
     L.pf = (float*)(d + 4 * Np);
     L.V = (float4*)d;
-    char* o = d + icp_v_bytes(n);
-    L.owner = (uint32_t*)o;
     const int kmax = (int)((double)n * 0.2) + 1;
     L.poolA = (unsigned long long*)d;               // trim pools + scratch alias the D region
     L.poolB = L.poolA + kmax;
     L.evict = L.poolB + kmax;                       // TRIM_CHUNK records, then 3 x TRIM_CHUNK floats
     L.pool_d = (float*)(L.evict + TRIM_CHUNK);
-    char* f = o + icp_o_bytes(n);
-    L.ref_bad = (uint8_t*)f;
-    L.pair_ok = (uint8_t*)(f + Np);
-    L.jprev = (uint16_t*)(f + 2 * Np);          // last iteration's match per beam (+1; 0 = none)
-    L.misc = (float*)(f + 4 * Np);
-    L.good = (uint32_t*)(f + 4 * Np + 256);     // Np / 32 words
-    return L;
+    char* f = d + icp_v_bytes(n);
+    L.owner = (uint32_t*)d;
+    if (icp_owner_separate(n)) { L.owner = (uint32_t*)f; f += 4 * Np; }
+    L.misc = (float*)f;
+    L.good = (uint32_t*)(f + 256);
+    L.pair_mask = (uint32_t*)(f + 256 + icp_mask_bytes(n));
+    return L;                                       // ref_bad, pair_ok, jprev stay null: bit masks / registers
 }
 
 struct Rec { float d; uint32_t ij; };   // match record: distance, cur beam | ref beam << 16
@@ -166,7 +168,7 @@ __device__ __forceinline__ void nn_range(const NnPlan& pl, int T, int im, int& d
 
 __device__ __forceinline__ void nn_eval(const Lds& L, float2 p, int j, float& best, int& best_j)
 {
-    if (L.ref_bad[j] == 0) {
+    if ((L.good[j >> 5] >> (j & 31)) & 1u) {
         const float2 rj = L.ref_xy[j];
         const float ex = p.x - rj.x, ey = p.y - rj.y;
         const float d = ex * ex + ey * ey;                 // :1803
@@ -174,16 +176,23 @@ __device__ __forceinline__ void nn_eval(const Lds& L, float2 p, int j, float& be
     }
 }
 
-// four consecutive rays with their loads issued together
+// usable-flags of rays j .. j+31 (bit o = ray j+o); the mask has a spare word at the end
+__device__ __forceinline__ uint32_t good_window(const Lds& L, int j)
+{
+    const int q = j >> 5;
+    return __builtin_amdgcn_alignbit(L.good[q + 1], L.good[q], (uint32_t)j & 31u);
+}
+
+// four consecutive rays with their loads issued together (ascending j: the first strict minimum wins)
 __device__ __forceinline__ void nn_eval4(const Lds& L, float2 p, int j, float& best, int& best_j)
 {
-    const uint8_t b0 = L.ref_bad[j], b1 = L.ref_bad[j + 1], b2 = L.ref_bad[j + 2], b3 = L.ref_bad[j + 3];
+    const uint32_t g = good_window(L, j);
     const float2 r0 = L.ref_xy[j], r1 = L.ref_xy[j + 1], r2 = L.ref_xy[j + 2], r3 = L.ref_xy[j + 3];
     float ex, ey, d;
-    ex = p.x - r0.x; ey = p.y - r0.y; d = ex * ex + ey * ey; if (b0 == 0 && d < best) { best = d; best_j = j; }
-    ex = p.x - r1.x; ey = p.y - r1.y; d = ex * ex + ey * ey; if (b1 == 0 && d < best) { best = d; best_j = j + 1; }
-    ex = p.x - r2.x; ey = p.y - r2.y; d = ex * ex + ey * ey; if (b2 == 0 && d < best) { best = d; best_j = j + 2; }
-    ex = p.x - r3.x; ey = p.y - r3.y; d = ex * ex + ey * ey; if (b3 == 0 && d < best) { best = d; best_j = j + 3; }
+    ex = p.x - r0.x; ey = p.y - r0.y; d = ex * ex + ey * ey; if ((g & 1u) && d < best) { best = d; best_j = j; }
+    ex = p.x - r1.x; ey = p.y - r1.y; d = ex * ex + ey * ey; if ((g & 2u) && d < best) { best = d; best_j = j + 1; }
+    ex = p.x - r2.x; ey = p.y - r2.y; d = ex * ex + ey * ey; if ((g & 4u) && d < best) { best = d; best_j = j + 2; }
+    ex = p.x - r3.x; ey = p.y - r3.y; d = ex * ex + ey * ey; if ((g & 8u) && d < best) { best = d; best_j = j + 3; }
 }
 
 #ifndef LSA_NN_FLAT
@@ -206,11 +215,11 @@ struct NnBeam {
 __device__ __forceinline__ void nn_eval_pred(const Lds& L, int N, float2 p, int j, bool pred, float& best, int& best_j)
 {
     const int jc = j < 0 ? 0 : (j > N - 1 ? N - 1 : j);
-    const uint8_t bad = L.ref_bad[jc];
+    const bool ok = (L.good[jc >> 5] >> (jc & 31)) & 1u;
     const float2 rj = L.ref_xy[jc];
     const float ex = p.x - rj.x, ey = p.y - rj.y;
     const float d = ex * ex + ey * ey;                 // :1803
-    const bool take = pred && bad == 0 && (d < best || (d == best && j < best_j));
+    const bool take = pred && ok && (d < best || (d == best && j < best_j));
     best = take ? d : best;
     best_j = take ? j : best_j;
 }
@@ -276,10 +285,25 @@ __device__ __forceinline__ void nn_plan(const DevParam& P, const Lds& L, int i, 
     b.best_j = 0x7fffffff;
 }
 
+// up to NN_FLAT (= 8) consecutive rays s0 .. e0, straight-line: one flag window, loads at fixed
+// offsets from one base (shifted down near the end of the scan so that all eight stay inside it)
 __device__ __forceinline__ void nn_flat(const Lds& L, int N, NnBeam& b)
 {
+    static_assert(NN_FLAT == 8, "nn_flat is written for eight rays");
+    const int base = b.s0 < N - 8 ? (b.s0 > 0 ? b.s0 : 0) : N - 8;
+    const int off = b.s0 - base;                                       // 0 unless clamped
+    const int cnt = b.flat ? b.e0 - b.s0 + 1 : 0;                      // <= 8
+    const uint32_t act = good_window(L, base) & (((1u << cnt) - 1u) << off) & 0xffu;
+    const float2* r = L.ref_xy + base;
     #pragma unroll
-    for (int o = 0; o < NN_FLAT; ++o) nn_eval_pred(L, N, b.p, b.s0 + o, b.flat && b.s0 + o <= b.e0, b.best, b.best_j);
+    for (int o = 0; o < 8; ++o) {
+        const float2 rj = r[o];
+        const float ex = b.p.x - rj.x, ey = b.p.y - rj.y;
+        const float d = ex * ex + ey * ey;                             // :1803
+        const bool take = (act & (1u << o)) && d < b.best;             // ascending j: first strict minimum
+        b.best = take ? d : b.best;
+        b.best_j = take ? base + o : b.best_j;
+    }
 }
 
 // the general path: candidate lists that are longer than NN_FLAT or span several images, per lane.
@@ -427,19 +451,38 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt
     float* ce = L.pool_d + TRIM_CHUNK;               // entering records' distances (arrival order)
     float* se = L.pool_d + 2 * TRIM_CHUNK;           // entering records' distances, descending
     int phase = 0;
-    // the first k records (k <= TRIM_CHUNK, host-checked): rank sort, descending by (distance, arrival)
+    // the first k records (k <= TRIM_CHUNK, host-checked): rank sort, descending by (distance, later
+    // arrival first among equals).  Each wave ranks its own 64 records by counting, publishes them
+    // as a sorted run, and ranks against the other waves' runs by binary search.
     {
+        const int wave = tid >> 6, lane = tid & 63;
         const unsigned long long rec = tid < k ? A[tid] : 0ull;
         const float d = rec_d(rec);
         if (tid < k) cd[tid] = d;
         if (tid < 4 && k + tid < ((k + 3) & ~3)) cd[k + tid] = -1.0f;
         __syncthreads();
-        {
-            int r0 = tid < k ? count_split(cd, k, d, tid + 1) : 0;
-#ifdef LSA_DUP_FIRSTK
-            LSA_TWICE(0, r0, tid < k ? count_split(cd, k, dd, tid + 1) : 0);
-#endif
-            if (tid < k) Pc[r0] = rec;
+        const int seg = k - 64 * wave < 64 ? k - 64 * wave : 64;        // records of this wave (may be <= 0)
+        int rank = 0;
+        if (tid < k) {
+            rank = count_split(cd + 64 * wave, seg, d, lane + 1);
+            ce[64 * wave + rank] = d;
+        }
+        __syncthreads();
+        if (tid < k) {
+            const int t1 = (int)f2u(d);
+            const int* srt = (const int*)ce;
+            for (int b = 0; 64 * b < k; ++b) {
+                if (b == wave) continue;
+                const int m = k - 64 * b < 64 ? k - 64 * b : 64;
+                const int thr = b < wave ? t1 : t1 - 1;                 // earlier records must be strictly greater
+                int lo = 0, hi = m;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (srt[64 * b + mid] > thr) lo = mid + 1; else hi = mid;
+                }
+                rank += lo;
+            }
+            Pc[rank] = rec;
         }
         __syncthreads();
         SUBSTAMP(13, 0.0f);
@@ -543,13 +586,21 @@ __device__ __forceinline__ float ordered_sum(const float* arr, int cnt)
 }
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
-    DevParam P, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
+#ifndef LSA_ICP_WG_PER_CU
+#define LSA_ICP_WG_PER_CU 5
+#endif
+// NC > 0: the beam count as a compile-time constant (the sensors' usual sizes), so that the LDS
+// layout and the trip counts are immediates instead of scalar registers; NC = 0: any size.
+template <int NC>
+__global__ __launch_bounds__(ICP_THREADS, LSA_ICP_WG_PER_CU) void icp_kernel(
+    DevParam P_, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
     const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
     const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
     float* __restrict__ err_xy, int* __restrict__ n_assoc, int* __restrict__ status_out, int* __restrict__ iters_out)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevParam P = P_;
+    if (NC > 0) P.n = NC;
     const int N = P.n, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     Lds L = carve_icp(smem, N);
     int* imisc = (int*)L.misc;              // [0] n
@@ -570,16 +621,19 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
             float rr = g_r[ro + i];
             L.ref_xy[i] = make_float2(rr * P.co[i], rr * P.si[i]);      // :1710-1711
             const uint8_t rb = g_bad[ro + i];
-            L.ref_bad[i] = rb;
-            const unsigned long long gm = __ballot(rb == 0);           // lanes past N are inactive here: their bits are 0
-            if (lane == 0) { L.good[(i >> 5)] = (uint32_t)gm; L.good[(i >> 5) + 1] = (uint32_t)(gm >> 32); }
-            uint8_t ok = 0;
+            bool ok = false;
             if (i >= 1) {
                 uint16_t s1 = g_seg[ao + i], s0 = g_seg[ao + i - 1];
-                ok = (s1 != 0 && s1 == s0 && g_bad[ao + i] == 0 && g_bad[ao + i - 1] == 0) ? 1 : 0;   // :1396
+                ok = s1 != 0 && s1 == s0 && g_bad[ao + i] == 0 && g_bad[ao + i - 1] == 0;     // :1396
             }
-            L.pair_ok[i] = ok;
+            // flags as bit masks (lanes past N are inactive here: their bits are 0)
+            const unsigned long long gm = __ballot(rb == 0), pm = __ballot(ok);
+            if (lane == 0) {
+                L.good[i >> 5] = (uint32_t)gm; L.good[(i >> 5) + 1] = (uint32_t)(gm >> 32);
+                L.pair_mask[i >> 5] = (uint32_t)pm; L.pair_mask[(i >> 5) + 1] = (uint32_t)(pm >> 32);
+            }
         }
+        if (tid == 0) { L.good[((N + 63) & ~63) >> 5] = 0; L.pair_mask[((N + 63) & ~63) >> 5] = 0; }   // spare words
         float ax, ay, ath;
         rel_pose(init_pose ? init_pose + 6 * (size_t)b : nullptr, ax, ay, ath);
         const float ax0 = init_pose ? init_pose[6 * (size_t)b + 3] : 0.0f;
@@ -589,6 +643,7 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
         int small = 0, status = LSA_ST_OK, n = 0, drop = 0, keep = 0;
         float nco = cosf_(ath), nsi = sinf_(ath);       // :1753-1754 for the coming iteration, refreshed with every pose update
         float co = 1.0f, si = 0.0f, pax = 0.0f, pay = 0.0f;
+        uint32_t jpk0 = 0, jpk1 = 0, jpk2 = 0;           // last matches (+1, 0 = none) of this thread's up to six beams, u16 pairs
         __syncthreads();
 #ifdef LSA_PHASE_STAMPS
         unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -621,11 +676,12 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
 #ifdef LSA_DUP_NN
                 for (int rep = 0; rep < 2; ++rep)
 #endif
-                for (int base = wave * WAVE; base < N; base += ICP_THREADS) {
+                for (int base = wave * WAVE, trip = 0; base < N; base += ICP_THREADS, ++trip) {
                     const int i0 = base + lane;
                     const bool lv0 = i0 < N && key_bad(L.key[i0 < N ? i0 : 0]) == 0;
                     const float2 p0 = cur_point(P, L.g_act_r, i0 < N ? i0 : N - 1, co, si, ax, ay);
-                    const int jp0 = iter > 0 && i0 < N ? (int)L.jprev[i0] - 1 : -1;
+                    const uint32_t jpw = trip < 2 ? jpk0 : (trip < 4 ? jpk1 : jpk2);
+                    const int jp0 = (int)((trip & 1) ? jpw >> 16 : jpw & 0xffffu) - 1;   // -1 in the first iteration
                     NnBeam b0;
                     nn_plan(P, L, i0, lv0, p0, jp0, T, inv_dfi, b0);
 #ifdef LSA_NN_STATS
@@ -646,11 +702,11 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
 #endif
                     nn_flat(L, N, b0);
 #if defined(LSA_DUP_NN) && defined(LSA_DUP_NN_PLANFLAT)
-                    if (rep == 1) { if (b0.best_j == 12345678) L.jprev[0] = 0; continue; }
+                    if (rep == 1) { if (b0.best_j == 12345678) L.key[0] = 0; continue; }
 #endif
                     if (__ballot(b0.live && !b0.flat)) nn_general(P, L, T, b0);
 #if defined(LSA_DUP_NN) && defined(LSA_DUP_NN_NOSTORE)
-                    if (rep == 1) { if (b0.best_j == 12345678) L.jprev[0] = 0; continue; }
+                    if (rep == 1) { if (b0.best_j == 12345678) L.key[0] = 0; continue; }
 #endif
 #ifdef LSA_NN_STATS
                     {   // list length the final best distance would have allowed
@@ -665,7 +721,11 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
                     }
 #endif
                     const int m0 = nn_store(L, N, i0, b0);
-                    if (i0 < N) L.jprev[i0] = (uint16_t)(m0 + 1);
+                    {
+                        const uint32_t nv = (uint32_t)(m0 + 1) & 0xffffu;
+                        const uint32_t nw = (trip & 1) ? (jpw & 0xffffu) | (nv << 16) : (jpw & 0xffff0000u) | nv;
+                        if (trip < 2) jpk0 = nw; else if (trip < 4) jpk1 = nw; else jpk2 = nw;
+                    }
                 }
             }
             __syncthreads();
@@ -706,20 +766,33 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_kernel(
 #ifdef LSA_DUP_OWNER
             for (int rep = 0; rep < 2; ++rep) {
 #endif
-            for (int i = tid; i < N; i += ICP_THREADS) L.owner[i] = 0;                   // (aliases the trim pool)
+            for (int i = tid; i < N; i += ICP_THREADS) L.owner[i] = 0;                   // (aliases the D region)
             __syncthreads();
             for (int k = tid; k < keep; k += ICP_THREADS)
                 atomicMax(&L.owner[(uint32_t)(L.key[k] >> 32) >> 16], (uint32_t)(k + 1));
             __syncthreads();
-            for (int k = tid; k < keep; k += ICP_THREADS) {
-                const uint32_t ij = (uint32_t)(L.key[k] >> 32);
-                const int i = ij & 0xffff, j = ij >> 16;
-                const int ko = (int)L.owner[j] - 1;
-                const int io = ko == k ? i : (int)((uint32_t)(L.key[ko] >> 32) & 0xffff);
-                const float2 p = cur_point(P, L.g_act_r, i, co, si, ax, ay);
-                const float2 po = io == i ? p : cur_point(P, L.g_act_r, io, co, si, ax, ay);
-                const float2 q = interp_candidate(L, N, po, j);
-                V0[k] = p.x; V0[VS + k] = p.y; V0[2 * VS + k] = q.x; V0[3 * VS + k] = q.y;
+            for (int k0 = 0; k0 < keep; k0 += 4 * ICP_THREADS) {
+                // the owners of this thread's pairs go to registers before the value lists overwrite the array
+                int ko[4];
+                #pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + u * ICP_THREADS + tid;
+                    ko[u] = k < keep ? (int)L.owner[(uint32_t)(L.key[k] >> 32) >> 16] - 1 : -1;
+                }
+                __syncthreads();
+                #pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + u * ICP_THREADS + tid;
+                    if (k < keep) {
+                        const uint32_t ij = (uint32_t)(L.key[k] >> 32);
+                        const int i = ij & 0xffff, j = ij >> 16;
+                        const int io = ko[u] == k ? i : (int)((uint32_t)(L.key[ko[u]] >> 32) & 0xffff);
+                        const float2 p = cur_point(P, L.g_act_r, i, co, si, ax, ay);
+                        const float2 po = io == i ? p : cur_point(P, L.g_act_r, io, co, si, ax, ay);
+                        const float2 q = interp_candidate(L, N, po, j);
+                        V0[k] = p.x; V0[VS + k] = p.y; V0[2 * VS + k] = q.x; V0[3 * VS + k] = q.y;
+                    }
+                }
             }
             __syncthreads();
 #ifdef LSA_DUP_OWNER

@@ -60,8 +60,19 @@ struct Lds {
     unsigned long long* evict;
     float* misc;               // broadcast slots
     uint16_t* jprev;           // ICP: last iteration's match per beam
-    uint32_t* good;            // ICP: bit j set = reference ray j is usable (ref_bad == 0)
+    uint32_t* good;            // ICP: bit j set = reference ray j is usable (ref_bad == 0); ref_bad is null there
+    uint32_t* pair_mask;       // ICP: bit i set = beams i-1,i form a valid pair; pair_ok is null there
 };
+
+// flags live either in byte arrays (PSM layout) or in bit masks (ICP layout, where LDS is scarce)
+__device__ __forceinline__ bool ref_is_bad(const Lds& L, int i)
+{
+    return L.ref_bad ? L.ref_bad[i] != 0 : ((L.good[i >> 5] >> (i & 31)) & 1u) == 0;
+}
+__device__ __forceinline__ bool pair_is_ok(const Lds& L, int i)
+{
+    return L.pair_ok ? L.pair_ok[i] != 0 : ((L.pair_mask[i >> 5] >> (i & 31)) & 1u) != 0;
+}
 
 __device__ __forceinline__ Lds carve_psm(char* base, int Np)
 {
@@ -164,7 +175,7 @@ __device__ void scan_project(const DevParam& P, const Lds& L, float ax, float ay
     }
     __syncthreads();
     for (int i = tid; i < N; i += nth)
-        if (L.pair_ok[i]) scatter_pair(P, L, i);
+        if (pair_is_ok(L, i)) scatter_pair(P, L, i);
     __syncthreads();
 }
 
@@ -218,7 +229,7 @@ __device__ void error_index2_tail(const DevParam& P, const Lds& L, float* exy, i
             unsigned long long k = L.key[i];
             float rr = L.ref_r[i];
             float delta = (float)((double)fabsf_(key_r(k) - rr) * 0.01);
-            if (key_bad(k) == 0 && L.ref_bad[i] == 0 && (double)delta < 50.0 && delta < 1.0f) {
+            if (key_bad(k) == 0 && !ref_is_bad(L, i) && (double)delta < 50.0 && delta < 1.0f) {
                 float a = delta * tab[i];
                 acc += a * a;
                 cnt++;
