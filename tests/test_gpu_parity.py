@@ -197,6 +197,37 @@ def test_match_vs_oracle_shuffled_pairs(name, torch_mod):
     ctx.close()
 
 
+@pytest.mark.parametrize("n_beams,window", [(64, 20), (200, 40), (777, 150), (1000, 200), (1280, 200)])
+def test_match_vs_oracle_other_beam_counts(n_beams, window, torch_mod):
+    """Beam counts outside the presets run the size-generic kernel (the presets' sizes are compiled
+    with the beam count as a constant): synthetic scans of odd sizes against the CPU oracle,
+    preprocessing included."""
+    torch = torch_mod
+    from laser_slam_amd import capi, synth
+    from oracle_lib import Oracle
+    kw = dict(points=n_beams, fov_deg=270, max_range=3000, min_valid=max(8, n_beams // 4), window=window,
+              fi_min_deg=-135, fi_max_deg=135)
+    raw, _ = synth.make_scans(10, n_beams=n_beams, noise_seed=4242 + n_beams)
+    o = Oracle(**kw)
+    ctx = capi.Context(capi.param_make(**kw))
+    S = raw.shape[0]
+    d_r = dev(torch, raw, np.float32)
+    d_bad = torch.zeros(S, n_beams, dtype=torch.uint8, device="cuda"); d_seg = torch.zeros(S, n_beams, dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    ctx.preprocess_batch(S, d_r, d_bad, d_seg); ctx.sync()
+    pre = [o.preprocess(raw[k]) for k in range(S)]
+    r = np.stack([q[0] for q in pre]); bad = np.stack([q[1] for q in pre]); seg = np.stack([q[2] for q in pre])
+    assert same_bits(d_r.cpu().numpy(), r.astype(np.float32))
+    assert np.array_equal(d_bad.cpu().numpy(), bad.astype(np.uint8)) and np.array_equal(d_seg.cpu().numpy(), seg.astype(np.int16))
+    ref_idx = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 0, 2, 5]); act_idx = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 3, 0, 9])
+    for which in (0, 1):
+        out = run_match(torch, ctx, which, r, bad, seg, ref_idx, act_idx, want_err=False)
+        pose_o, st_o = o.match_batch(which, r, bad, seg, ref_idx, act_idx)
+        assert np.array_equal(out["status"], st_o)
+        assert same_bits(out["pose"], pose_o)
+    ctx.close()
+
+
 @pytest.mark.parametrize("name", ["mit", "intel", "syn1081"])
 def test_fmatch_chain_host_api(name, torch_mod):
     g = load(name)
