@@ -19,48 +19,92 @@
 
 constexpr int PSM_THREADS = 256;
 
-__host__ __device__ inline int psm_lds_bytes(int n) { int Np = (n + 63) & ~63; return 35 * Np + 64; }
-
-// NaN-masked rows: nrm[i] = new_r or NaN; rfm[W + j] = ref_r[j] or NaN, NaN outside [0,N)
-__device__ __forceinline__ void build_masked_rows(const DevParam& P, const Lds& L, float* nrm, float* rfm)
+// validity bit masks of the orientation search: new scan (Np/32 + 1 words), padded reference row
+// (2 Np / 32 + 4 words; the window satisfies 2W + 1 <= Np)
+__host__ __device__ inline int psm_mask_words_new(int Np) { return Np / 32 + 1; }
+__host__ __device__ inline int psm_mask_words_ref(int Np) { return 2 * Np / 32 + 4; }
+__host__ __device__ inline int psm_lds_bytes(int n)
 {
-    const int N = P.n, W = P.window;
+    int Np = (n + 63) & ~63;
+    return 35 * Np + 64 + 4 * ((psm_mask_words_new(Np) + psm_mask_words_ref(Np) + 3) & ~3);
+}
+
+// NaN-masked rows: nrm[i] = new_r or NaN; rfm[W + j] = ref_r[j] or NaN, NaN outside [0,N); and the
+// same validity as bit masks (newm bit i, refm bit j of the padded row), built with ballots.  Both
+// loops run to a multiple of 64 so that every mask bit that can meet a set bit of the other mask
+// is written here (the count only looks at bits i < N of newm, i.e. j < N + 2W of refm).
+__device__ __forceinline__ void build_masked_rows(const DevParam& P, const Lds& L, float* nrm, float* rfm,
+                                                  uint32_t* newm, uint32_t* refm)
+{
+    const int N = P.n, W = P.window, Np = (N + 63) & ~63;
     const float qnan = u2f(0x7fc00000u);
-    for (int i = threadIdx.x; i < N; i += blockDim.x) nrm[i] = L.new_bad[i] ? qnan : L.new_r[i];
-    for (int j = threadIdx.x; j < N + 2 * W + 4; j += blockDim.x) {
-        const int src = j - W;
-        rfm[j] = (src >= 0 && src < N && L.ref_bad[src] == 0) ? L.ref_r[src] : qnan;
+    const bool lane0 = lane_id() == 0;
+    for (int i = threadIdx.x; i < Np; i += blockDim.x) {
+        const bool ok = i < N && L.new_bad[i] == 0;
+        nrm[i] = ok ? L.new_r[i] : qnan;
+        const unsigned long long m = __ballot(ok);
+        if (lane0) { newm[i >> 5] = (uint32_t)m; newm[(i >> 5) + 1] = (uint32_t)(m >> 32); }
     }
+    const int Jp = (N + 2 * W + 4 + 63) & ~63;                 // <= 2 Np + 64 <= 3 Np floats: pf row + key rows
+    for (int j = threadIdx.x; j < Jp; j += blockDim.x) {
+        const int src = j - W;
+        const bool ok = src >= 0 && src < N && L.ref_bad[src] == 0;
+        rfm[j] = ok ? L.ref_r[src] : qnan;
+        const unsigned long long m = __ballot(ok);
+        if (lane0) { refm[j >> 5] = (uint32_t)m; refm[(j >> 5) + 1] = (uint32_t)(m >> 32); }
+    }
+}
+
+// one beam quad of one shift: e += |a - b| for the valid terms, in beam order.  An invalid term is
+// NaN; fmaxf(NaN, 0) = 0, and adding +0 leaves the (non-negative) ordered sum unchanged.
+__device__ __forceinline__ void orient_quad(float& e, const float4 a, const float* rb)
+{
+    const float b0 = rb[0], b1 = rb[1], b2 = rb[2], b3 = rb[3];
+    e += fmaxf(fabsf_(a.x - b0), 0.0f);
+    e += fmaxf(fabsf_(a.y - b1), 0.0f);
+    e += fmaxf(fabsf_(a.z - b2), 0.0f);
+    e += fmaxf(fabsf_(a.w - b3), 0.0f);
 }
 
 // pm_orientation_search (:1152-1261) on L.new_r/new_bad vs L.ref_r/ref_bad.  Whole
 // workgroup; returns the status, dth by reference.  Uses pr/pf/key as scratch.
+// Thread t owns the shifts di = t - W and t + 256 - W (two independent ordered sums side by
+// side); the number of valid terms of a shift is the popcount of the two validity masks.
 __device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, float* bc)
 {
-    const int N = P.n, W = P.window, K = 2 * W + 1, tid = threadIdx.x;
-    float* nrm = L.pr;                 // N floats (the pr row)
-    float* rfm = L.pf;                 // N + 2W + 4 floats (pf row + the key rows)
+    const int N = P.n, W = P.window, K = 2 * W + 1, tid = threadIdx.x, Np = (N + 63) & ~63;
+    float* nrm = L.pr;                 // Np floats (the pr row)
+    float* rfm = L.pf;                 // N + 2W + 4 (+ pad) floats (pf row + the key rows)
     float* err = L.err;
-    build_masked_rows(P, L, nrm, rfm);
+    uint32_t* newm = (uint32_t*)(bc + 16);
+    uint32_t* refm = newm + psm_mask_words_new(Np);
+    build_masked_rows(P, L, nrm, rfm, newm, refm);
     __syncthreads();
-    for (int k = tid; k < K; k += blockDim.x) {
-        const float* rb = rfm + k;                  // rfm[W + i + di] with di = k - W
-        float e = 0.0f, cnt = 0.0f;
-        int i = 0;
-        for (; i + 4 <= N; i += 4) {
-            const float4 a = *(const float4*)(nrm + i);
-            const float b0 = rb[i], b1 = rb[i + 1], b2 = rb[i + 2], b3 = rb[i + 3];
-            float d;
-            d = fabsf_(a.x - b0); if (d == d) { e += d; cnt += 1.0f; }
-            d = fabsf_(a.y - b1); if (d == d) { e += d; cnt += 1.0f; }
-            d = fabsf_(a.z - b2); if (d == d) { e += d; cnt += 1.0f; }
-            d = fabsf_(a.w - b3); if (d == d) { e += d; cnt += 1.0f; }
+    const int N4 = (N + 3) & ~3, nw = (N + 31) >> 5;
+    for (int k0 = tid; k0 < K; k0 += 2 * blockDim.x) {
+        const int k1 = k0 + blockDim.x;
+        const bool has1 = k1 < K;
+        const float* rb0 = rfm + k0;                // rfm[W + i + di] with di = k - W
+        const float* rb1 = rfm + (has1 ? k1 : k0);
+        float e0 = 0.0f, e1 = 0.0f;
+        if (__ballot(has1)) {
+            for (int i = 0; i < N4; i += 4) {
+                const float4 a = *(const float4*)(nrm + i);
+                orient_quad(e0, a, rb0 + i);
+                orient_quad(e1, a, rb1 + i);
+            }
+        } else {
+            for (int i = 0; i < N4; i += 4) orient_quad(e0, *(const float4*)(nrm + i), rb0 + i);
         }
-        for (; i < N; ++i) {
-            const float d = fabsf_(nrm[i] - rb[i]);
-            if (d == d) { e += d; cnt += 1.0f; }
+        int c0 = 0, c1 = 0;
+        for (int w = 0; w < nw; ++w) {
+            const uint32_t nm = newm[w];
+            const int j0 = 32 * w + k0, j1 = 32 * w + (has1 ? k1 : k0);
+            c0 += __popc(nm & __builtin_amdgcn_alignbit(refm[(j0 >> 5) + 1], refm[j0 >> 5], (uint32_t)j0 & 31u));
+            c1 += __popc(nm & __builtin_amdgcn_alignbit(refm[(j1 >> 5) + 1], refm[j1 >> 5], (uint32_t)j1 & 31u));
         }
-        err[k] = cnt > 0.0f ? e / cnt : 10000.0f;                                     // :1203-1206
+        err[k0] = c0 > 0 ? e0 / (float)c0 : 10000.0f;                                 // :1203-1206
+        if (has1) err[k1] = c1 > 0 ? e1 / (float)c1 : 10000.0f;
     }
     __syncthreads();
     // first strict minimum (:1225-1234): arg-min on (err, k) by wave 0
