@@ -343,8 +343,18 @@ int lsa_match_batch(lsa_ctx* c, int which, int B,
         }
 #undef LSA_LAUNCH_ICP
     } else
-        hipLaunchKernelGGL(lsa::psm_kernel, dim3(B), dim3(lsa::PSM_THREADS), psm_lds(P.n), c->stream, P, B, d_r, d_bad, d_seg,
-                           d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters);
+    {
+#define LSA_LAUNCH_PSM(NC) hipLaunchKernelGGL(lsa::psm_kernel<NC>, dim3(B), dim3(lsa::PSM_THREADS), lsa::psm_compact_lds_bytes(P.n), c->stream, P, B, \
+                           d_r, d_bad, d_seg, d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters)
+        switch (P.n) {
+        case 181:  LSA_LAUNCH_PSM(181); break;
+        case 361:  LSA_LAUNCH_PSM(361); break;
+        case 541:  LSA_LAUNCH_PSM(541); break;
+        case 1081: LSA_LAUNCH_PSM(1081); break;
+        default:   LSA_LAUNCH_PSM(0); break;
+        }
+#undef LSA_LAUNCH_PSM
+    }
     HIP_TRY(hipGetLastError());
     return LSA_OK;
 }

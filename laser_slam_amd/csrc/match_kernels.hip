@@ -62,12 +62,17 @@ struct Lds {
     uint16_t* jprev;           // ICP: last iteration's match per beam
     uint32_t* good;            // ICP: bit j set = reference ray j is usable (ref_bad == 0); ref_bad is null there
     uint32_t* pair_mask;       // ICP: bit i set = beams i-1,i form a valid pair; pair_ok is null there
+    uint32_t* new_mask;        // PSM (compact layout): bit i set = projected reading i is valid; new_bad is null there
 };
 
 // flags live either in byte arrays (PSM layout) or in bit masks (ICP layout, where LDS is scarce)
 __device__ __forceinline__ bool ref_is_bad(const Lds& L, int i)
 {
     return L.ref_bad ? L.ref_bad[i] != 0 : ((L.good[i >> 5] >> (i & 31)) & 1u) == 0;
+}
+__device__ __forceinline__ bool new_is_bad(const Lds& L, int i)
+{
+    return L.new_bad ? L.new_bad[i] != 0 : ((L.new_mask[i >> 5] >> (i & 31)) & 1u) == 0;
 }
 __device__ __forceinline__ bool pair_is_ok(const Lds& L, int i)
 {

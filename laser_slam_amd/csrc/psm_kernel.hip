@@ -10,12 +10,14 @@
 //   translation estimation (:1015-1131): per-beam terms in parallel, six ordered sums in
 //     six lanes.
 //
-// LDS (Np = N rounded up to 64; 35 Np bytes + 64):
-//   [ 0, 4) ref_r   [ 4, 8) act_r   [ 8,24) projection scratch (pr, pf, u64 keys)
-//                                     -> NaN-masked rows for the orientation search
-//                                     -> translation terms 0..3
-//   [24,28) new_r -> |dr| term   [28,32) err[2W+1] -> term 4
-//   [32,33) ref_bad  [33,34) pair_ok  [34,35) new_bad
+// LDS of psm_kernel (Np = N rounded up to 64; 28 Np bytes + 64 + bit masks = 31.0 KiB at N = 1081
+// -> 5 pairs per CU; the stand-alone stage kernels keep the 35 Np byte-flag layout of carve_psm):
+//   [ 0, 4) ref_r   [ 4,20) projection scratch (pr, pf, u64 keys)
+//                           -> NaN-masked rows for the orientation search
+//                           -> translation terms 0..3
+//   [20,24) new_r -> |dr| term   [24,28) err[2W+1] -> term 4
+//   broadcast slots (64 B), validity masks of the orientation search, then one bit per beam for
+//   ref_bad / pair_ok / new_bad.  The current scan's ranges are read from HBM/L2.
 
 constexpr int PSM_THREADS = 256;
 
@@ -23,10 +25,31 @@ constexpr int PSM_THREADS = 256;
 // (2 Np / 32 + 4 words; the window satisfies 2W + 1 <= Np)
 __host__ __device__ inline int psm_mask_words_new(int Np) { return Np / 32 + 1; }
 __host__ __device__ inline int psm_mask_words_ref(int Np) { return 2 * Np / 32 + 4; }
-__host__ __device__ inline int psm_lds_bytes(int n)
+__host__ __device__ inline int psm_scratch_bytes(int Np) { return 64 + 4 * ((psm_mask_words_new(Np) + psm_mask_words_ref(Np) + 3) & ~3); }
+// byte-flag layout (carve_psm): stage / projection / error-index kernels
+__host__ __device__ inline int psm_lds_bytes(int n) { int Np = (n + 63) & ~63; return 35 * Np + psm_scratch_bytes(Np); }
+// compact layout of psm_kernel
+__host__ __device__ inline int psm_flag_mask_bytes(int Np) { return (Np / 8 + 8 + 15) & ~15; }
+__host__ __device__ inline int psm_compact_lds_bytes(int n)
 {
     int Np = (n + 63) & ~63;
-    return 35 * Np + 64 + 4 * ((psm_mask_words_new(Np) + psm_mask_words_ref(Np) + 3) & ~3);
+    return 28 * Np + psm_scratch_bytes(Np) + 3 * psm_flag_mask_bytes(Np);
+}
+__device__ __forceinline__ Lds carve_psm_compact(char* base, int Np, float*& bc)
+{
+    Lds L = {};
+    L.ref_r = (float*)base;
+    L.pr = (float*)(base + 4 * Np);
+    L.pf = (float*)(base + 8 * Np);
+    L.key = (unsigned long long*)(base + 12 * Np);
+    L.new_r = (float*)(base + 20 * Np);
+    L.err = (float*)(base + 24 * Np);
+    bc = (float*)(base + 28 * Np);
+    char* m = base + 28 * Np + psm_scratch_bytes(Np);
+    L.good = (uint32_t*)m;
+    L.pair_mask = (uint32_t*)(m + psm_flag_mask_bytes(Np));
+    L.new_mask = (uint32_t*)(m + 2 * psm_flag_mask_bytes(Np));
+    return L;                       // act_r, ref_bad, pair_ok, new_bad stay null: HBM / bit masks
 }
 
 // NaN-masked rows: nrm[i] = new_r or NaN; rfm[W + j] = ref_r[j] or NaN, NaN outside [0,N); and the
@@ -40,7 +63,7 @@ __device__ __forceinline__ void build_masked_rows(const DevParam& P, const Lds& 
     const float qnan = u2f(0x7fc00000u);
     const bool lane0 = lane_id() == 0;
     for (int i = threadIdx.x; i < Np; i += blockDim.x) {
-        const bool ok = i < N && L.new_bad[i] == 0;
+        const bool ok = i < N && !new_is_bad(L, i);
         nrm[i] = ok ? L.new_r[i] : qnan;
         const unsigned long long m = __ballot(ok);
         if (lane0) { newm[i >> 5] = (uint32_t)m; newm[(i >> 5) + 1] = (uint32_t)(m >> 32); }
@@ -48,7 +71,7 @@ __device__ __forceinline__ void build_masked_rows(const DevParam& P, const Lds& 
     const int Jp = (N + 2 * W + 4 + 63) & ~63;                 // <= 2 Np + 64 <= 3 Np floats: pf row + key rows
     for (int j = threadIdx.x; j < Jp; j += blockDim.x) {
         const int src = j - W;
-        const bool ok = src >= 0 && src < N && L.ref_bad[src] == 0;
+        const bool ok = src >= 0 && src < N && !ref_is_bad(L, src);
         rfm[j] = ok ? L.ref_r[src] : qnan;
         const unsigned long long m = __ballot(ok);
         if (lane0) { refm[j >> 5] = (uint32_t)m; refm[(j >> 5) + 1] = (uint32_t)(m >> 32); }
@@ -152,7 +175,7 @@ __device__ int translation_estimation(const DevParam& P, const Lds& L, float C, 
         if (i < N) {
             const float nr = L.new_r[i];
             const float dr = L.ref_r[i] - nr;
-            const bool ok = L.ref_bad[i] == 0 && L.new_bad[i] == 0 && nr < (float)P.max_range &&
+            const bool ok = !ref_is_bad(L, i) && !new_is_bad(L, i) && nr < (float)P.max_range &&
                             nr > LSA_MIN_RANGE && fabsf_(dr) < LSA_MAX_ERROR;          // :1034
             if (ok) {
                 const float w = C / (dr * dr + C);
@@ -195,41 +218,59 @@ __device__ int translation_estimation(const DevParam& P, const Lds& L, float C, 
 
 __device__ __forceinline__ void unpack_projection(const DevParam& P, const Lds& L)
 {
-    for (int i = threadIdx.x; i < P.n; i += blockDim.x) {
-        const unsigned long long k = L.key[i];
-        L.new_r[i] = key_r(k);
-        L.new_bad[i] = (uint8_t)key_bad(k);
+    const int Np = (P.n + 63) & ~63;
+    for (int i = threadIdx.x; i < Np; i += blockDim.x) {
+        const unsigned long long k = i < P.n ? L.key[i] : KEY_INIT;
+        if (i < P.n) L.new_r[i] = key_r(k);
+        if (L.new_bad) { if (i < P.n) L.new_bad[i] = (uint8_t)key_bad(k); }
+        else {
+            const unsigned long long m = __ballot(i < P.n && key_bad(k) == 0);
+            if (lane_id() == 0) { L.new_mask[i >> 5] = (uint32_t)m; L.new_mask[(i >> 5) + 1] = (uint32_t)(m >> 32); }
+        }
     }
     __syncthreads();
 }
 
-__device__ __forceinline__ void load_pair_psm(const DevParam& P, const Lds& L, const float* g_r, const uint8_t* g_bad,
+__device__ __forceinline__ void load_pair_psm(const DevParam& P, Lds& L, const float* g_r, const uint8_t* g_bad,
                                               const uint16_t* g_seg, size_t ro, size_t ao)
 {
-    const int N = P.n;
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
-        L.ref_r[i] = g_r[ro + i];
-        L.ref_bad[i] = g_bad[ro + i];
-        L.act_r[i] = g_r[ao + i];
-        uint8_t ok = 0;
-        if (i >= 1) {
-            uint16_t s1 = g_seg[ao + i], s0 = g_seg[ao + i - 1];
-            ok = (s1 != 0 && s1 == s0 && g_bad[ao + i] == 0 && g_bad[ao + i - 1] == 0) ? 1 : 0;   // :1396
+    const int N = P.n, Np = (N + 63) & ~63;
+    L.g_act_r = g_r + ao;
+    for (int i = threadIdx.x; i < Np; i += blockDim.x) {
+        bool good = false, ok = false;
+        if (i < N) {
+            L.ref_r[i] = g_r[ro + i];
+            good = g_bad[ro + i] == 0;
+            if (i >= 1) {
+                uint16_t s1 = g_seg[ao + i], s0 = g_seg[ao + i - 1];
+                ok = s1 != 0 && s1 == s0 && g_bad[ao + i] == 0 && g_bad[ao + i - 1] == 0;     // :1396
+            }
         }
-        L.pair_ok[i] = ok;
+        const unsigned long long gm = __ballot(good), pm = __ballot(ok);
+        if (lane_id() == 0) {
+            L.good[i >> 5] = (uint32_t)gm; L.good[(i >> 5) + 1] = (uint32_t)(gm >> 32);
+            L.pair_mask[i >> 5] = (uint32_t)pm; L.pair_mask[(i >> 5) + 1] = (uint32_t)(pm >> 32);
+        }
     }
 }
 
-__global__ __launch_bounds__(PSM_THREADS, 4) void psm_kernel(
-    DevParam P, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
+#ifndef LSA_PSM_WG_PER_CU
+#define LSA_PSM_WG_PER_CU 5
+#endif
+// NC > 0: the beam count as a compile-time constant (see icp_kernel)
+template <int NC>
+__global__ __launch_bounds__(PSM_THREADS, LSA_PSM_WG_PER_CU) void psm_kernel(
+    DevParam P_, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
     const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
     const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
     float* __restrict__ err_xy, int* __restrict__ n_assoc, int* __restrict__ status_out, int* __restrict__ iters_out)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevParam P = P_;
+    if (NC > 0) P.n = NC;
     const int N = P.n, Np = (N + 63) & ~63, tid = threadIdx.x;
-    const Lds L = carve_psm(smem, Np);
-    float* bc = (float*)(smem + 35 * Np);
+    float* bc;
+    Lds L = carve_psm_compact(smem, Np, bc);
 
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const size_t ro = (size_t)ref_idx[b] * N, ao = (size_t)act_idx[b] * N;

@@ -18,8 +18,9 @@ B = 32768
 idx = np.arange(B) % (S - 1); idx = np.where(idx % 200 == 199, idx - 1, idx)
 ri = torch.from_numpy(idx.astype(np.int32)).cuda(); ai = ri + 1
 pose = torch.zeros(B, 3, device="cuda"); it = torch.zeros(B, dtype=torch.int32, device="cuda"); torch.cuda.synchronize()
-ctx.match_batch(1, B, d_r, d_bad, d_seg, ri, ai, pose, d_iters=it); ctx.sync()
+W = int(os.environ.get("LSA_WHICH", "1"))
+ctx.match_batch(W, B, d_r, d_bad, d_seg, ri, ai, pose, d_iters=it); ctx.sync()
 t0 = time.perf_counter()
-for _ in range(3): ctx.match_batch(1, B, d_r, d_bad, d_seg, ri, ai, pose)
+for _ in range(3): ctx.match_batch(W, B, d_r, d_bad, d_seg, ri, ai, pose)
 ctx.sync(); dt = (time.perf_counter() - t0) / 3
 print("%s 541 beams: %.0f matches/s, mean iterations %.1f" % (os.path.basename(sys.argv[1]), B / dt, float(it.float().mean())))
