@@ -166,7 +166,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "%s_kernel" % args.matcher, "kernel_ms": kernel_ms,
                          "bytes_per_pair": BYTES_PER_PAIR,
-                         "note": "the matcher is instruction-issue/LDS-latency bound, not HBM bound (DESIGN.md 4.1); "
+                         "note": "the matcher is vector-instruction-issue bound, not HBM bound (DESIGN.md 4.1; valu_busy_frac); "
                                  "effective_fp32_frac prices the REFERENCE algorithm's arithmetic (brute-force window "
                                  "search) at this rate against the fp32 vector peak - the kernel prunes that search "
                                  "exactly, so these are not executed flops",
@@ -175,6 +175,7 @@ def main():
         }
         out["secondary"] = secondary(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, which)
         out["roofline"]["traffic"] = pmc_traffic(args.matcher, B)
+        out["roofline"]["valu_busy_frac"] = pmc_valu_busy(args.matcher)
         if args.extras:
             out["extras"] = extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p)
         if not args.no_cpu:
@@ -208,6 +209,19 @@ def pmc_traffic(matcher, B):
         rec = json.load(open(path))["lsa::%s_kernel" % matcher]
         per_pair = (2.0 * rec["FETCH_SIZE_KB_per_launch"] + rec["WRITE_SIZE_KB_per_launch"]) * 1024.0 / rec.get("pairs_per_launch", 32768)
         return per_pair * B
+    except Exception:
+        return None
+
+
+def pmc_valu_busy(matcher):
+    """Share of the SIMDs' issue slots the dominant kernel keeps busy with vector instructions, from the
+    committed SQ counter pass (profiles/r01_pmc_sq_counters.json): SQ_ACTIVE_INST_VALU (quad-cycles) over
+    GRBM_GUI_ACTIVE / 8 XCDs / 4 cycles x 1024 SIMDs.  This, not HBM, is the resource the matcher runs
+    against.  None when the profile file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_sq_counters.json")
+    try:
+        rec = json.load(open(path))["lsa::%s_kernel" % matcher]
+        return rec["SQ_ACTIVE_INST_VALU"] / (rec["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0)
     except Exception:
         return None
 
