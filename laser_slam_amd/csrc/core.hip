@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <climits>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -587,6 +589,13 @@ struct lsa_grid {
     // staging for lsa_grid_update_host
     float* d_pts = nullptr;
     int pts_cap = 0;
+    // scratch of the owned-tile batch update: end cells, per-scan info, batch bounding box
+    int2* d_ends = nullptr;
+    lsa::ScanInfo* d_info = nullptr;
+    int4* d_blk = nullptr;
+    size_t blk_cap = 0;
+    int* d_bbox = nullptr;
+    size_t ends_cap = 0, info_cap = 0;
     size_t cells = 0;
 };
 
@@ -618,7 +627,7 @@ void lsa_grid_destroy(lsa_grid* g)
     if (!g) return;
     hipSetDevice(g->c->device);
     hipStreamSynchronize(g->c->stream);
-    hipFree(g->d_hit); hipFree(g->d_sum); hipFree(g->d_prob); hipFree(g->d_tmp); hipFree(g->d_rows); hipFree(g->d_pts);
+    hipFree(g->d_hit); hipFree(g->d_sum); hipFree(g->d_prob); hipFree(g->d_tmp); hipFree(g->d_rows); hipFree(g->d_pts); hipFree(g->d_ends); hipFree(g->d_info); hipFree(g->d_blk); hipFree(g->d_bbox);
     delete g;
 }
 
@@ -645,6 +654,43 @@ int lsa_grid_update_batch(lsa_grid* g, int S, int n_beams, const float* d_gx, co
     if (!g || !d_gx || !d_gy || !d_robot_xy) return fail(LSA_E_ARG, "null argument");
     if (S <= 0 || n_beams <= 0) return LSA_OK;
     HIP_TRY(hipSetDevice(g->c->device));
+    // Batches: tile ownership (no global atomics).  LSA_GRID_PATH=scan forces the per-scan kernels.
+    const char* path_env = getenv("LSA_GRID_PATH");
+    const char* splits_env = getenv("LSA_GRID_SPLITS");
+    if (S >= 8 && n_beams <= 4096 && !(path_env && !strcmp(path_env, "scan"))) {      // (one lane per 64-beam block)
+        const size_t need = (size_t)S * n_beams;
+        if (g->ends_cap < need) {
+            if (g->d_ends) HIP_TRY(hipFree(g->d_ends));
+            g->d_ends = nullptr; g->ends_cap = 0;
+            HIP_TRY(hipMalloc((void**)&g->d_ends, need * sizeof(int2)));
+            g->ends_cap = need;
+        }
+        if (g->info_cap < (size_t)S) {
+            if (g->d_info) HIP_TRY(hipFree(g->d_info));
+            g->d_info = nullptr; g->info_cap = 0;
+            HIP_TRY(hipMalloc((void**)&g->d_info, (size_t)S * sizeof(lsa::ScanInfo)));
+            g->info_cap = (size_t)S;
+        }
+        const size_t nblk = ((size_t)n_beams + 63) / 64;
+        if (g->blk_cap < (size_t)S * nblk) {
+            if (g->d_blk) HIP_TRY(hipFree(g->d_blk));
+            g->d_blk = nullptr; g->blk_cap = 0;
+            HIP_TRY(hipMalloc((void**)&g->d_blk, (size_t)S * nblk * sizeof(int4)));
+            g->blk_cap = (size_t)S * nblk;
+        }
+        if (!g->d_bbox) HIP_TRY(hipMalloc((void**)&g->d_bbox, 4 * sizeof(int)));
+        static const int bbox0[4] = {INT_MAX, INT_MAX, INT_MIN, INT_MIN};
+        HIP_TRY(hipMemcpyAsync(g->d_bbox, bbox0, sizeof bbox0, hipMemcpyHostToDevice, g->c->stream));
+        hipLaunchKernelGGL(lsa::grid_prep_kernel, dim3(S < 8192 ? S : 8192), dim3(256), 0, g->c->stream, g->G, S, n_beams,
+                           d_gx, d_gy, d_robot_xy, d_n_valid, g->d_ends, g->d_info, g->d_blk, g->d_bbox);
+        // scans per tile are divided among several workgroups when the batch covers few tiles (decided on the
+        // device from the batch's bounding box; LSA_GRID_SPLITS overrides)
+        const int splits = splits_env ? atoi(splits_env) : 0;
+        hipLaunchKernelGGL(lsa::grid_owned_kernel, dim3(1536), dim3(256), 0, g->c->stream, g->G, S, n_beams,
+                           g->d_ends, g->d_info, g->d_blk, g->d_bbox, splits, g->d_hit, g->d_sum);
+        HIP_TRY(hipGetLastError());
+        return LSA_OK;
+    }
     if (n_beams < 65536)    // per-scan increments fit the packed u16 tile counters
         hipLaunchKernelGGL(lsa::grid_update_tile_kernel, dim3(S < 4096 ? S : 4096), dim3(256), 0,
                            g->c->stream, g->G, S, n_beams, d_gx, d_gy, d_robot_xy, d_n_valid, g->d_hit, g->d_sum);

@@ -159,6 +159,241 @@ __global__ __launch_bounds__(256) void grid_update_tile_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batched update with tile ownership (the throughput path): no global atomics at all.
+//
+//   grid_prep_kernel   one workgroup per scan: robot cell, end cell of every beam (stored as
+//                      int2, the double-precision cell arithmetic is done once), the scan's
+//                      cell bounding box and the batch's bounding box.
+//   grid_owned_kernel  one workgroup per 64x64-cell tile of the grid: the tile's two count
+//                      layers live in LDS for the whole batch; the workgroup walks through the
+//                      scans whose bounding box meets the tile and, for every ray that crosses
+//                      it, exactly the part of the reference's Bresenham line inside the tile.
+//                      A standard integer DDA (d0 = 2 dmin - len; a minor step whenever d >= 0)
+//                      has taken floor((2 dmin t + len) / (2 len)) minor steps after t major
+//                      steps, so the walk can start anywhere on the line with the reference's
+//                      exact state.  At the end the tile is added to the layers with plain,
+//                      row-contiguous read-modify-writes - the tile is nobody else's.
+//                      All rays of a scan meet in the robot cell (hundreds of increments of one
+//                      address): that cell is skipped by the walks and receives its totals once
+//                      per wave.  With `splits` > 1 the scans are divided among several
+//                      workgroups per tile (more parallelism when the batch covers few tiles)
+//                      and the flush uses atomic adds instead.
+// Counts are additive and integer, so the result equals the sequential update bit for bit.
+struct ScanInfo { int sx, sy, xmin, xmax, ymin, ymax, nb, nh, s, pad; };   // nh: rays whose last generated cell is the robot cell
+
+constexpr int OWN_T = 64;               // cells per owned tile side (2 x 16 KiB of LDS)
+constexpr int OWN_CHUNK = 256;          // scans looked at per culling round
+
+__global__ __launch_bounds__(256) void grid_prep_kernel(
+    GridParam G, int S, int n_beams, const float* __restrict__ gx, const float* __restrict__ gy,
+    const float* __restrict__ robot_xy, const int* __restrict__ n_valid,
+    int2* __restrict__ ends, ScanInfo* __restrict__ info, int4* __restrict__ blk /* [S][n_beams/64]: xmin,xmax,ymin,ymax */,
+    int* __restrict__ bbox /* xmin, ymin, xmax, ymax */)
+{
+    __shared__ int red[4][5];
+    const int nblk = (n_beams + 63) >> 6;
+    for (int s = blockIdx.x; s < S; s += gridDim.x) {
+        const int sx = grid_cell1(robot_xy[2 * s], G.off_x, G.center_x, G.res);
+        const int sy = grid_cell1(robot_xy[2 * s + 1], G.off_y, G.center_y, G.res);
+        const int nb = n_valid ? n_valid[s] : n_beams;
+        int x0 = sx, x1 = sx, y0 = sy, y1 = sy, nh = 0;
+        for (int i = threadIdx.x; i < nblk * 64; i += blockDim.x) {
+            const size_t t = (size_t)s * n_beams + i;
+            int ex = sx, ey = sy;
+            if (i < nb) {
+                ex = grid_cell1(gx[t], G.off_x, G.center_x, G.res);
+                ey = grid_cell1(gy[t], G.off_y, G.center_y, G.res);
+                ends[t] = make_int2(ex, ey);
+            }
+            {   // bounding box of this wave's 64 consecutive rays (all of them start in the robot cell)
+                int a0 = ex < sx ? ex : sx, a1 = ex > sx ? ex : sx, c0 = ey < sy ? ey : sy, c1 = ey > sy ? ey : sy;
+                for (int o = 32; o; o >>= 1) {
+                    const int p0 = __shfl_xor(a0, o), p1 = __shfl_xor(a1, o), q0 = __shfl_xor(c0, o), q1 = __shfl_xor(c1, o);
+                    a0 = p0 < a0 ? p0 : a0; a1 = p1 > a1 ? p1 : a1; c0 = q0 < c0 ? q0 : c0; c1 = q1 > c1 ? q1 : c1;
+                }
+                if ((threadIdx.x & 63) == 0) blk[(size_t)s * nblk + (i >> 6)] = make_int4(a0, a1, c0, c1);
+            }
+            if (i >= nb) continue;
+            x0 = ex < x0 ? ex : x0; x1 = ex > x1 ? ex : x1;
+            y0 = ey < y0 ? ey : y0; y1 = ey > y1 ? ey : y1;
+            // the robot cell is the last generated cell when the line comes from the beam's end
+            // (the end has the smaller major coordinate, line.cpp:17-27, 61-70) or is a single cell
+            const int dx = abs(ex - sx), dy = abs(ey - sy);
+            const bool from_end = dy <= dx ? sx > ex : sy > ey;
+            nh += (from_end || (dx == 0 && dy == 0)) ? 1 : 0;
+        }
+        for (int o = 32; o; o >>= 1) {
+            const int a = __shfl_xor(x0, o), b = __shfl_xor(x1, o), c = __shfl_xor(y0, o), d = __shfl_xor(y1, o);
+            x0 = a < x0 ? a : x0; x1 = b > x1 ? b : x1; y0 = c < y0 ? c : y0; y1 = d > y1 ? d : y1;
+            nh += __shfl_xor(nh, o);
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { int w = threadIdx.x >> 6; red[w][0] = x0; red[w][1] = x1; red[w][2] = y0; red[w][3] = y1; red[w][4] = nh; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) {
+                x0 = red[w][0] < x0 ? red[w][0] : x0; x1 = red[w][1] > x1 ? red[w][1] : x1;
+                y0 = red[w][2] < y0 ? red[w][2] : y0; y1 = red[w][3] > y1 ? red[w][3] : y1;
+                nh += red[w][4];
+            }
+            ScanInfo si; si.sx = sx; si.sy = sy; si.xmin = x0; si.xmax = x1; si.ymin = y0; si.ymax = y1;
+            si.nb = nb > 0 ? nb : 0; si.nh = nh; si.s = s; si.pad = 0;
+            info[s] = si;
+            atomicMin(&bbox[0], x0); atomicMin(&bbox[1], y0); atomicMax(&bbox[2], x1); atomicMax(&bbox[3], y1);
+        }
+    }
+}
+
+// The part of one ray inside the tile [X0, X0+T) x [Y0, Y0+T); the robot cell (sx, sy) is left out when `rin`.
+// `inside`: the whole tile lies in the grid (no per-cell bounds test).  (Neighbouring beams add to the
+// same LDS cells; starting every lane's walk at a different place of its range was measured: the
+// second closed-form start costs more than the serialised adds.)
+__device__ __forceinline__ void own_walk(const GridParam& G, uint32_t* lh, uint32_t* ls, int X0, int Y0, bool inside,
+                                         int sx, int sy, bool rin, int ex, int ey)
+{
+    const int X1 = X0 + OWN_T - 1, Y1 = Y0 + OWN_T - 1;
+    if (ex >= X0 && ex <= X1 && ey >= Y0 && ey <= Y1 && inb(G, ex, ey))                  // :72-75
+        atomicAdd(&lh[(ex - X0) * OWN_T + (ey - Y0)], 1u);
+    const int dx = abs(ex - sx), dy = abs(ey - sy);
+    const bool x_major = dy <= dx;
+    const bool from_end = x_major ? sx > ex : sy > ey;
+    const int len = x_major ? dx : dy, dmin = x_major ? dy : dx;
+    const int m0 = x_major ? (from_end ? ex : sx) : (from_end ? ey : sy);                  // major / minor of the first cell
+    const int n0 = x_major ? (from_end ? ey : sy) : (from_end ? ex : sx);
+    const int mstep = ((x_major ? ey - sy : ex - sx) * (from_end ? -1 : 1)) > 0 ? 1 : -1;
+    const int M0 = x_major ? X0 : Y0, N0 = x_major ? Y0 : X0;
+    const int t_lo = M0 - m0 > 0 ? M0 - m0 : 0;
+    const int t_hi = M0 + OWN_T - 1 - m0 < len ? M0 + OWN_T - 1 - m0 : len;
+    if (t_lo > t_hi) return;
+    const int robot_cc = rin ? (sx - X0) * OWN_T + (sy - Y0) : -1;
+    const int c_major = x_major ? OWN_T : 1, c_minor = x_major ? mstep : mstep * OWN_T;   // cell index steps
+    const int inc_keep = 2 * dmin, inc_step = 2 * (dmin - len);
+    int t = t_lo;
+    int steps = 0;                                                                       // minor steps taken before cell t
+    if (len > 0) {
+        if (len < 32768) steps = (int)((2u * (unsigned)dmin * (unsigned)t + (unsigned)len) / (2u * (unsigned)len));   // t <= len
+        else steps = (int)((2ll * dmin * t + len) / (2ll * len));
+    }
+    int minor = n0 + mstep * steps;
+    int d = (int)(2ll * dmin * (t + 1) - len - 2ll * len * steps);                      // |d| <= 2 len
+    int cc = x_major ? (m0 + t - X0) * OWN_T + (minor - Y0) : (minor - X0) * OWN_T + (m0 + t - Y0);
+    for (; t <= t_hi; ++t) {
+        bool ok = (unsigned)(minor - N0) < (unsigned)OWN_T && cc != robot_cc;
+        if (!inside) ok = ok && inb(G, x_major ? m0 + t : minor, x_major ? minor : m0 + t);
+        if (ok) {
+            atomicAdd(&ls[cc], 1u);                                                      // :87
+            if (t == len) atomicAdd(&lh[cc], 1u);                                        // last generated cell, :84-86
+        }
+        cc += c_major;
+        if (d < 0) d += inc_keep; else { minor += mstep; cc += c_minor; d += inc_step; }
+    }
+}
+
+__global__ __launch_bounds__(256) void grid_owned_kernel(
+    GridParam G, int S, int n_beams, const int2* __restrict__ ends, const ScanInfo* __restrict__ info,
+    const int4* __restrict__ blk, const int* __restrict__ bbox, int splits_req, uint32_t* __restrict__ hit, uint32_t* __restrict__ sum)
+{
+    __shared__ uint32_t lh[OWN_T * OWN_T], ls[OWN_T * OWN_T];
+    __shared__ ScanInfo cand[OWN_CHUNK];
+    __shared__ int ncand;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // work items = (tile of the batch's bounding box, share of the scans); the launch is a fixed number of
+    // workgroups that stride over them (launching one workgroup per tile of a 4096^2 grid costs more
+    // than the update itself when the batch covers a few dozen tiles)
+    const int bx0 = (bbox[0] > 0 ? bbox[0] : 0) / OWN_T, by0 = (bbox[1] > 0 ? bbox[1] : 0) / OWN_T;
+    const int bx1 = (bbox[2] < G.size_x - 1 ? bbox[2] : G.size_x - 1) / OWN_T, by1 = (bbox[3] < G.size_y - 1 ? bbox[3] : G.size_y - 1) / OWN_T;
+    if (bbox[2] < 0 || bbox[3] < 0 || bbox[0] >= G.size_x || bbox[1] >= G.size_y || bx1 < bx0 || by1 < by0) return;
+    const int ntx = bx1 - bx0 + 1, nty = by1 - by0 + 1, nt = ntx * nty;
+    int splits = splits_req;
+    if (splits <= 0) {                      // about 32 scans per item (measured: 2048 scans, 64-128 shares per tile)
+        splits = S / 32;
+        if (splits > 128) splits = 128;
+        if (splits < 1) splits = 1;
+    }
+    if (splits > S) splits = S;
+    for (int item = blockIdx.x; item < nt * splits; item += gridDim.x) {
+    const int tile = item % nt, part = item / nt;
+    const int X0 = (bx0 + tile / nty) * OWN_T, Y0 = (by0 + tile % nty) * OWN_T;
+    const int X1 = X0 + OWN_T - 1, Y1 = Y0 + OWN_T - 1;
+    const bool inside = X1 < G.size_x && Y1 < G.size_y;          // (X0, Y0 >= 0 by construction)
+    __syncthreads();
+    for (int k = tid; k < OWN_T * OWN_T; k += blockDim.x) { lh[k] = 0; ls[k] = 0; }
+    const int s_lo = (int)((long long)S * part / splits), s_hi = (int)((long long)S * (part + 1) / splits);
+    bool touched = false;
+    for (int c0 = s_lo; c0 < s_hi; c0 += OWN_CHUNK) {
+        __syncthreads();
+        if (tid == 0) ncand = 0;
+        __syncthreads();
+        // culling round: the scans of this chunk whose bounding box meets the tile
+        {
+            const int s = c0 + tid;
+            ScanInfo si = {};
+            bool ov = false;
+            if (s < s_hi) {
+                si = info[s];
+                ov = !(si.xmax < X0 || si.xmin > X1 || si.ymax < Y0 || si.ymin > Y1);
+            }
+            const unsigned long long m = __ballot(ov);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(&ncand, __popcll(m));
+            base = __shfl(base, 0);
+            if (ov) {
+                cand[base + prefix_popc(m)] = si;
+                // all rays of a scan meet in its robot cell: that cell gets its totals here, the walks skip it
+                if (si.sx >= X0 && si.sx <= X1 && si.sy >= Y0 && si.sy <= Y1 && inb(G, si.sx, si.sy)) {
+                    const int cc = (si.sx - X0) * OWN_T + (si.sy - Y0);
+                    if (si.nb) atomicAdd(&ls[cc], (uint32_t)si.nb);
+                    if (si.nh) atomicAdd(&lh[cc], (uint32_t)si.nh);
+                }
+            }
+        }
+        __syncthreads();
+        const int nc = ncand;
+        if (nc) touched = true;
+        // Each wave takes candidate scans on its own.  A scan's rays come in blocks of 64 consecutive beams
+        // with their own bounding boxes (grid_prep_kernel): the lanes test one block each, and only the
+        // blocks that meet the tile are walked, 64 rays at a time; the next block's end cells are in flight
+        // while the current block is walked.
+        const int wave = tid >> 6, nblk = (n_beams + 63) >> 6;
+        for (int q = wave; q < nc; q += 4) {
+            const int s = cand[q].s, sx = cand[q].sx, sy = cand[q].sy, nb = cand[q].nb;
+            const bool rin = sx >= X0 && sx <= X1 && sy >= Y0 && sy <= Y1;
+            bool ov = false;
+            if (lane < nblk) {
+                const int4 bb = blk[(size_t)s * nblk + lane];
+                ov = !(bb.y < X0 || bb.x > X1 || bb.w < Y0 || bb.z > Y1);
+            }
+            unsigned long long m = __ballot(ov);
+            if (!m) continue;
+            int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            int2 e = 64 * b + lane < nb ? ends[(size_t)s * n_beams + 64 * b + lane] : make_int2(0, 0);
+            while (true) {
+                const int bn = m ? __ffsll((long long)m) - 1 : -1;
+                m &= m - 1;
+                int2 en = make_int2(0, 0);
+                if (bn >= 0 && 64 * bn + lane < nb) en = ends[(size_t)s * n_beams + 64 * bn + lane];
+                if (64 * b + lane < nb) own_walk(G, lh, ls, X0, Y0, inside, sx, sy, rin, e.x, e.y);
+                if (bn < 0) break;
+                b = bn; e = en;
+            }
+        }
+    }
+    __syncthreads();
+    if (!touched) continue;
+    // flush: consecutive lanes -> consecutive y of one x row (contiguous in the [x][y] layers)
+    for (int k = tid; k < OWN_T * OWN_T; k += blockDim.x) {
+        const int x = X0 + k / OWN_T, y = Y0 + k % OWN_T;
+        if (!inb(G, x, y)) continue;
+        const uint32_t vh = lh[k], vs = ls[k];
+        const size_t c = (size_t)x * G.size_y + y;
+        if (splits == 1) { if (vh) hit[c] += vh; if (vs) sum[c] += vs; }
+        else { if (vh) atomicAdd(&hit[c], vh); if (vs) atomicAdd(&sum[c], vs); }
+    }
+    }
+}
+
 // computeProbsOfMap: prob = hit / (double) sum clipped to 1, unseen cells 0.3.
 // Counts are converted to float first (the reference stores them as float).
 __global__ __launch_bounds__(256) void grid_prob_kernel(

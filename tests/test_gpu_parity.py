@@ -396,6 +396,18 @@ def test_full_size_grid_checksum(torch_mod):
     hit1, sum1 = g1.download(0), g1.download(1)
     hit2, sum2 = g2.download(0), g2.download(1)
     assert np.array_equal(hit1, hit2) and np.array_equal(sum1, sum2)
+    # the per-scan kernels (global atomics) and the owned-tile batch path (none) must agree,
+    # whatever the number of workgroups per tile
+    for env in ({"LSA_GRID_PATH": "scan"}, {"LSA_GRID_SPLITS": "1"}, {"LSA_GRID_SPLITS": "5"}):
+        os.environ.update(env)
+        try:
+            g3 = capi.Grid(ctx, 4096, 4096, 1024, 1024, 0.0, 0.0, 0.05)
+            g3.update_batch(nb, 1081, dgx, dgy, drob)
+            assert np.array_equal(g3.download(0), hit1) and np.array_equal(g3.download(1), sum1), env
+            g3.close()
+        finally:
+            for k in env:
+                del os.environ[k]
     assert hit1.sum(dtype=np.float64) == 2.0 * nb * 1081          # the map is large enough for every ray
     # visits: one per traversed cell = max(|dx|,|dy|)+1 per ray (cells from the grid's own cell function)
     cx = np.array([[g1.cell(float(gx[s, i]), float(gy[s, i])) for i in range(0, 1081, 40)] for s in range(0, nb, 64)])

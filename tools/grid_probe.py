@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Diagnostic: grid-update throughput (2048 synthetic 1081-beam scans into a 4096^2 grid) of a prebuilt variant."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from laser_slam_amd import capi, synth
+capi.LIB_PATH = os.path.abspath(sys.argv[1])
+import torch
+raw, _ = synth.make_scans(256)
+p = capi.param_make(**synth.SYN1081)
+fi = capi.param_tables(p)[0]
+nb = 2048
+poses = synth.path_pose(np.arange(nb))
+rr = np.concatenate([raw] * 8)[:nb] / 100.0
+gx = (poses[:, 0:1] + rr * np.cos(poses[:, 2:3] + fi[None])).astype(np.float32)
+gy = (poses[:, 1:2] + rr * np.sin(poses[:, 2:3] + fi[None])).astype(np.float32)
+ctx = capi.Context(p)
+g = capi.Grid(ctx, 4096, 4096, 1024, 1024, 0.0, 0.0, 0.05)
+dgx = torch.from_numpy(gx).cuda(); dgy = torch.from_numpy(gy).cuda(); drob = torch.from_numpy(poses[:, :2].astype(np.float32)).cuda()
+torch.cuda.synchronize()
+g.update_batch(nb, 1081, dgx, dgy, drob); ctx.sync()
+t0 = time.perf_counter()
+for _ in range(3): g.update_batch(nb, 1081, dgx, dgy, drob)
+ctx.sync(); dt = (time.perf_counter() - t0) / 3
+print("%s splits=%s: %.0f scans/s (%.2f ms per 2048 scans)" % (os.path.basename(sys.argv[1]), os.environ.get("LSA_GRID_SPLITS", "auto"), nb / dt, dt * 1e3))
