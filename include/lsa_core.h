@@ -229,6 +229,29 @@ int lsa_pf_weights(lsa_ctx* c, const float* d_score, int n, float max_score, flo
 int lsa_pf_resample(lsa_ctx* c, const float* d_w, int n, double u0, int n_total, int first, int M,
                     int32_t* d_parent);
 int lsa_gather_poses(lsa_ctx* c, const float* d_src, const int32_t* d_parent, int M, float* d_dst);
+/* threadLocalization::topK (localization.cpp:126-149): the k largest scores in descending order,
+ * equal scores in index order; h_score may be NULL */
+int lsa_pose_topk(lsa_ctx* c, const float* d_score, int n, int k, int32_t* h_index, float* h_score);
+/* CParticles::weightMean + meanDis over the k best particles (particles.cpp:231-281): weighted
+ * mean pose, mean weight ("goodness") and mean squared pairwise distance; h_index (k) may be NULL */
+int lsa_pf_estimate(lsa_ctx* c, const float* d_poses, const float* d_score, int n, int k,
+                    double h_mean_pose[3], double* h_mean_weight, double* h_mean_dis, int32_t* h_index);
+/* CParticles::predict (particles.cpp:119-153): particle i = mean pose + sigma * normal_i per state;
+ * d_normals [n][3] standard normal draws (the reference's Boost generator is not reproducible) */
+int lsa_pf_predict(lsa_ctx* c, int n, const double mean_pose[3], const double sigma[3], const float* d_normals,
+                   float* d_poses);
+/* SIR_scheme::roughen_minmax (src/sensorFusion/SIRFlt.cpp:359-413): state += normal * (max - min) * K n^(-1/3) */
+int lsa_pf_roughen(lsa_ctx* c, int n, double K, const float* d_normals, float* d_poses);
+/* CVPmap::laserScanSimulator / simulateScanRay (src/localization/VPmap.cpp:180-303): virtual scans of
+ * n_poses poses [x, y, theta] in the probability map d_prob ([x][y], geometry of `f`); ranges [m],
+ * bad = ray left the map / ran into unknown space / exceeded max_range.  Defaults of the reference:
+ * fov 4.712388981, min_angle 3 * -0.7853981635, max_range 30 (VPmap.h:12-31) */
+int lsa_simulate_scans(lsa_field* f, const float* d_prob, const float* d_poses, int n_poses, int n_beams,
+                       float fov, float min_angle, float max_range, float* d_ranges, uint8_t* d_bad);
+/* CVPmap::obsLikelyhood2 (VPmap.cpp:454-483): beam-model score of every pose against one observed scan */
+int lsa_beam_model_scores(lsa_field* f, const float* d_prob, const float* d_poses, int n_poses, const float* d_obs_r,
+                          const uint8_t* d_obs_bad, int n_beams, float fov, float min_angle, float max_range,
+                          float* d_score);
 
 /* ---- point-to-point ICP on 2D point clouds: CICPWarpper, src/zhicp/ZHIcp_Warpper.{h,cpp}
  *      (forwards to MRPT 0.9.6 CICP::Align, icpClassic — third-party, PARITY UNPINNED) ---- */

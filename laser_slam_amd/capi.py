@@ -99,6 +99,12 @@ def lib():
     L.lsa_pose_argmax.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     L.lsa_pf_weights.argtypes = [vp, vp, C.c_int, C.c_float, vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.lsa_pf_resample.argtypes = [vp, vp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, vp]
+    L.lsa_pose_topk.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+    L.lsa_pf_estimate.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
+    L.lsa_pf_predict.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.lsa_pf_roughen.argtypes = [vp, C.c_int, C.c_double, vp, vp]
+    L.lsa_simulate_scans.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp]
+    L.lsa_beam_model_scores.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, vp]
     L.lsa_gather_poses.argtypes = [vp, vp, vp, C.c_int, vp]
     L.lsa_p2p_icp_host.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp]
     L.lsa_p2p_icp_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
@@ -396,6 +402,51 @@ def pf_weights(ctx, d_score, P, max_score, d_w):
     s, s2 = C.c_double(0), C.c_double(0)
     check(lib().lsa_pf_weights(ctx.h, _dp(d_score), P, max_score, _dp(d_w), C.byref(s), C.byref(s2)), "lsa_pf_weights")
     return s.value, s2.value
+
+
+# defaults of CVPmap::laserScanSimulator (VPmap.h:12-31)
+SIM_FOV = 4.712388981
+SIM_MIN_ANGLE = 3 * -0.7853981635
+SIM_MAX_RANGE = 30.0
+
+
+def pose_topk(ctx, d_score, n, k):
+    """threadLocalization::topK: indices and scores of the k best, best first."""
+    k = min(k, n)
+    idx = np.zeros(k, np.int32); sc = np.zeros(k, np.float32)
+    check(lib().lsa_pose_topk(ctx.h, _dp(d_score), n, k, _hp(idx), _hp(sc)), "lsa_pose_topk")
+    return idx, sc
+
+
+def pf_estimate(ctx, d_poses, d_score, n, k):
+    """CParticles::weightMean + meanDis over the k best: (mean pose[3], mean weight, mean sq. distance, indices)."""
+    k = min(k, n)
+    mean = np.zeros(3, np.float64); idx = np.zeros(k, np.int32)
+    mw, md = C.c_double(0), C.c_double(0)
+    check(lib().lsa_pf_estimate(ctx.h, _dp(d_poses), _dp(d_score), n, k, _hp(mean), C.byref(mw), C.byref(md), _hp(idx)),
+          "lsa_pf_estimate")
+    return mean, mw.value, md.value, idx
+
+
+def pf_predict(ctx, n, mean_pose, sigma, d_normals, d_poses):
+    m = np.ascontiguousarray(mean_pose, np.float64); sg = np.ascontiguousarray(sigma, np.float64)
+    check(lib().lsa_pf_predict(ctx.h, n, _hp(m), _hp(sg), _dp(d_normals), _dp(d_poses)), "lsa_pf_predict")
+
+
+def pf_roughen(ctx, n, K, d_normals, d_poses):
+    check(lib().lsa_pf_roughen(ctx.h, n, K, _dp(d_normals), _dp(d_poses)), "lsa_pf_roughen")
+
+
+def simulate_scans(field, d_prob, d_poses, P, n_beams, d_ranges, d_bad, fov=SIM_FOV, min_angle=SIM_MIN_ANGLE,
+                   max_range=SIM_MAX_RANGE):
+    check(lib().lsa_simulate_scans(field.h, _dp(d_prob), _dp(d_poses), P, n_beams, fov, min_angle, max_range,
+                                   _dp(d_ranges), _dp(d_bad)), "lsa_simulate_scans")
+
+
+def beam_model_scores(field, d_prob, d_poses, P, d_obs_r, d_obs_bad, n_beams, d_score, fov=SIM_FOV,
+                      min_angle=SIM_MIN_ANGLE, max_range=SIM_MAX_RANGE):
+    check(lib().lsa_beam_model_scores(field.h, _dp(d_prob), _dp(d_poses), P, _dp(d_obs_r), _dp(d_obs_bad), n_beams,
+                                      fov, min_angle, max_range, _dp(d_score)), "lsa_beam_model_scores")
 
 
 def pf_resample(ctx, d_w, P, u0, n_total, first, M, d_parent):

@@ -15,6 +15,7 @@
 #include "match_kernels.hip"
 #include "grid_kernels.hip"
 #include "pose_kernels.hip"
+#include "sim_kernels.hip"
 #include "p2p_kernels.hip"
 
 static thread_local std::string g_err;
@@ -180,7 +181,7 @@ static int ensure_staging(lsa_ctx* c)
     HIP_TRY(hipMalloc((void**)&c->d_bad, 2 * n));
     HIP_TRY(hipMalloc((void**)&c->d_seg, sizeof(uint16_t) * 2 * n));
     HIP_TRY(hipMalloc((void**)&c->d_idx, sizeof(int) * 2));
-    HIP_TRY(hipMalloc((void**)&c->d_small, sizeof(float) * 16));
+    HIP_TRY(hipMalloc((void**)&c->d_small, sizeof(float) * 32));      // [16..21]: min/max slots of lsa_pf_roughen
     HIP_TRY(hipMalloc((void**)&c->d_ismall, sizeof(int) * 4));
     const int idx[2] = {0, 1};
     HIP_TRY(hipMemcpy(c->d_idx, idx, sizeof idx, hipMemcpyHostToDevice));
@@ -896,6 +897,141 @@ int lsa_pose_argmax(lsa_ctx* c, const float* d_score, int P, float* h_max, int32
     const uint32_t bits = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
     memcpy(h_max, &bits, 4);
     *h_index = (int32_t)(0xffffffffu - (uint32_t)h);
+    return LSA_OK;
+}
+
+// top-k of the scores with their poses (host copies): topK + the gathers of weightMean / meanDis
+static int topk_device(lsa_ctx* c, const float* d_poses, const float* d_score, int n, int k,
+                       std::vector<int32_t>& index, std::vector<float>& rec4)
+{
+    unsigned long long* d_keys = nullptr; float* d_out = nullptr; int* d_idx = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_keys, sizeof(unsigned long long) * k));
+    hipError_t e = hipMalloc((void**)&d_out, sizeof(float) * 4 * k);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_idx, sizeof(int) * k);
+    if (e == hipSuccess) e = hipMemsetAsync(d_keys, 0, sizeof(unsigned long long) * k, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, sizeof(float) * 4 * k, c->stream);
+    if (e == hipSuccess) {
+        for (int pass = 0; pass < k; ++pass)
+            hipLaunchKernelGGL(lsa::topk_pass_kernel, dim3(blocks_for((size_t)n, 256, 1024)), dim3(256), 0, c->stream, d_score, n, d_keys, pass);
+        hipLaunchKernelGGL(lsa::topk_gather_kernel, dim3((k + 63) / 64), dim3(64), 0, c->stream, d_keys, k, d_poses, d_score, d_out, d_idx);
+        e = hipGetLastError();
+    }
+    index.resize(k); rec4.resize(4 * (size_t)k);
+    if (e == hipSuccess) e = hipMemcpyAsync(index.data(), d_idx, sizeof(int) * k, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(rec4.data(), d_out, sizeof(float) * 4 * k, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_keys); hipFree(d_out); hipFree(d_idx);
+    if (e != hipSuccess) return fail(LSA_E_HIP, "top-k", e);
+    return LSA_OK;
+}
+
+int lsa_pose_topk(lsa_ctx* c, const float* d_score, int n, int k, int32_t* h_index, float* h_score)
+{
+    if (!c || !d_score || !h_index || n <= 0 || k <= 0) return fail(LSA_E_ARG, "bad argument");
+    if (k > n) k = n;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<int32_t> idx; std::vector<float> rec;
+    int rc = topk_device(c, nullptr, d_score, n, k, idx, rec); if (rc) return rc;
+    for (int i = 0; i < k; ++i) { h_index[i] = idx[i]; if (h_score) h_score[i] = rec[4 * (size_t)i + 3]; }
+    return LSA_OK;
+}
+
+// CParticles::weightMean + meanDis over the top-k particles (particles.cpp:231-281), in double on the host
+int lsa_pf_estimate(lsa_ctx* c, const float* d_poses, const float* d_score, int n, int k,
+                    double h_mean_pose[3], double* h_mean_weight, double* h_mean_dis, int32_t* h_index)
+{
+    if (!c || !d_poses || !d_score || !h_mean_pose || n <= 0 || k <= 0) return fail(LSA_E_ARG, "bad argument");
+    if (k > n) k = n;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<int32_t> idx; std::vector<float> rec;
+    int rc = topk_device(c, d_poses, d_score, n, k, idx, rec); if (rc) return rc;
+    double sumw = 0;
+    for (int i = 0; i < k; ++i) sumw += rec[4 * (size_t)i + 3];
+    double x = 0, y = 0, th = 0;
+    for (int i = 0; i < k; ++i) {
+        const double w = rec[4 * (size_t)i + 3] / sumw;
+        x += w * rec[4 * (size_t)i]; y += w * rec[4 * (size_t)i + 1]; th += w * rec[4 * (size_t)i + 2];
+    }
+    h_mean_pose[0] = x; h_mean_pose[1] = y; h_mean_pose[2] = th;
+    if (h_mean_weight) *h_mean_weight = sumw / k;
+    if (h_mean_dis) {
+        double sum = 0;
+        for (int i = 0; i < k; ++i) {
+            double si = 0;
+            for (int j = 0; j < k; ++j) {
+                const double dx = (double)rec[4 * (size_t)j] - (double)rec[4 * (size_t)i];
+                const double dy = (double)rec[4 * (size_t)j + 1] - (double)rec[4 * (size_t)i + 1];
+                si += dx * dx + dy * dy;
+            }
+            sum += si / k;
+        }
+        *h_mean_dis = sum / k;
+    }
+    if (h_index) for (int i = 0; i < k; ++i) h_index[i] = idx[i];
+    return LSA_OK;
+}
+
+int lsa_pf_predict(lsa_ctx* c, int n, const double mean_pose[3], const double sigma[3], const float* d_normals, float* d_poses)
+{
+    if (!c || !mean_pose || !sigma || !d_normals || !d_poses || n <= 0) return fail(LSA_E_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(lsa::pf_predict_kernel, dim3(blocks_for((size_t)n, 256, 2048)), dim3(256), 0, c->stream, n,
+                       mean_pose[0], mean_pose[1], mean_pose[2], sigma[0], sigma[1], sigma[2], d_normals, d_poses);
+    HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+
+int lsa_pf_roughen(lsa_ctx* c, int n, double K, const float* d_normals, float* d_poses)
+{
+    if (!c || !d_normals || !d_poses || n <= 0) return fail(LSA_E_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_staging(c); if (rc) return rc;
+    uint32_t* mm = (uint32_t*)(c->d_small + 16);
+    static const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    HIP_TRY(hipMemcpyAsync(mm, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(lsa::pf_minmax_kernel, dim3(blocks_for((size_t)n, 256, 1024)), dim3(256), 0, c->stream, n, d_poses, mm);
+    const double scale = K * pow((double)n, -1.0 / 3.0);                    // SIRFlt.cpp:373, x_size = 3
+    hipLaunchKernelGGL(lsa::pf_roughen_kernel, dim3(blocks_for((size_t)n, 256, 2048)), dim3(256), 0, c->stream, n, scale, mm, d_normals, d_poses);
+    HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+
+static lsa::SimParam sim_param(const lsa_field* f, int n_beams, float fov, float min_angle, float max_range)
+{
+    lsa::SimParam S{};
+    S.size_x = f->F.size_x; S.size_y = f->F.size_y; S.center_x = f->F.center_x; S.center_y = f->F.center_y;
+    S.off_x = f->F.off_x; S.off_y = f->F.off_y; S.res = f->F.res;
+    S.n_beams = n_beams; S.fov = fov; S.min_angle = min_angle;
+    S.max_ray_len = (unsigned)llround((double)max_range / f->F.res);        // VPmap.cpp:214
+    S.thr_free = 0.65f; S.unknown = 0.5f;                                  // VPmap.h:34, globaldef.cpp:10
+    return S;
+}
+
+int lsa_simulate_scans(lsa_field* f, const float* d_prob, const float* d_poses, int n_poses, int n_beams,
+                       float fov, float min_angle, float max_range, float* d_ranges, uint8_t* d_bad)
+{
+    if (!f || !d_prob || !d_poses || !d_ranges || !d_bad) return fail(LSA_E_ARG, "null argument");
+    if (n_poses <= 0) return LSA_OK;
+    if (n_beams < 2 || !(max_range > 0)) return fail(LSA_E_ARG, "bad scan geometry");
+    HIP_TRY(hipSetDevice(f->c->device));
+    const lsa::SimParam S = sim_param(f, n_beams, fov, min_angle, max_range);
+    hipLaunchKernelGGL(lsa::sim_scans_kernel, dim3(n_poses < 65535 ? n_poses : 65535), dim3(256), 0, f->c->stream, S, d_prob, d_poses,
+                       n_poses, d_ranges, d_bad);
+    HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+
+int lsa_beam_model_scores(lsa_field* f, const float* d_prob, const float* d_poses, int n_poses, const float* d_obs_r,
+                          const uint8_t* d_obs_bad, int n_beams, float fov, float min_angle, float max_range, float* d_score)
+{
+    if (!f || !d_prob || !d_poses || !d_obs_r || !d_obs_bad || !d_score) return fail(LSA_E_ARG, "null argument");
+    if (n_poses <= 0) return LSA_OK;
+    if (n_beams < 2 || n_beams > 4096 || !(max_range > 0)) return fail(LSA_E_ARG, "bad scan geometry");
+    HIP_TRY(hipSetDevice(f->c->device));
+    const lsa::SimParam S = sim_param(f, n_beams, fov, min_angle, max_range);
+    hipLaunchKernelGGL(lsa::beam_model_kernel, dim3(n_poses < 65535 ? n_poses : 65535), dim3(256), sizeof(double) * n_beams, f->c->stream,
+                       S, d_prob, d_poses, n_poses, d_obs_r, d_obs_bad, d_score);
+    HIP_TRY(hipGetLastError());
     return LSA_OK;
 }
 

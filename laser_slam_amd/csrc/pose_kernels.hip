@@ -224,4 +224,79 @@ __global__ __launch_bounds__(256) void gather_poses_kernel(const float* __restri
     }
 }
 
+// ---- top-k, predict, roughening ---------------------------------------------------------
+// threadLocalization::topK (localization.cpp:126-149): the k largest scores, equal scores in
+// index order.  Pass i finds the largest key below the key of pass i-1; key = ordered(score) in
+// the high word, ~index in the low word, so the maximum is the best score with the lowest index.
+__device__ __forceinline__ unsigned long long topk_key(float sc, int i)
+{
+    return ((unsigned long long)f_ord(sc) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i);
+}
+
+__global__ __launch_bounds__(256) void topk_pass_kernel(const float* __restrict__ score, int n, unsigned long long* __restrict__ keys, int pass)
+{
+    const unsigned long long below = pass == 0 ? ~0ull : keys[pass - 1];
+    unsigned long long best = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned long long k = topk_key(score[i], i);
+        if (k < below && k > best) best = k;
+    }
+    for (int o = 32; o; o >>= 1) { const unsigned long long v = __shfl_xor(best, o); best = v > best ? v : best; }
+    if ((threadIdx.x & 63) == 0 && best) atomicMax(&keys[pass], best);
+}
+
+// gathers the top-k poses and scores into a staging buffer: out[i] = {x, y, theta, score}
+__global__ void topk_gather_kernel(const unsigned long long* __restrict__ keys, int k, const float* __restrict__ poses,
+                                   const float* __restrict__ score, float* __restrict__ out4, int* __restrict__ index)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const int j = (int)(0xffffffffu - (uint32_t)(keys[i] & 0xffffffffull));
+    index[i] = keys[i] ? j : -1;
+    if (keys[i]) {
+        out4[4 * i] = poses ? poses[3 * (size_t)j] : 0.0f; out4[4 * i + 1] = poses ? poses[3 * (size_t)j + 1] : 0.0f;
+        out4[4 * i + 2] = poses ? poses[3 * (size_t)j + 2] : 0.0f; out4[4 * i + 3] = score[j];
+    }
+}
+
+// CParticles::predict (particles.cpp:119-153): every particle = mean pose + N(0, sigma) per state
+__global__ __launch_bounds__(256) void pf_predict_kernel(int n, double mx, double my, double mth, double sx, double sy, double sth,
+                                                         const float* __restrict__ normals, float* __restrict__ poses)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        poses[3 * (size_t)i]     = (float)(mx + (double)normals[3 * (size_t)i] * sx);
+        poses[3 * (size_t)i + 1] = (float)(my + (double)normals[3 * (size_t)i + 1] * sy);
+        poses[3 * (size_t)i + 2] = (float)(mth + (double)normals[3 * (size_t)i + 2] * sth);
+    }
+}
+
+// SIR_scheme::roughen_minmax (SIRFlt.cpp:359-413): per-state range of the particles ...
+__global__ __launch_bounds__(256) void pf_minmax_kernel(int n, const float* __restrict__ poses, uint32_t* __restrict__ mm /* [3] min, [3] max, ordered */)
+{
+    uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0, 0, 0};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        for (int d = 0; d < 3; ++d) {
+            const uint32_t o = f_ord(poses[3 * (size_t)i + d]);
+            lo[d] = o < lo[d] ? o : lo[d]; hi[d] = o > hi[d] ? o : hi[d];
+        }
+    for (int d = 0; d < 3; ++d) {
+        for (int o = 32; o; o >>= 1) {
+            const uint32_t a = __shfl_xor(lo[d], o), b = __shfl_xor(hi[d], o);
+            lo[d] = a < lo[d] ? a : lo[d]; hi[d] = b > hi[d] ? b : hi[d];
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&mm[d], lo[d]); atomicMax(&mm[3 + d], hi[d]); }
+    }
+}
+
+// ... and the roughening noise: state += normal * (max - min) * K n^(-1/3)
+__global__ __launch_bounds__(256) void pf_roughen_kernel(int n, double scale, const uint32_t* __restrict__ mm,
+                                                         const float* __restrict__ normals, float* __restrict__ poses)
+{
+    double rootq[3];
+    for (int d = 0; d < 3; ++d) rootq[d] = ((double)ord_f(mm[3 + d]) - (double)ord_f(mm[d])) * scale;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        for (int d = 0; d < 3; ++d)
+            poses[3 * (size_t)i + d] = (float)((double)poses[3 * (size_t)i + d] + (double)normals[3 * (size_t)i + d] * rootq[d]);
+}
+
 } // namespace lsa

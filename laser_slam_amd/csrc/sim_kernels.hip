@@ -1,0 +1,122 @@
+// Ray-cast scan simulator and beam-model pose scoring on gfx950.
+//
+// Reference semantics (sources readable, not compilable here: Qt4/Boost/MRPT absent, so this
+// block is "parity unpinned" - SURVEY.md §8c; the checker is oracle/sim_oracle.c):
+//   CVPmap::laserScanSimulator   src/localization/VPmap.cpp:180-234
+//   CVPmap::simulateScanRay      src/localization/VPmap.cpp:236-303   fixed-step ray march
+//   CVPmap::obsLikelyhood2       src/localization/VPmap.cpp:454-483   beam model
+//
+// One lane per (pose, beam): the march is a chain of dependent cell reads of a map that stays in
+// L2 / Infinity Cache, so the parallelism comes from the poses.  The beam model sums the per-beam
+// likelihoods in beam order (float accumulator, as the reference does).
+#include "lsa_device.h"
+
+namespace lsa {
+
+struct SimParam {
+    int size_x, size_y, center_x, center_y;
+    float off_x, off_y;
+    double res;
+    int n_beams;
+    float fov, min_angle;
+    unsigned max_ray_len;       // round(max_range / res), VPmap.cpp:214
+    float thr_free, unknown;    // 0.65 (VPmap.h:34), g_unknown_value 0.5
+};
+
+__device__ __forceinline__ int sim_idx1(float r, float off, int center, double res)     // x2idx / y2idx, :94-100
+{
+    return (int)((double)center + ((double)(r - off) + 0.0005) / res);
+}
+
+// simulateScanRay (:236-303)
+__device__ __forceinline__ void sim_ray(const SimParam& S, const float* __restrict__ prob, double px, double py, double A,
+                                        float& out_r, bool& out_valid)
+{
+    const double Arx = cos(A) * S.res, Ary = sin(A) * S.res;
+    unsigned ray_len = 0, first_unknown = S.max_ray_len + 1;
+    double rx = px, ry = py;
+    float occ = 0.5f;
+    int x, y = sim_idx1((float)ry, S.off_y, S.center_y, S.res);
+    while ((x = sim_idx1((float)rx, S.off_x, S.center_x, S.res)) >= 0 &&
+           (y = sim_idx1((float)ry, S.off_y, S.center_y, S.res)) >= 0 && x < S.size_x && y < S.size_y &&
+           (occ = prob[(size_t)x * S.size_y + y]) < S.thr_free && ray_len < S.max_ray_len) {
+        if (fabs((double)(occ - S.unknown)) < (double)0.01f) {
+            if (ray_len < first_unknown) first_unknown = ray_len;
+            break;
+        }
+        rx += Arx; ry += Ary; ray_len++;
+    }
+    if (fabs((double)(occ - S.unknown)) < (double)0.01f || (unsigned)x >= (unsigned)S.size_x || (unsigned)y >= (unsigned)S.size_y) {
+        out_valid = false;
+        out_r = (float)((double)(first_unknown < ray_len ? first_unknown : ray_len) * S.res);
+    } else {
+        out_valid = ray_len < S.max_ray_len;
+        out_r = (float)((double)ray_len * S.res);
+    }
+}
+
+// bearing of beam i at pose angle th (:184-219): A_0 = -(float)(min_angle) - normAngle(th, -pi'), A_i = A_0 - i AA
+__device__ __forceinline__ double sim_beam_angle(const SimParam& S, float th, int i)
+{
+    const double AA = (double)(S.fov / (float)(S.n_beams - 1));
+    double t = (double)th;                                   // normAngle(th, -M_PI) with PolarParameter.h's M_PI, true 2 pi
+    while (t >= -LSA_ZPI + 6.28318530717958647692) t -= 6.28318530717958647692;
+    while (t < -LSA_ZPI) t += 6.28318530717958647692;
+    double A = (double)(-(float)((double)S.min_angle + 0.0 * AA)) + -1.0 * t;
+    for (int k = 0; k < i; ++k) A -= AA;                      // the reference's running subtraction
+    return A;
+}
+
+__global__ __launch_bounds__(256) void sim_scans_kernel(SimParam S, const float* __restrict__ prob,
+                                                        const float* __restrict__ poses, int P,
+                                                        float* __restrict__ r, uint8_t* __restrict__ bad)
+{
+    // one workgroup per pose; lane i walks the running angle A_i = A_0 - i AA exactly like the loop of :219
+    for (int p = blockIdx.x; p < P; p += gridDim.x) {
+        const float px = poses[3 * (size_t)p], py = poses[3 * (size_t)p + 1], th = poses[3 * (size_t)p + 2];
+        for (int i = threadIdx.x; i < S.n_beams; i += blockDim.x) {
+            float rr; bool valid;
+            sim_ray(S, prob, (double)px, (double)py, sim_beam_angle(S, th, i), rr, valid);
+            r[(size_t)p * S.n_beams + i] = rr;
+            bad[(size_t)p * S.n_beams + i] = valid ? 0 : 1;
+        }
+    }
+}
+
+// obsLikelyhood2 (:454-483): one workgroup per pose, likelihoods of the beams in LDS, summed in beam order
+__global__ __launch_bounds__(256) void beam_model_kernel(SimParam S, const float* __restrict__ prob,
+                                                         const float* __restrict__ poses, int P,
+                                                         const float* __restrict__ obs_r, const uint8_t* __restrict__ obs_bad,
+                                                         float* __restrict__ score)
+{
+    extern __shared__ double lik[];                           // n_beams doubles
+    const double std_sqrt2 = (double)sqrtf(2.0f) * 0.02;       // :462-463
+    for (int p = blockIdx.x; p < P; p += gridDim.x) {
+        const float px = poses[3 * (size_t)p], py = poses[3 * (size_t)p + 1], th = poses[3 * (size_t)p + 2];
+        __syncthreads();
+        for (int j = threadIdx.x; j < S.n_beams; j += blockDim.x) {
+            double l = 0.0;
+            if (!obs_bad[j]) {
+                float rr; bool valid;
+                sim_ray(S, prob, (double)px, (double)py, sim_beam_angle(S, th, j), rr, valid);
+                if (!valid) { const double q = (double)2.0f / std_sqrt2; l = exp(-(q * q)); }
+                else {
+                    float d = fabsf(rr - obs_r[j]);
+                    d = d < 2.0f ? d : 2.0f;
+                    const double q = (double)d / std_sqrt2;
+                    l = exp(-(q * q));
+                }
+            }
+            lik[j] = l;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float ret = 1.0f;
+            for (int j = 0; j < S.n_beams; ++j)
+                if (!obs_bad[j]) ret = (float)((double)ret + lik[j]);
+            score[p] = ret;
+        }
+    }
+}
+
+} // namespace lsa

@@ -127,6 +127,19 @@ void orc_score_poses(const float* lik, int sx, int sy, int cx0, int cy0, float o
 void orc_systematic_resample(const float* w, int P, double u0, int n_out, int* parent);
 double orc_neff(const float* w, int P);
 
+/* ray-cast scan simulator, beam model, top-k / estimate / predict / roughening (sim_oracle.c): PARITY UNPINNED */
+void orc_simulate_scan(const float* prob, int sx, int sy, int cx, int cy, float offx, float offy, double res,
+                       const float pose[3], int n_beams, float fov, float min_angle, float max_range,
+                       float* r, int* bad);
+void orc_beam_model(const float* prob, int sx, int sy, int cx, int cy, float offx, float offy, double res,
+                    const float* poses, int P, const float* obs_r, const int* obs_bad, int n_beams,
+                    float fov, float min_angle, float max_range, float* score);
+void orc_topk(const float* score, int n, int k, int* index);
+void orc_pf_estimate(const float* poses, const float* score, const int* index, int k,
+                     double mean[3], double* mean_weight, double* mean_dis);
+void orc_pf_predict(int n, const double mean[3], const double sigma[3], const float* normals, float* poses);
+void orc_pf_roughen(int n, double K, const float* normals, float* poses);
+
 /* classic point-to-point ICP with CICPWarpper's options (MRPT absent: PARITY UNPINNED), p2p_oracle.c */
 void orc_p2p_icp(const float* rx, const float* ry, int n1, const float* cx, const float* cy, int n2,
                  const double init[3], int max_iter, float thr_d, float thr_a, float alfa, float smallest,

@@ -465,3 +465,58 @@ class RefPMap:
             self.L.ref_pmap_destroy(C.c_void_p(self.h))
         except Exception:
             pass
+
+
+def _orc():
+    if Oracle._L is None:
+        Oracle._L = _load_oracle()
+    return Oracle._L
+
+
+def simulate_scan(prob, cx, cy, offx, offy, res, pose, n_beams, fov, min_angle, max_range):
+    """CVPmap::laserScanSimulator for one pose -> (ranges [m], bad)."""
+    prob = np.ascontiguousarray(prob, f32)
+    r = np.zeros(n_beams, f32); bad = np.zeros(n_beams, i32)
+    pose = np.ascontiguousarray(pose, f32)
+    _orc().orc_simulate_scan(_p(prob), prob.shape[0], prob.shape[1], cx, cy, C.c_float(offx), C.c_float(offy),
+                                C.c_double(res), _p(pose), n_beams, C.c_float(fov), C.c_float(min_angle),
+                                C.c_float(max_range), _p(r), _p(bad))
+    return r, bad
+
+
+def beam_model(prob, cx, cy, offx, offy, res, poses, obs_r, obs_bad, fov, min_angle, max_range):
+    prob = np.ascontiguousarray(prob, f32); poses = np.ascontiguousarray(poses, f32)
+    obs_r = np.ascontiguousarray(obs_r, f32); obs_bad = np.ascontiguousarray(obs_bad, i32)
+    score = np.zeros(len(poses), f32)
+    _orc().orc_beam_model(_p(prob), prob.shape[0], prob.shape[1], cx, cy, C.c_float(offx), C.c_float(offy),
+                             C.c_double(res), _p(poses), len(poses), _p(obs_r), _p(obs_bad), len(obs_r),
+                             C.c_float(fov), C.c_float(min_angle), C.c_float(max_range), _p(score))
+    return score
+
+
+def topk(score, k):
+    score = np.ascontiguousarray(score, f32)
+    idx = np.zeros(k, i32)
+    _orc().orc_topk(_p(score), len(score), k, _p(idx))
+    return idx
+
+
+def pf_estimate(poses, score, index):
+    poses = np.ascontiguousarray(poses, f32); score = np.ascontiguousarray(score, f32)
+    index = np.ascontiguousarray(index, i32)
+    mean = np.zeros(3, np.float64); mw, md = C.c_double(0), C.c_double(0)
+    _orc().orc_pf_estimate(_p(poses), _p(score), _p(index), len(index), _p(mean), C.byref(mw), C.byref(md))
+    return mean, mw.value, md.value
+
+
+def pf_predict(n, mean, sigma, normals):
+    mean = np.ascontiguousarray(mean, np.float64); sigma = np.ascontiguousarray(sigma, np.float64)
+    normals = np.ascontiguousarray(normals, f32); poses = np.zeros((n, 3), f32)
+    _orc().orc_pf_predict(n, _p(mean), _p(sigma), _p(normals), _p(poses))
+    return poses
+
+
+def pf_roughen(poses, K, normals):
+    poses = np.ascontiguousarray(poses, f32).copy(); normals = np.ascontiguousarray(normals, f32)
+    _orc().orc_pf_roughen(len(poses), C.c_double(K), _p(normals), _p(poses))
+    return poses

@@ -133,3 +133,74 @@ def test_sharded_filter_single_gpu(world):
     assert info["resampled"] and new.shape == (P, 3)
     # resampling concentrates the particles on high-score poses
     assert float(score(new).mean()) > float(score(poses).mean())
+
+
+def test_scan_simulator_and_beam_model(world):
+    """CVPmap::laserScanSimulator / obsLikelyhood2 against oracle/sim_oracle.c.  Ranges are whole
+    numbers of ray-march steps; device and host cos/sin/exp may differ in the last bit, so a ray that
+    passes within an ulp of a cell boundary may stop one step apart: at most 0.1 % of the rays may
+    differ, by one step, and the beam-model scores agree to 1e-3 relative."""
+    torch, capi, ctx, fld = world["torch"], world["capi"], world["ctx"], world["fld"]
+    from oracle_lib import beam_model, simulate_scan
+    rng = np.random.default_rng(11)
+    prob, res = world["prob"], world["res"]
+    n, P = 181, 96
+    poses = np.stack([rng.uniform(0.5, 12.5, P), rng.uniform(0.5, 9.5, P), rng.uniform(-7, 7, P)], 1).astype(np.float32)
+    poses[0] = [-3.0, 2.0, 0.1]                     # outside the map: every ray invalid at range 0
+    d_prob = torch.from_numpy(prob).cuda(); d_p = torch.from_numpy(poses).cuda()
+    d_r = torch.zeros(P, n, device="cuda"); d_b = torch.zeros(P, n, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    capi.simulate_scans(fld, d_prob, d_p, P, n, d_r, d_b, max_range=8.0)
+    ctx.sync()
+    r_g, b_g = d_r.cpu().numpy(), d_b.cpu().numpy()
+    r_o = np.zeros((P, n), np.float32); b_o = np.zeros((P, n), np.int32)
+    for p in range(P):
+        r_o[p], b_o[p] = simulate_scan(prob, 0, 0, 0.0, 0.0, res, poses[p], n, capi.SIM_FOV, capi.SIM_MIN_ANGLE, 8.0)
+    diff = (r_g != r_o) | (b_g != b_o)
+    assert diff.mean() <= 1e-3
+    assert np.abs(r_g - r_o).max() <= 1.01 * res
+    assert b_g[0].all() and (r_g[0] == 0).all()
+    assert 0.02 < b_g.mean() < 0.9                  # the test world produces both valid and invalid rays
+    # beam model: the scan seen from pose 5, scored at all poses
+    obs_r, obs_bad = r_o[5].copy(), b_o[5].astype(np.uint8)
+    d_or, d_ob = torch.from_numpy(obs_r).cuda(), torch.from_numpy(obs_bad).cuda()
+    d_s = torch.zeros(P, device="cuda")
+    torch.cuda.synchronize()
+    capi.beam_model_scores(fld, d_prob, d_p, P, d_or, d_ob, n, d_s, max_range=8.0)
+    ctx.sync()
+    s_g = d_s.cpu().numpy()
+    s_o = beam_model(prob, 0, 0, 0.0, 0.0, res, poses, obs_r, obs_bad.astype(np.int32), capi.SIM_FOV, capi.SIM_MIN_ANGLE, 8.0)
+    assert np.allclose(s_g, s_o, rtol=1e-3, atol=1e-3)
+    assert s_g.argmax() == 5 and s_g[5] == np.float32(1 + (obs_bad == 0).sum())
+
+
+def test_topk_estimate_predict_roughen(world):
+    """topK / weightMean / meanDis / predict / roughen_minmax against oracle/sim_oracle.c."""
+    torch, capi, ctx = world["torch"], world["capi"], world["ctx"]
+    import oracle_lib as ol
+    rng = np.random.default_rng(21)
+    n = 20000
+    score = rng.random(n).astype(np.float32)
+    score[[17, 4000, 19999]] = 2.0                  # equal maxima come out in index order
+    score[123] = -1.0
+    poses = rng.normal(size=(n, 3)).astype(np.float32)
+    d_s, d_p = torch.from_numpy(score).cuda(), torch.from_numpy(poses).cuda()
+    torch.cuda.synchronize()
+    for k in (1, 8, 60):
+        idx, sc = capi.pose_topk(ctx, d_s, n, k)
+        idx_o = ol.topk(score, k)
+        assert np.array_equal(idx, idx_o) and np.array_equal(sc, score[idx_o])
+    mean, mw, md, idx = capi.pf_estimate(ctx, d_p, d_s, n, 8)
+    mean_o, mw_o, md_o = ol.pf_estimate(poses, score, ol.topk(score, 8))
+    assert np.array_equal(mean, mean_o) and mw == mw_o and md == md_o        # same double arithmetic on the host
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    d_n = torch.from_numpy(nrm).cuda(); d_out = torch.zeros(n, 3, device="cuda")
+    torch.cuda.synchronize()
+    capi.pf_predict(ctx, n, [1.5, -2.0, 0.7], [0.25, 0.25, (np.pi / 6) ** 2], d_n, d_out)
+    ctx.sync()
+    assert np.array_equal(d_out.cpu().numpy(), ol.pf_predict(n, [1.5, -2.0, 0.7], [0.25, 0.25, (np.pi / 6) ** 2], nrm))
+    d_q = torch.from_numpy(poses).cuda()
+    torch.cuda.synchronize()
+    capi.pf_roughen(ctx, n, 0.2, d_n, d_q)
+    ctx.sync()
+    assert np.array_equal(d_q.cpu().numpy(), ol.pf_roughen(poses, 0.2, nrm))
