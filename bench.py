@@ -281,6 +281,18 @@ def extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p):
     ms = timed(lambda: fld.score_poses(d_sx, d_sy, n, 3, d_p, P, d_sc), reps=3)
     res["score_poses_per_s"] = P / (ms * 1e-3)
     res["score_gather_GBps"] = P * ((n + 2) // 3) * 4 / (ms * 1e-3) / 1e9
+    # beam model (ray-cast 541-beam virtual scans in the map just built, 16384 poses) and top-60 of 1 M scores
+    P2, nb2 = 16384, 541
+    d_prob = torch.from_numpy(grid.download(2)).cuda()
+    d_or = torch.full((nb2,), 4.0, device="cuda"); d_ob = torch.zeros(nb2, dtype=torch.uint8, device="cuda")
+    d_s2 = torch.zeros(P2, device="cuda")
+    torch.cuda.synchronize()
+    ms = timed(lambda: capi.beam_model_scores(fld, d_prob, d_p, P2, d_or, d_ob, nb2, d_s2), reps=2)
+    res["beam_model_poses_per_s"] = P2 / (ms * 1e-3)
+    res["beam_model_rays_per_s"] = P2 * nb2 / (ms * 1e-3)
+    t0 = time.perf_counter()
+    capi.pose_topk(ctx, d_sc, P, 60)
+    res["topk60_of_1M_ms"] = (time.perf_counter() - t0) * 1e3
     fld.close()
     grid.close()
     return res
