@@ -18,6 +18,9 @@ def cloud(n):
 
 @pytest.fixture(scope="module")
 def ctx():
+    import torch
+    assert torch.cuda.is_available()       # torch first: it refuses to initialise HIP after another library has
+    torch.zeros(1, device="cuda")
     from laser_slam_amd import capi
     return capi.Context(capi.param_preset("LMS211"))
 
@@ -56,3 +59,61 @@ def test_recovers_known_transform(ctx):
     # empty clouds are handled
     e = capi.p2p_icp_host(ctx, ref[:0, 0], ref[:0, 1], cur[:, 0], cur[:, 1], (0, 0, 0))
     assert e[3] == 0 and e[6] == 0
+
+
+def test_map_node_rasterise_cloud_icp_chain(ctx):
+    """The one place where the reference chains CPMap and CICPWarpper (CMapNode::computePMAP +
+    matchNodePairICP, src/mapGraph/MapNode.cpp:703-757, 625-656): the scans of a map node are
+    rasterised into a node-local counting grid, the cells above the threshold become the node's
+    point cloud, and two nodes' clouds are aligned by point-to-point ICP.  Device chain (batched grid
+    update -> probabilities -> cloud -> ICP) against the oracle chain; the clouds must be identical."""
+    import torch
+    from laser_slam_amd import capi, synth
+    from oracle_lib import OraclePMap, p2p_icp
+    n_beams, fov = 361, 270.0
+    raw, poses = synth.make_scans(30, n_beams=n_beams, fov_deg=fov)
+    bearings = np.deg2rad(-fov / 2 + fov * np.arange(n_beams) / (n_beams - 1))
+
+    def node(first, last):
+        """scans first..last-1 in the frame of scan `first` (metres), as computeGlobalScans does"""
+        x0, y0, t0 = poses[first]
+        c, s = np.cos(-t0), np.sin(-t0)
+        gx, gy, rob = [], [], []
+        for k in range(first, last):
+            px, py, pt = poses[k]
+            lx, ly = c * (px - x0) - s * (py - y0), s * (px - x0) + c * (py - y0)
+            lt = pt - t0
+            r = raw[k] / 100.0
+            gx.append((lx + r * np.cos(lt + bearings)).astype(np.float32))
+            gy.append((ly + r * np.sin(lt + bearings)).astype(np.float32))
+            rob.append((np.float32(lx), np.float32(ly)))
+        gx, gy, rob = np.stack(gx), np.stack(gy), np.array(rob, np.float32)
+        # computeBoundary / computePMAP: grid twice the extent, origin in the middle, 5 cm cells
+        size_x = int((gx.max() - gx.min() + 0.05) / 0.05) * 2
+        size_y = int((gy.max() - gy.min() + 0.05) / 0.05) * 2
+        grid = capi.Grid(ctx, size_x, size_y, size_x // 2, size_y // 2, 0.0, 0.0, 0.05)
+        torch.cuda.synchronize()
+        grid.update_batch(len(gx), n_beams, torch.from_numpy(gx).cuda(), torch.from_numpy(gy).cuda(), torch.from_numpy(rob).cuda())
+        grid.compute_prob()
+        cx_, cy_ = grid.cloud(0.5)
+        o = OraclePMap(size_x, size_y, size_x // 2, size_y // 2, 0.0, 0.0, 0.05)
+        for k in range(len(gx)):
+            o.update(gx[k], gy[k], float(rob[k, 0]), float(rob[k, 1]))
+        o.compute()
+        ox, oy = o.cloud(0.5)
+        assert np.array_equal(cx_, ox) and np.array_equal(cy_, oy) and len(ox) > 200
+        grid.close()
+        return cx_, cy_
+
+    ax, ay = node(0, 12)
+    bx, by = node(6, 18)
+    # true pose of node B's frame in node A's frame
+    x0, y0, t0 = poses[0]; x1, y1, t1 = poses[6]
+    c, s = np.cos(-t0), np.sin(-t0)
+    true = np.array([c * (x1 - x0) - s * (y1 - y0), s * (x1 - x0) + c * (y1 - y0), t1 - t0])
+    init = true + [0.05, -0.04, 0.02]                  # the odometry guess the graph hands to matchNodePairICP
+    got = capi.p2p_icp_host(ctx, ax, ay, bx, by, init)
+    want = p2p_icp(ax, ay, bx, by, init)
+    assert got[5] == want[5] and got[6] == want[6]
+    assert np.allclose(got[:5], want[:5], rtol=1e-9, atol=1e-9)
+    assert np.abs(got[:2] - true[:2]).max() < 0.05 and abs(got[2] - true[2]) < 0.02 and got[3] > 0.5
