@@ -80,6 +80,7 @@ __device__ __forceinline__ void build_masked_rows(const DevParam& P, const Lds& 
 
 // one beam quad of one shift: e += |a - b| for the valid terms, in beam order.  An invalid term is
 // NaN; fmaxf(NaN, 0) = 0, and adding +0 leaves the (non-negative) ordered sum unchanged.
+// (Packed v_pk_add_f32 over the two shifts of a thread was measured 8 % slower than the scalar form.)
 __device__ __forceinline__ void orient_quad(float& e, const float4 a, const float* rb)
 {
     const float b0 = rb[0], b1 = rb[1], b2 = rb[2], b3 = rb[3];
