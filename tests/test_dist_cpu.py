@@ -98,3 +98,50 @@ def test_shard_bounds_cover_everything():
             for (a, c), (b, _) in zip(spans, spans[1:]):
                 assert a + c == b
             assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def _grid_inputs():
+    rng = np.random.default_rng(9)
+    S, nb = 37, 181
+    rob = rng.uniform(-3, 3, (S, 2)).astype(np.float32)
+    ang = rng.uniform(0, 2 * np.pi, (S, nb)); d = rng.uniform(0.2, 6, (S, nb))
+    gx = (rob[:, :1] + d * np.cos(ang)).astype(np.float32); gy = (rob[:, 1:] + d * np.sin(ang)).astype(np.float32)
+    return S, gx, gy, rob
+
+
+def _grid_update_fn():
+    from oracle_lib import OraclePMap
+    S, gx, gy, rob = _grid_inputs()
+
+    def update(first, count):
+        o = OraclePMap(320, 320, 160, 160, 0.0, 0.0, 0.05)
+        for k in range(first, first + count):
+            o.update(gx[k], gy[k], float(rob[k, 0]), float(rob[k, 1]))
+        hit, visits, _ = o.layers()
+        return torch.from_numpy(hit.astype(np.int32)), torch.from_numpy(visits.astype(np.int32))
+
+    return S, update
+
+
+def _grid_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from laser_slam_amd import mapping
+    S, update = _grid_update_fn()
+    hit, visits = mapping.sharded_grid_update(S, update)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "hit.npy"), hit.numpy()); np.save(os.path.join(out_dir, "sum.npy"), visits.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_grid_mapping_equals_single_process(tmp_path):
+    """Config 5's exchange step: scans split over two ranks, count layers all-reduced."""
+    port = 29950 + (os.getpid() % 40)
+    mp.spawn(_grid_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    S, update = _grid_update_fn()
+    hit, visits = update(0, S)
+    assert np.array_equal(np.load(tmp_path / "hit.npy"), hit.numpy())
+    assert np.array_equal(np.load(tmp_path / "sum.npy"), visits.numpy())
+    assert int(hit.sum()) == 2 * S * 181 or int(hit.sum()) > 0

@@ -332,6 +332,33 @@ def test_grid_vs_oracle_random(torch_mod):
     grid.close(); ctx.close()
 
 
+def test_grid_batch_ragged_scans(torch_mod):
+    """Scans with different numbers of valid beams (incl. none) through the batched path against the oracle."""
+    torch = torch_mod
+    from laser_slam_amd import capi
+    from oracle_lib import OraclePMap
+    rng = np.random.default_rng(13)
+    sx, sy, cx, cy, res = 400, 300, 200, 150, 0.05
+    ctx = capi.Context(capi.param_preset("LMS151"))
+    grid = capi.Grid(ctx, sx, sy, cx, cy, 0.0, 0.0, res)
+    o = OraclePMap(sx, sy, cx, cy, 0.0, 0.0, res)
+    S, nb = 40, 541
+    nv = rng.integers(0, nb + 1, S).astype(np.int32); nv[3] = 0; nv[5] = nb; nv[7] = 1
+    rob = rng.uniform(-6, 6, (S, 2)).astype(np.float32)
+    ang = rng.uniform(0, 2 * np.pi, (S, nb)); d = rng.uniform(0, 14, (S, nb))
+    gx = (rob[:, :1] + d * np.cos(ang)).astype(np.float32); gy = (rob[:, 1:] + d * np.sin(ang)).astype(np.float32)
+    for s in range(S):
+        if nv[s]:
+            o.update(gx[s, :nv[s]], gy[s, :nv[s]], float(rob[s, 0]), float(rob[s, 1]))
+    torch.cuda.synchronize()
+    grid.update_batch(S, nb, dev(torch, gx, np.float32), dev(torch, gy, np.float32), dev(torch, rob, np.float32),
+                      dev(torch, nv, np.int32))
+    grid.compute_prob(); o.compute()
+    for a, b in zip(grid.layers(), o.layers()):
+        assert same_bits(a, b)
+    grid.close(); ctx.close()
+
+
 def test_full_size_batch_properties(torch_mod):
     """BASELINE-size batch (65 536 pairs of 1081-beam scans): results must not depend on a pair's
     position in the batch or on what runs beside it (every copy of a pair gives the same bits),
