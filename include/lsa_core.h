@@ -273,6 +273,15 @@ int lsa_p2p_icp_batch(lsa_ctx* c, int n_problems, const float* d_ref_x, const fl
 int lsa_p2p_icp_host(lsa_ctx* c, const float* h_ref_x, const float* h_ref_y, int n_ref,
                      const float* h_cur_x, const float* h_cur_y, int n_cur, const double h_init_pose[3],
                      const lsa_p2p_options* opt, double h_out16[16]);
+/* CVPmap::obsLikelyhood (src/localization/VPmap.cpp:485-503): the scorer the reference's particle
+ * filter and global search actually call (particles.cpp:335, localization.cpp:500).  For every pose a
+ * virtual scan is ray-cast in d_prob and aligned with the observed scan (scan-frame points [m]) by
+ * CICPWarpper::ICPMatch from a zero guess; d_weight = goodness, d_rel_pose [P][3] (may be NULL) = the
+ * ICP correction where the weight exceeds 0.5, else 0.  opt NULL = the reference's options. */
+int lsa_icp_goodness_scores(lsa_field* f, const float* d_prob, const float* d_poses, int n_poses,
+                            const float* d_obs_x, const float* d_obs_y, int n_beams, float fov, float min_angle,
+                            float max_range, const lsa_p2p_options* opt, float* d_weight, float* d_rel_pose);
+
 
 #ifdef __cplusplus
 }

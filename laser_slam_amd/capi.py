@@ -105,6 +105,7 @@ def lib():
     L.lsa_pf_roughen.argtypes = [vp, C.c_int, C.c_double, vp, vp]
     L.lsa_simulate_scans.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp]
     L.lsa_beam_model_scores.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, vp]
+    L.lsa_icp_goodness_scores.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp, vp]
     L.lsa_gather_poses.argtypes = [vp, vp, vp, C.c_int, vp]
     L.lsa_p2p_icp_host.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp]
     L.lsa_p2p_icp_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
@@ -447,6 +448,14 @@ def beam_model_scores(field, d_prob, d_poses, P, d_obs_r, d_obs_bad, n_beams, d_
                       min_angle=SIM_MIN_ANGLE, max_range=SIM_MAX_RANGE):
     check(lib().lsa_beam_model_scores(field.h, _dp(d_prob), _dp(d_poses), P, _dp(d_obs_r), _dp(d_obs_bad), n_beams,
                                       fov, min_angle, max_range, _dp(d_score)), "lsa_beam_model_scores")
+
+
+def icp_goodness_scores(field, d_prob, d_poses, P, d_obs_x, d_obs_y, n_beams, d_weight, d_rel_pose=None, fov=SIM_FOV,
+                        min_angle=SIM_MIN_ANGLE, max_range=SIM_MAX_RANGE):
+    """CVPmap::obsLikelyhood: ray-cast a virtual scan per pose and align it with the observed scan by ICP."""
+    check(lib().lsa_icp_goodness_scores(field.h, _dp(d_prob), _dp(d_poses), P, _dp(d_obs_x), _dp(d_obs_y), n_beams,
+                                        fov, min_angle, max_range, None, _dp(d_weight), _dp(d_rel_pose)),
+          "lsa_icp_goodness_scores")
 
 
 def pf_resample(ctx, d_w, P, u0, n_total, first, M, d_parent):

@@ -1016,7 +1016,7 @@ int lsa_simulate_scans(lsa_field* f, const float* d_prob, const float* d_poses, 
     HIP_TRY(hipSetDevice(f->c->device));
     const lsa::SimParam S = sim_param(f, n_beams, fov, min_angle, max_range);
     hipLaunchKernelGGL(lsa::sim_scans_kernel, dim3(n_poses < 65535 ? n_poses : 65535), dim3(256), 0, f->c->stream, S, d_prob, d_poses,
-                       n_poses, d_ranges, d_bad);
+                       n_poses, d_ranges, d_bad, (float*)nullptr, (float*)nullptr);
     HIP_TRY(hipGetLastError());
     return LSA_OK;
 }
@@ -1032,6 +1032,49 @@ int lsa_beam_model_scores(lsa_field* f, const float* d_prob, const float* d_pose
     hipLaunchKernelGGL(lsa::beam_model_kernel, dim3(n_poses < 65535 ? n_poses : 65535), dim3(256), sizeof(double) * n_beams, f->c->stream,
                        S, d_prob, d_poses, n_poses, d_obs_r, d_obs_bad, d_score);
     HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+
+// CVPmap::obsLikelyhood (VPmap.cpp:485-503), the scorer wired into the reference's particle filter
+// (particles.cpp:335) and global search (localization.cpp:500): virtual scan of every pose, then
+// CICPWarpper::ICPMatch(virtual scan, observed scan, zero guess); weight = ICP goodness, and the ICP
+// correction is adopted when the weight exceeds 0.5.
+int lsa_icp_goodness_scores(lsa_field* f, const float* d_prob, const float* d_poses, int n_poses,
+                            const float* d_obs_x, const float* d_obs_y, int n_beams, float fov, float min_angle,
+                            float max_range, const lsa_p2p_options* opt, float* d_weight, float* d_rel_pose)
+{
+    if (!f || !d_prob || !d_poses || !d_obs_x || !d_obs_y || !d_weight) return fail(LSA_E_ARG, "null argument");
+    if (n_poses <= 0) return LSA_OK;
+    if (n_beams < 2 || !(max_range > 0)) return fail(LSA_E_ARG, "bad scan geometry");
+    lsa_p2p_options o;
+    if (opt) o = *opt; else lsa_p2p_options_default(&o);
+    lsa_ctx* c = f->c;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t pts = (size_t)n_poses * n_beams;
+    char* d = nullptr;
+    const size_t bytes = pts * (2 * sizeof(float) + sizeof(unsigned long long) + sizeof(int)) + (size_t)(n_poses + 1) * sizeof(int)
+                       + (size_t)n_poses * (3 + 16) * sizeof(double) + 64;
+    HIP_TRY(hipMalloc((void**)&d, bytes));
+    double* d_out = (double*)d; double* d_init = d_out + 16 * (size_t)n_poses;
+    unsigned long long* d_owner = (unsigned long long*)(d_init + 3 * (size_t)n_poses);
+    float* d_sx = (float*)(d_owner + pts); float* d_sy = d_sx + pts;
+    int* d_match = (int*)(d_sy + pts); int* d_off = d_match + pts;
+    const lsa::SimParam S = sim_param(f, n_beams, fov, min_angle, max_range);
+    hipError_t e = hipMemsetAsync(d_init, 0, sizeof(double) * 3 * (size_t)n_poses, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(lsa::sim_scans_kernel, dim3(n_poses < 65535 ? n_poses : 65535), dim3(256), 0, c->stream, S, d_prob, d_poses,
+                           n_poses, (float*)nullptr, (uint8_t*)nullptr, d_sx, d_sy);
+        hipLaunchKernelGGL(lsa::iota_scaled_kernel, dim3((n_poses + 256) / 256), dim3(256), 0, c->stream, n_poses + 1, n_beams, d_off);
+        lsa::P2PParam P = {o.max_iterations, o.threshold_dist, o.threshold_ang, o.alfa, o.smallest_threshold_dist};
+        hipLaunchKernelGGL(lsa::p2p_icp_kernel, dim3(n_poses), dim3(lsa::P2P_THREADS), 0, c->stream, P, n_poses, d_sx, d_sy, d_off,
+                           d_obs_x, d_obs_y, (const int*)nullptr, d_init, d_owner, d_match, d_out, n_beams);
+        hipLaunchKernelGGL(lsa::icp_goodness_extract_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, c->stream, n_poses, d_out,
+                           d_weight, d_rel_pose);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(LSA_E_HIP, "icp goodness", e);
     return LSA_OK;
 }
 
@@ -1126,7 +1169,7 @@ int lsa_p2p_icp_batch(lsa_ctx* c, int B, const float* d_ref_x, const float* d_re
     if (e != hipSuccess) { hipFree(d_owner); return fail(LSA_E_NOMEM, "hipMalloc", e); }
     lsa::P2PParam P = {o.max_iterations, o.threshold_dist, o.threshold_ang, o.alfa, o.smallest_threshold_dist};
     hipLaunchKernelGGL(lsa::p2p_icp_kernel, dim3(B), dim3(lsa::P2P_THREADS), 0, c->stream, P, B, d_ref_x, d_ref_y,
-                       d_ref_off, d_cur_x, d_cur_y, d_cur_off, d_init_pose, d_owner, d_match, d_out16);
+                       d_ref_off, d_cur_x, d_cur_y, d_cur_off, d_init_pose, d_owner, d_match, d_out16, 0);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(d_owner); hipFree(d_match);

@@ -43,13 +43,15 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
     P2PParam O, int B, const float* __restrict__ ref_x, const float* __restrict__ ref_y, const int* __restrict__ ref_off,
     const float* __restrict__ cur_x, const float* __restrict__ cur_y, const int* __restrict__ cur_off,
     const double* __restrict__ init_pose, unsigned long long* __restrict__ owner, int* __restrict__ match,
-    double* __restrict__ out)
+    double* __restrict__ out, int n_cur_shared /* cur_off == nullptr: every problem aligns the same second map */)
 {
     __shared__ float2 tile[P2P_TILE];
     __shared__ double sh[8];
     const int tid = threadIdx.x;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        const int r0 = ref_off[b], n1 = ref_off[b + 1] - r0, c0 = cur_off[b], n2 = cur_off[b + 1] - c0;
+        const int r0 = ref_off[b], n1 = ref_off[b + 1] - r0;
+        const int c0 = cur_off ? cur_off[b] : 0, n2 = cur_off ? cur_off[b + 1] - c0 : n_cur_shared;
+        int* const match_b = match + (cur_off ? (size_t)c0 : (size_t)b * n_cur_shared);       // per-problem scratch
         double qx = init_pose[3 * b], qy = init_pose[3 * b + 1], qphi = init_pose[3 * b + 2];
         float thr_d = O.thr_dist, thr_a = O.thr_ang;
         int iter = 0, n_pairs = 0;
@@ -91,14 +93,14 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
                         atomicMin(&owner[r0 + bj], ((unsigned long long)f2u(best) << 32) | (unsigned)i);
                     }
                 }
-                if (i < n2) match[c0 + i] = mj;
+                if (i < n2) match_b[i] = mj;
             }
             __syncthreads();
             // sums over the surviving pairs (a = first map, b = second map in its own frame)
             double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // n, xa, ya, xb, yb, xaxb, yayb, xayb, yaxb
             double sq = 0;
             for (int i = tid; i < n2; i += P2P_THREADS) {
-                const int j = match[c0 + i];
+                const int j = match_b[i];
                 if (j >= 0 && (unsigned)owner[r0 + j] == (unsigned)i) {
                     const double xa = ref_x[r0 + j], ya = ref_y[r0 + j], xb = cur_x[c0 + i], yb = cur_y[c0 + i];
                     s[0] += 1; s[1] += xa; s[2] += ya; s[3] += xb; s[4] += yb;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
             const double cc = cos(qphi), ss = sin(qphi);
             double h[4] = {0, 0, 0, 0};     // sum jx, sum jy, sum (jx^2 + jy^2), (n comes from n_pairs)
             for (int i = tid; i < n2; i += P2P_THREADS) {
-                const int j = match[c0 + i];
+                const int j = match_b[i];
                 if (j >= 0 && (unsigned)owner[r0 + j] == (unsigned)i) {
                     const double xb = cur_x[c0 + i], yb = cur_y[c0 + i];
                     const double jx = -(ss * xb + cc * yb), jy = cc * xb - ss * yb;

@@ -10,8 +10,25 @@
 // L2 / Infinity Cache, so the parallelism comes from the poses.  The beam model sums the per-beam
 // likelihoods in beam order (float accumulator, as the reference does).
 #include "lsa_device.h"
+#include "lsa_math.h"
 
 namespace lsa {
+
+// weight and relative pose of obsLikelyhood (:485-503) from the ICP result records
+__global__ void icp_goodness_extract_kernel(int P, const double* __restrict__ out16, float* __restrict__ weight, float* __restrict__ rel)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float w = (float)out16[16 * (size_t)p + 3];
+    weight[p] = w;
+    if (rel) for (int d = 0; d < 3; ++d) rel[3 * (size_t)p + d] = w > 0.5f ? (float)out16[16 * (size_t)p + d] : 0.0f;
+}
+
+__global__ void iota_scaled_kernel(int n, int scale, int* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i * scale;
+}
 
 struct SimParam {
     int size_x, size_y, center_x, center_y;
@@ -69,7 +86,8 @@ __device__ __forceinline__ double sim_beam_angle(const SimParam& S, float th, in
 
 __global__ __launch_bounds__(256) void sim_scans_kernel(SimParam S, const float* __restrict__ prob,
                                                         const float* __restrict__ poses, int P,
-                                                        float* __restrict__ r, uint8_t* __restrict__ bad)
+                                                        float* __restrict__ r, uint8_t* __restrict__ bad,
+                                                        float* __restrict__ x, float* __restrict__ y)
 {
     // one workgroup per pose; lane i walks the running angle A_i = A_0 - i AA exactly like the loop of :219
     for (int p = blockIdx.x; p < P; p += gridDim.x) {
@@ -77,8 +95,15 @@ __global__ __launch_bounds__(256) void sim_scans_kernel(SimParam S, const float*
         for (int i = threadIdx.x; i < S.n_beams; i += blockDim.x) {
             float rr; bool valid;
             sim_ray(S, prob, (double)px, (double)py, sim_beam_angle(S, th, i), rr, valid);
-            r[(size_t)p * S.n_beams + i] = rr;
-            bad[(size_t)p * S.n_beams + i] = valid ? 0 : 1;
+            if (r) r[(size_t)p * S.n_beams + i] = rr;
+            if (bad) bad[(size_t)p * S.n_beams + i] = valid ? 0 : 1;
+            if (x) {                                         // scan-frame points, :191-207 and :224-225
+                const double AA = (double)(S.fov / (float)(S.n_beams - 1));
+                const float begin = (float)(-LSA_ZPI / 4.0);
+                const float angle = (float)((double)begin + (double)i * AA);
+                x[(size_t)p * S.n_beams + i] = rr * cosf_(angle);
+                y[(size_t)p * S.n_beams + i] = rr * sinf_(angle);
+            }
         }
     }
 }

@@ -134,6 +134,9 @@ void orc_simulate_scan(const float* prob, int sx, int sy, int cx, int cy, float 
 void orc_beam_model(const float* prob, int sx, int sy, int cx, int cy, float offx, float offy, double res,
                     const float* poses, int P, const float* obs_r, const int* obs_bad, int n_beams,
                     float fov, float min_angle, float max_range, float* score);
+void orc_icp_goodness(const float* prob, int sx, int sy, int cx, int cy, float offx, float offy, double res,
+                      const float* poses, int P, const float* obs_x, const float* obs_y, int n_beams,
+                      float fov, float min_angle, float max_range, float* weight, float* rel);
 void orc_topk(const float* score, int n, int k, int* index);
 void orc_pf_estimate(const float* poses, const float* score, const int* index, int k,
                      double mean[3], double* mean_weight, double* mean_dis);

@@ -162,3 +162,30 @@ void orc_pf_roughen(int n, double K, const float* normals, float* poses)
         for (int i = 0; i < n; ++i) poses[3 * i + d] = (float)((double)poses[3 * i + d] + (double)normals[3 * i + d] * rootq);
     }
 }
+
+/* obsLikelyhood, VPmap.cpp:485-503: virtual scan -> scan-frame points (:191-207, :224-225) ->
+ * ICPMatch(virtual, observed, zero guess) with CICPWarpper's options; weight = goodness */
+void orc_icp_goodness(const float* prob, int sx, int sy, int cx, int cy, float offx, float offy, double res,
+                      const float* poses, int P, const float* obs_x, const float* obs_y, int n_beams,
+                      float fov, float min_angle, float max_range, float* weight, float* rel)
+{
+    float* r = (float*)malloc(sizeof(float) * n_beams);
+    float* x = (float*)malloc(sizeof(float) * n_beams);
+    float* y = (float*)malloc(sizeof(float) * n_beams);
+    int* bad = (int*)malloc(sizeof(int) * n_beams);
+    const double AA = fov / (float)(n_beams - 1);
+    const float begin = (float)(-Z_PI / 4.0);
+    for (int p = 0; p < P; ++p) {
+        orc_simulate_scan(prob, sx, sy, cx, cy, offx, offy, res, poses + 3 * p, n_beams, fov, min_angle, max_range, r, bad);
+        for (int i = 0; i < n_beams; ++i) {
+            const float angle = (float)((double)begin + (double)i * AA);
+            x[i] = r[i] * cosf(angle); y[i] = r[i] * sinf(angle);
+        }
+        const double init[3] = {0, 0, 0};
+        double out[16];
+        orc_p2p_icp(x, y, n_beams, obs_x, obs_y, n_beams, init, 100, 0.75f, (float)(10.0 * 3.14159265358979323846 / 180.0), 0.5f, 0.05f, out);
+        weight[p] = (float)out[3];
+        for (int d = 0; d < 3; ++d) rel[3 * p + d] = weight[p] > 0.5f ? (float)out[d] : 0.0f;
+    }
+    free(r); free(x); free(y); free(bad);
+}

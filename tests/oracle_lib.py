@@ -520,3 +520,13 @@ def pf_roughen(poses, K, normals):
     poses = np.ascontiguousarray(poses, f32).copy(); normals = np.ascontiguousarray(normals, f32)
     _orc().orc_pf_roughen(len(poses), C.c_double(K), _p(normals), _p(poses))
     return poses
+
+
+def icp_goodness(prob, cx, cy, offx, offy, res, poses, obs_x, obs_y, fov, min_angle, max_range):
+    prob = np.ascontiguousarray(prob, f32); poses = np.ascontiguousarray(poses, f32)
+    obs_x = np.ascontiguousarray(obs_x, f32); obs_y = np.ascontiguousarray(obs_y, f32)
+    w = np.zeros(len(poses), f32); rel = np.zeros((len(poses), 3), f32)
+    _orc().orc_icp_goodness(_p(prob), prob.shape[0], prob.shape[1], cx, cy, C.c_float(offx), C.c_float(offy),
+                            C.c_double(res), _p(poses), len(poses), _p(obs_x), _p(obs_y), len(obs_x),
+                            C.c_float(fov), C.c_float(min_angle), C.c_float(max_range), _p(w), _p(rel))
+    return w, rel

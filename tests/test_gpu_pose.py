@@ -204,3 +204,33 @@ def test_topk_estimate_predict_roughen(world):
     capi.pf_roughen(ctx, n, 0.2, d_n, d_q)
     ctx.sync()
     assert np.array_equal(d_q.cpu().numpy(), ol.pf_roughen(poses, 0.2, nrm))
+
+
+def test_icp_goodness_scorer(world):
+    """CVPmap::obsLikelyhood (the scorer the reference's PF calls): virtual scan + ICPMatch per pose,
+    against the oracle composition (sim_oracle.c + p2p_oracle.c).  Tolerances as for the p2p tests."""
+    torch, capi, ctx, fld = world["torch"], world["capi"], world["ctx"], world["fld"]
+    from oracle_lib import icp_goodness, simulate_scan
+    rng = np.random.default_rng(31)
+    prob, res = world["prob"], world["res"]
+    n = 181
+    true = np.array([6.0, 5.0, 0.4], np.float32)
+    r, bad = simulate_scan(prob, 0, 0, 0.0, 0.0, res, true, n, capi.SIM_FOV, capi.SIM_MIN_ANGLE, 30.0)
+    AA = np.float32(capi.SIM_FOV) / np.float32(n - 1)
+    ang = (np.float32(-3.141592654 / 4.0) + np.arange(n) * float(AA)).astype(np.float32)
+    obs_x, obs_y = (r * np.cos(ang)).astype(np.float32), (r * np.sin(ang)).astype(np.float32)
+    P = 24
+    poses = (true + np.concatenate([np.zeros((1, 3)), rng.normal(0, [0.15, 0.15, 0.05], (P - 2, 3)), [[-3, 3, 2.0]]])).astype(np.float32)
+    d_prob = torch.from_numpy(prob).cuda(); d_p = torch.from_numpy(poses).cuda()
+    d_ox, d_oy = torch.from_numpy(obs_x).cuda(), torch.from_numpy(obs_y).cuda()
+    d_w = torch.zeros(P, device="cuda"); d_rel = torch.zeros(P, 3, device="cuda")
+    torch.cuda.synchronize()
+    capi.icp_goodness_scores(fld, d_prob, d_p, P, d_ox, d_oy, n, d_w, d_rel)
+    ctx.sync()
+    w_g, rel_g = d_w.cpu().numpy(), d_rel.cpu().numpy()
+    w_o, rel_o = icp_goodness(prob, 0, 0, 0.0, 0.0, res, poses, obs_x, obs_y, capi.SIM_FOV, capi.SIM_MIN_ANGLE, 30.0)
+    assert np.allclose(w_g, w_o, atol=2.0 / n)                       # goodness = paired fraction: at most a pair or two apart
+    ok = (w_g > 0.5) & (w_o > 0.5)
+    assert ok.sum() >= P // 2 and np.allclose(rel_g[ok], rel_o[ok], atol=2e-3)
+    assert w_g[0] > 0.95 and np.abs(rel_g[0]).max() < 5e-3          # the true pose: everything pairs, no correction
+    assert w_g[-1] < w_g[0]
