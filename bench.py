@@ -290,6 +290,19 @@ def extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p):
     ms = timed(lambda: capi.beam_model_scores(fld, d_prob, d_p, P2, d_or, d_ob, nb2, d_s2), reps=2)
     res["beam_model_poses_per_s"] = P2 / (ms * 1e-3)
     res["beam_model_rays_per_s"] = P2 * nb2 / (ms * 1e-3)
+    # ICP-goodness scorer (obsLikelyhood): virtual 541-beam scan + point-to-point ICP per pose, 2048 poses
+    P3 = 2048
+    ang = (-3.141592654 / 4.0 + np.arange(nb2) * (4.712388981 / (nb2 - 1))).astype(np.float32)
+    d_r1 = torch.zeros(1, nb2, device="cuda"); d_b1 = torch.zeros(1, nb2, dtype=torch.uint8, device="cuda")
+    d_c = torch.tensor([[10.0, 7.5, 0.0]], device="cuda")
+    torch.cuda.synchronize()
+    capi.simulate_scans(fld, d_prob, d_c, 1, nb2, d_r1, d_b1); ctx.sync()
+    r1 = d_r1.cpu().numpy()[0]                      # the scan seen from the centre of the pose cloud
+    d_ox = torch.from_numpy((r1 * np.cos(ang)).astype(np.float32)).cuda(); d_oy = torch.from_numpy((r1 * np.sin(ang)).astype(np.float32)).cuda()
+    d_w3 = torch.zeros(P3, device="cuda")
+    torch.cuda.synchronize()
+    ms = timed(lambda: capi.icp_goodness_scores(fld, d_prob, d_p, P3, d_ox, d_oy, nb2, d_w3), reps=1)
+    res["icp_goodness_poses_per_s"] = P3 / (ms * 1e-3)
     t0 = time.perf_counter()
     capi.pose_topk(ctx, d_sc, P, 60)
     res["topk60_of_1M_ms"] = (time.perf_counter() - t0) * 1e3
