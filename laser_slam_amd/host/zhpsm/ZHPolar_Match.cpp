@@ -5,6 +5,8 @@
 #include "../../csrc/lsa_math.h"
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <stdexcept>
@@ -43,7 +45,7 @@ void must(int rc, const char* what)
 
 } // namespace
 
-CPolarMatch::CPolarMatch(string laser_name) : pm_fi(0), pm_si(0), pm_co(0), m_bReady(false), m_ctx(0), m_tableLen(0)
+CPolarMatch::CPolarMatch(string laser_name) : m_trajectory_path("zhnew.log"), pm_fi(0), pm_si(0), pm_co(0), m_bReady(false), m_ctx(0), m_tableLen(0)
 {
     m_pParam = paramByName(laser_name);
     if (m_pParam == NULL) {
@@ -379,6 +381,174 @@ bool CPolarMatch::pm_is_corridor(PMScan* act)
 }
 
 // ---- batched path (addition) -------------------------------------------------------
+// ---- offline drivers -----------------------------------------------------------------------
+void CPolarMatch::runFlirtFile(string filename, int run_num)           // :332-340
+{
+    if (!readFlirt(filename)) { cout << "failed to read file: " << filename << endl; return; }
+    runlog(run_num);
+}
+void CPolarMatch::runSICKFile(string filename, int run_num)            // :343-350
+{
+    if (!readSICK(filename)) { cout << "failed to read file: " << filename << endl; return; }
+    runlogImproved(run_num);
+}
+void CPolarMatch::runOurFile(string filename, int run_num)             // :353-360
+{
+    if (!readCarmon(filename)) { cout << "failed to read file: " << filename << endl; return; }
+    runlogImproved(run_num);
+}
+
+bool CPolarMatch::construct511Data(char* line, PMScan& scan)           // :649-667
+{
+    char* save = 0;
+    if (!strtok_r(line, " ", &save)) return false;                     // timestamp
+    char* tok = strtok_r(NULL, " ", &save);
+    const unsigned num = tok ? (unsigned)atoi(tok) : 0u;
+    if (num != (unsigned)m_pParam->pm_l_points) { cout << "failed to read sick 511!" << endl; return false; }
+    for (unsigned i = 0; i < num; ++i) {
+        tok = strtok_r(NULL, " ", &save);
+        scan.r[i] = (float)(atof(tok ? tok : "0") * 100.);
+        scan.x[i] = scan.r[i] * pm_co[i];
+        scan.y[i] = scan.r[i] * pm_si[i];
+        scan.bad[i] = 0;
+        if (scan.r[i] < m_pParam->pm_min_range) scan.r[i] = m_pParam->pm_max_range + 1;
+    }
+    return true;
+}
+
+// :449-647.  Frames whose odometry turned by more than 40 degrees, whose match failed, whose error
+// index exceeds 10 or which moved more than 1 m are bridged with the log's odometry.
+void CPolarMatch::runlog(int run_num)
+{
+    using zhpsm::OrientedPoint2D;
+    if (!m_bReady) { cout << "Laser is not initialized!" << endl; return; }
+    if (m_SickScans.empty()) { cout << "No record data is prepared!" << endl; return; }
+    ofstream out(m_trajectory_path.c_str());
+    if (!out.is_open()) cout << "failed to open output trajectory!" << endl;
+    if (run_num < 0) run_num = (int)m_SickScans.size() + 1;
+    const double odometry_thre = 0.6982, dis_squre_thre = 10000;
+    const float err_thre = 10;
+    double rx = 0, ry = 0, th = 0;                                      // global pose, cm / rad
+    PMScan* prev = 0;
+    OrientedPoint2D last_odo;
+    int n_gt = 0, n_angle = 0, n_err = 0;
+    for (int cnt = 0; cnt < (int)m_SickScans.size() && cnt < run_num; ++cnt) {
+        PMScan* ls = m_SickScans[cnt];
+        pm_preprocessScan(ls);
+        if (!prev) {
+            last_odo = OrientedPoint2D(ls->rx, ls->ry, ls->th);
+            rx = ls->rx * 100; ry = ls->ry * 100; th = ls->th;
+            prev = ls;
+            out << ls->rx << " " << ls->ry << " " << th << endl;
+            continue;
+        }
+        const OrientedPoint2D odo(ls->rx, ls->ry, ls->th);
+        // bridging with the odometry increment keeps the chain going
+        const bool big_turn = fabs(ls->th - th) > odometry_thre;
+        bool bridge = big_turn;
+        double xx = 0, yy = 0, tth = 0;
+        if (!bridge) {
+            ls->rx = prev->rx = 0; ls->ry = prev->ry = 0; ls->th = prev->th = 0;      // no prior
+            bool failed = false;
+            try {
+                pm_error_index2(prev, ls);
+                pm_psm(prev, ls);
+                pm_icp(prev, ls);
+                pm_error_index2(prev, ls);
+            } catch (int) { cerr << "Error caught: psm failed match at: " << cnt + 1 << endl; failed = true; }
+            if (failed) {
+                failed = false;
+                try { pm_icp(prev, ls); }
+                catch (int) { cerr << "Error caught: icp failed match at: " << cnt + 1 << endl; failed = true; }
+            }
+            const pair<float, float> e = pm_error_index2(prev, ls);
+            const float err_idx = sqrtf(e.first + e.second);
+            xx = ls->rx * cos(th) - ls->ry * sin(th) + rx;
+            yy = ls->rx * sin(th) + ls->ry * cos(th) + ry;
+            tth = th + ls->th;
+            const double rel_dis = (xx - rx) * (xx - rx) + (yy - ry) * (yy - ry);
+            bridge = err_idx > err_thre || rel_dis > dis_squre_thre || failed;
+            if (bridge) n_err++;
+        } else n_angle++;
+        if (bridge) {
+            const OrientedPoint2D trans(last_odo.ominus(odo));
+            const OrientedPoint2D cur = OrientedPoint2D(rx / 100.0, ry / 100.0, th).oplus(trans);
+            rx = cur.x * 100; ry = cur.y * 100; th = cur.theta;
+            if (big_turn) out << cur.x << " " << cur.y << " " << cur.theta << endl;
+            else out << (rx / 100.0) << " " << (ry / 100.0) << " " << th << endl;
+            n_gt++;
+        } else {
+            rx = xx; ry = yy; th = tth;
+            ls->rx = (float)xx; ls->ry = (float)yy; ls->th = (float)tth;
+            out << (xx / 100.0) << " " << (yy / 100.0) << " " << tth << endl;
+        }
+        prev = ls;
+        last_odo = odo;
+    }
+    out.close();
+    cout << "Number of GT: " << n_gt << endl;
+    cout << "Number for big angle: " << n_angle << endl;
+    cout << "Number for big err: " << n_err << endl;
+}
+
+// norm_a of the reference (ZHPolar_Match.h:77-87, sic: subtracts m * pi)
+static inline double run_norm_a(double a)
+{
+    const int m = (int)(a / (2.0 * M_PI));
+    a = a - (double)m * M_PI;
+    if (a < -M_PI) a += 2.0 * M_PI;
+    if (a >= M_PI) a -= 2.0 * M_PI;
+    return a;
+}
+
+// :736-852.  PSM against a reference scan that is kept until the match degrades (failure or an error
+// index above 5 cm), then switched to the previous scan; ICP when PSM fails twice.
+void CPolarMatch::runlogImproved(int run_num)
+{
+    if (!m_bReady) { cout << "Laser is not initialized!" << endl; return; }
+    if (m_SickScans.empty()) { cout << "No record data is prepared!" << endl; return; }
+    ofstream out(m_trajectory_path.c_str());
+    if (!out.is_open()) cout << "failed to open output trajectory!" << endl;
+    if (run_num < 0) run_num = (int)m_SickScans.size() + 1;
+    double rx = 0, ry = 0, th = 0, xx_last = 0, yy_last = 0, tth_last = 0;
+    PMScan *prev = 0, *ref = 0;
+    for (int cnt = 0; cnt < (int)m_SickScans.size() && cnt < run_num; ++cnt) {
+        PMScan* ls = m_SickScans[cnt];
+        pm_preprocessScan(ls);
+        if (!prev) { ls->rx = ls->ry = ls->th = 0; prev = ref = ls; continue; }
+        ls->rx = prev->rx; ls->ry = prev->ry; ls->th = prev->th;         // previous result as prior
+        ref->rx = ref->ry = ref->th = 0;
+        bool failed = false;
+        try { pm_psm(ref, ls); }
+        catch (int) { cerr << "Error caught: psm failed match at " << cnt + 1 << endl; failed = true; }
+        const pair<PM_TYPE, PM_TYPE> e = pm_error_index2(prev, ls);
+        if (failed || sqrtf(e.first + e.second) > 0.05f) {
+            printf(" Switching reference scan.\n");
+            ref = prev;
+            ls->rx = ls->ry = ls->th = 0;
+            ref->rx = ref->ry = ref->th = 0;
+            bool to_icp = false;
+            try { pm_psm(ref, ls); }
+            catch (int) { cerr << "psm failed again! switch to icp!" << endl; to_icp = true; }
+            if (to_icp) {
+                printf("switch to icp at: %d \n", cnt + 1);
+                try { pm_icp(ref, ls); }
+                catch (int) { cerr << "icp also failed at: " << cnt + 1 << endl; printf("Frame %d is discarded!\n", cnt + 1); continue; }
+            }
+            rx = xx_last; ry = yy_last; th = tth_last;
+            ref = prev;
+        }
+        const double xx = ls->rx * cos(th) - ls->ry * sin(th) + rx;
+        const double yy = ls->rx * sin(th) + ls->ry * cos(th) + ry;
+        const double tth = run_norm_a(th + ls->th);
+        out << xx << " " << yy << " " << tth << endl;
+        ls->rx = ls->ry = ls->th = 0;
+        prev = ls;
+        xx_last = xx; yy_last = yy; tth_last = tth;
+    }
+    out.close();
+}
+
 bool CPolarMatch::matchConsecutive(int which, vector<float>& poses, vector<int>& status)
 {
     syncParam();

@@ -8,6 +8,7 @@
 #include <utility>
 #include <vector>
 #include "PolarParameter.h"
+#include "point.h"
 using namespace std;
 
 struct lsa_ctx;
@@ -37,6 +38,18 @@ public:
     PM_TYPE pm_icp(const PMScan* lsr, PMScan* lsa);      // throws int on failure
     PM_TYPE point_line_distance(PM_TYPE x1, PM_TYPE y1, PM_TYPE x2, PM_TYPE y2, PM_TYPE x3, PM_TYPE y3,
                                 PM_TYPE* x, PM_TYPE* y);
+
+public:
+    // offline drivers (ZHPolar_Match.cpp:332-360, 449-647, 736-852): read a log, match every scan against
+    // its predecessor and write one "x y theta" line per accepted frame.  The reference writes to
+    // hard-coded /mnt/hgfs/SharedFold/... files; here the output goes to m_trajectory_path.
+    void runSICKFile(string filename, int run_num = -1);
+    void runFlirtFile(string filename, int run_num = -1);
+    void runOurFile(string filename, int run_num = -1);
+    bool construct511Data(char* line, PMScan& scan);        // "timestamp n r_1 .. r_n" [m], :649-667
+    void runlog(int run_num);                                // odometry-gated PSM+ICP chain, metres out
+    void runlogImproved(int run_num);                        // PSM with reference switching, ICP fallback, cm out
+    string m_trajectory_path;
 
 public:
     bool readSICK(string filename);

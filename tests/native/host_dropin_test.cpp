@@ -144,6 +144,15 @@ int main(int argc, char** argv)
 {
     if (argc >= 6 && !strcmp(argv[1], "match")) return run_match(argv[2], argv[3], argv[4], atoi(argv[5]));
     if (argc >= 4 && !strcmp(argv[1], "pmap")) return run_pmap(argv[2], argv[3]);
+    if (argc >= 7 && !strcmp(argv[1], "runlog")) {       // runlog <our|flirt> <laser> <log> <out> <n>
+        CPolarMatch m(argv[3]);
+        m.m_trajectory_path = argv[5];
+        // (runOurFile passes an empty laser name to readCarmon, which then matches no record - as in the
+        //  reference; the in-house log is therefore read with its tag and handed to the driver directly)
+        if (!strcmp(argv[2], "our")) { if (!m.readCarmon(argv[4], argv[3])) return 2; m.runlogImproved(atoi(argv[6])); }
+        else m.runFlirtFile(argv[4], atoi(argv[6]));
+        return 0;
+    }
     fprintf(stderr, "usage: host_dropin_test match <laser> <log> <tag> <n> | pmap <in> <out>\n");
     return 1;
 }

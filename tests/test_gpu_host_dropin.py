@@ -113,3 +113,58 @@ def test_cpmap_dropin(name, exe, tmp_path):
     cx = np.frombuffer(raw, np.float32, nc, 12 * cells + 4)
     cy = np.frombuffer(raw, np.float32, nc, 12 * cells + 4 + 4 * nc)
     assert same_bits(cx, z["cloud_x"]) and same_bits(cy, z["cloud_y"])
+
+
+def test_offline_driver_runlog_improved(exe, tmp_path):
+    """CPolarMatch::runOurFile -> runlogImproved (ZHPolar_Match.cpp:353-360, 736-852) on the in-house
+    LMS151 log: the trajectory file against the same driver logic replayed with the CPU oracle."""
+    from oracle_lib import Oracle
+    laser, fn, tag = SETS["indoor"]
+    n = 20
+    out = str(tmp_path / "traj.log")
+    res = subprocess.run([exe, "runlog", "our", laser, os.path.join(GOLDEN, fn), out, str(n)],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    got = np.loadtxt(out).reshape(-1, 3)
+    o = Oracle(laser)
+    r_all, _, _, bad_all, _ = o.read_carmen(os.path.join(GOLDEN, fn), tag)
+    PI = 3.141592654
+
+    def norm_a(a):
+        m = int(a / (2.0 * PI)); a = a - m * PI
+        if a < -PI: a += 2.0 * PI
+        if a >= PI: a -= 2.0 * PI
+        return a
+
+    rx = ry = th = 0.0
+    last = (0.0, 0.0, 0.0)
+    prev = ref = None
+    want = []
+    for k in range(min(n, len(r_all))):
+        ls = o.preprocess(r_all[k], bad_all[k])
+        if prev is None:
+            prev = ref = ls
+            continue
+        st, pose, _, _ = o.match(0, ref, ls)
+        failed = st != 0
+        if failed:
+            pose = np.zeros(3, np.float32)
+        exy, _ = o.error_index2(prev, ls, (0, 0, 0), pose)
+        if failed or np.sqrt(np.float32(exy[0] + exy[1])) > np.float32(0.05):
+            ref = prev
+            st, pose, _, _ = o.match(0, ref, ls)
+            if st != 0:
+                st, pose, _, _ = o.match(1, ref, ls)
+                if st != 0:
+                    continue
+            rx, ry, th = last
+            ref = prev
+        xx = float(pose[0]) * np.cos(th) - float(pose[1]) * np.sin(th) + rx
+        yy = float(pose[0]) * np.sin(th) + float(pose[1]) * np.cos(th) + ry
+        tth = norm_a(th + float(pose[2]))
+        want.append((xx, yy, tth))
+        prev = ls
+        last = (xx, yy, tth)
+    want = np.array(want)
+    assert got.shape == want.shape and len(want) >= n - 3
+    assert np.allclose(got, want, rtol=2e-5, atol=2e-5)          # the file holds 6 significant digits
