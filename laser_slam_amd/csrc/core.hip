@@ -679,8 +679,8 @@ int lsa_grid_update_batch(lsa_grid* g, int S, int n_beams, const float* d_gx, co
             HIP_TRY(hipMalloc((void**)&g->d_blk, (size_t)S * nblk * sizeof(int4)));
             g->blk_cap = (size_t)S * nblk;
         }
-        if (!g->d_bbox) HIP_TRY(hipMalloc((void**)&g->d_bbox, 4 * sizeof(int)));
-        static const int bbox0[4] = {INT_MAX, INT_MAX, INT_MIN, INT_MIN};
+        if (!g->d_bbox) HIP_TRY(hipMalloc((void**)&g->d_bbox, 8 * sizeof(int)));
+        static const int bbox0[8] = {INT_MAX, INT_MAX, INT_MIN, INT_MIN, 0, 0, 0, 0};      // box, work-item counter
         HIP_TRY(hipMemcpyAsync(g->d_bbox, bbox0, sizeof bbox0, hipMemcpyHostToDevice, g->c->stream));
         hipLaunchKernelGGL(lsa::grid_prep_kernel, dim3(S < 8192 ? S : 8192), dim3(256), 0, g->c->stream, g->G, S, n_beams,
                            d_gx, d_gy, d_robot_xy, d_n_valid, g->d_ends, g->d_info, g->d_blk, g->d_bbox);

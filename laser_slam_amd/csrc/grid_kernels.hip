@@ -282,7 +282,11 @@ __device__ __forceinline__ void own_walk(const GridParam& G, uint32_t* lh, uint3
         bool ok = (unsigned)(minor - N0) < (unsigned)OWN_T && cc != robot_cc;
         if (!inside) ok = ok && inb(G, x_major ? m0 + t : minor, x_major ? minor : m0 + t);
         if (ok) {
+#ifdef LSA_GRID_DIAG_NOCONFLICT        // diagnostics (wrong counts): what same-address LDS adds cost
+            atomicAdd(&ls[(cc + (int)(threadIdx.x & 63) * 67) & (OWN_T * OWN_T - 1)], 1u);
+#else
             atomicAdd(&ls[cc], 1u);                                                      // :87
+#endif
             if (t == len) atomicAdd(&lh[cc], 1u);                                        // last generated cell, :84-86
         }
         cc += c_major;
@@ -292,7 +296,8 @@ __device__ __forceinline__ void own_walk(const GridParam& G, uint32_t* lh, uint3
 
 __global__ __launch_bounds__(256) void grid_owned_kernel(
     GridParam G, int S, int n_beams, const int2* __restrict__ ends, const ScanInfo* __restrict__ info,
-    const int4* __restrict__ blk, const int* __restrict__ bbox, int splits_req, uint32_t* __restrict__ hit, uint32_t* __restrict__ sum)
+    const int4* __restrict__ blk, int* __restrict__ bbox /* [0..3] box, [4] item counter */, int splits_req,
+    uint32_t* __restrict__ hit, uint32_t* __restrict__ sum)
 {
     __shared__ uint32_t lh[OWN_T * OWN_T], ls[OWN_T * OWN_T];
     __shared__ ScanInfo cand[OWN_CHUNK];
@@ -312,7 +317,15 @@ __global__ __launch_bounds__(256) void grid_owned_kernel(
         if (splits < 1) splits = 1;
     }
     if (splits > S) splits = S;
-    for (int item = blockIdx.x; item < nt * splits; item += gridDim.x) {
+    // items are claimed from a counter (bbox[4], zeroed with the box) so that a workgroup that drew a
+    // light tile moves on: the work per item differs by orders of magnitude
+    __shared__ int next_item;
+    for (;;) {
+    __syncthreads();
+    if (tid == 0) next_item = atomicAdd((int*)&bbox[4], 1);
+    __syncthreads();
+    const int item = next_item;
+    if (item >= nt * splits) break;
     const int tile = item % nt, part = item / nt;
     const int X0 = (bx0 + tile / nty) * OWN_T, Y0 = (by0 + tile % nty) * OWN_T;
     const int X1 = X0 + OWN_T - 1, Y1 = Y0 + OWN_T - 1;
