@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) void grid_update_tile_kernel(
 struct ScanInfo { int sx, sy, xmin, xmax, ymin, ymax, nb, nh, s, pad; };   // nh: rays whose last generated cell is the robot cell
 
 constexpr int OWN_T = 64;               // cells per owned tile side (2 x 16 KiB of LDS)
-constexpr int OWN_CHUNK = 256;          // scans looked at per culling round
+constexpr int OWN_CHUNK = 256;          // scans looked at per culling round (fewer when a scan has many blocks)
+constexpr int OWN_LIST = 256 * 17;      // candidate blocks per round
 
 __global__ __launch_bounds__(256) void grid_prep_kernel(
     GridParam G, int S, int n_beams, const float* __restrict__ gx, const float* __restrict__ gy,
@@ -301,7 +302,8 @@ __global__ __launch_bounds__(256) void grid_owned_kernel(
 {
     __shared__ uint32_t lh[OWN_T * OWN_T], ls[OWN_T * OWN_T];
     __shared__ ScanInfo cand[OWN_CHUNK];
-    __shared__ int ncand;
+    __shared__ uint16_t list[OWN_LIST];             // (scan of the round << 8) | block
+    __shared__ int nlist;
     const int tid = threadIdx.x, lane = tid & 63;
     // work items = (tile of the batch's bounding box, share of the scans); the launch is a fixed number of
     // workgroups that stride over them (launching one workgroup per tile of a 4096^2 grid costs more
@@ -334,63 +336,58 @@ __global__ __launch_bounds__(256) void grid_owned_kernel(
     for (int k = tid; k < OWN_T * OWN_T; k += blockDim.x) { lh[k] = 0; ls[k] = 0; }
     const int s_lo = (int)((long long)S * part / splits), s_hi = (int)((long long)S * (part + 1) / splits);
     bool touched = false;
-    for (int c0 = s_lo; c0 < s_hi; c0 += OWN_CHUNK) {
+    const int wave = tid >> 6, nblk = (n_beams + 63) >> 6;
+    const int chunk = OWN_LIST / nblk < OWN_CHUNK ? OWN_LIST / nblk : OWN_CHUNK;     // scans per round: the list holds all their blocks
+    for (int c0 = s_lo; c0 < s_hi; c0 += chunk) {
+        const int ns = s_hi - c0 < chunk ? s_hi - c0 : chunk;
         __syncthreads();
-        if (tid == 0) ncand = 0;
-        __syncthreads();
-        // culling round: the scans of this chunk whose bounding box meets the tile
-        {
-            const int s = c0 + tid;
-            ScanInfo si = {};
-            bool ov = false;
-            if (s < s_hi) {
-                si = info[s];
-                ov = !(si.xmax < X0 || si.xmin > X1 || si.ymax < Y0 || si.ymin > Y1);
-            }
-            const unsigned long long m = __ballot(ov);
-            int base = 0;
-            if (lane == 0 && m) base = atomicAdd(&ncand, __popcll(m));
-            base = __shfl(base, 0);
-            if (ov) {
-                cand[base + prefix_popc(m)] = si;
-                // all rays of a scan meet in its robot cell: that cell gets its totals here, the walks skip it
-                if (si.sx >= X0 && si.sx <= X1 && si.sy >= Y0 && si.sy <= Y1 && inb(G, si.sx, si.sy)) {
-                    const int cc = (si.sx - X0) * OWN_T + (si.sy - Y0);
-                    if (si.nb) atomicAdd(&ls[cc], (uint32_t)si.nb);
-                    if (si.nh) atomicAdd(&lh[cc], (uint32_t)si.nh);
-                }
+        if (tid == 0) nlist = 0;
+        // the round's scans: header into LDS; all rays of a scan meet in its robot cell - that cell gets
+        // its totals here and the walks skip it
+        if (tid < ns) {
+            const ScanInfo si = info[c0 + tid];
+            cand[tid] = si;
+            if (si.sx >= X0 && si.sx <= X1 && si.sy >= Y0 && si.sy <= Y1 && inb(G, si.sx, si.sy)) {
+                const int cc = (si.sx - X0) * OWN_T + (si.sy - Y0);
+                if (si.nb) atomicAdd(&ls[cc], (uint32_t)si.nb);
+                if (si.nh) atomicAdd(&lh[cc], (uint32_t)si.nh);
             }
         }
         __syncthreads();
-        const int nc = ncand;
-        if (nc) touched = true;
-        // Each wave takes candidate scans on its own.  A scan's rays come in blocks of 64 consecutive beams
-        // with their own bounding boxes (grid_prep_kernel): the lanes test one block each, and only the
-        // blocks that meet the tile are walked, 64 rays at a time; the next block's end cells are in flight
-        // while the current block is walked.
-        const int wave = tid >> 6, nblk = (n_beams + 63) >> 6;
-        for (int q = wave; q < nc; q += 4) {
-            const int s = cand[q].s, sx = cand[q].sx, sy = cand[q].sy, nb = cand[q].nb;
-            const bool rin = sx >= X0 && sx <= X1 && sy >= Y0 && sy <= Y1;
+        // culling: every (scan, 64-beam block) whose bounding box (grid_prep_kernel) meets the tile goes to a list
+        for (int pr = tid; pr < ((ns * nblk + 63) & ~63); pr += blockDim.x) {
             bool ov = false;
-            if (lane < nblk) {
-                const int4 bb = blk[(size_t)s * nblk + lane];
+            if (pr < ns * nblk) {
+                const int4 bb = blk[(size_t)c0 * nblk + pr];               // the round's boxes are contiguous
                 ov = !(bb.y < X0 || bb.x > X1 || bb.w < Y0 || bb.z > Y1);
             }
-            unsigned long long m = __ballot(ov);
-            if (!m) continue;
-            int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            int2 e = 64 * b + lane < nb ? ends[(size_t)s * n_beams + 64 * b + lane] : make_int2(0, 0);
-            while (true) {
-                const int bn = m ? __ffsll((long long)m) - 1 : -1;
-                m &= m - 1;
-                int2 en = make_int2(0, 0);
-                if (bn >= 0 && 64 * bn + lane < nb) en = ends[(size_t)s * n_beams + 64 * bn + lane];
-                if (64 * b + lane < nb) own_walk(G, lh, ls, X0, Y0, inside, sx, sy, rin, e.x, e.y);
-                if (bn < 0) break;
-                b = bn; e = en;
+            const unsigned long long m = __ballot(ov);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(&nlist, __popcll(m));
+            base = __shfl(base, 0);
+            if (ov) list[base + prefix_popc(m)] = (uint16_t)(((pr / nblk) << 8) | (pr % nblk));
+        }
+        __syncthreads();
+        const int nl = nlist;
+        if (nl) touched = true;
+        // every wave walks listed blocks, 64 rays at a time; the next block's end cells are in flight meanwhile
+        int q = wave;
+        int2 e = make_int2(0, 0);
+        if (q < nl) {
+            const int j = list[q] >> 8, bk = list[q] & 255;
+            if (64 * bk + lane < cand[j].nb) e = ends[(size_t)cand[j].s * n_beams + 64 * bk + lane];
+        }
+        for (; q < nl; q += 4) {
+            const int j = list[q] >> 8, bk = list[q] & 255;
+            int2 en = make_int2(0, 0);
+            if (q + 4 < nl) {
+                const int jn = list[q + 4] >> 8, bn = list[q + 4] & 255;
+                if (64 * bn + lane < cand[jn].nb) en = ends[(size_t)cand[jn].s * n_beams + 64 * bn + lane];
             }
+            const int sx = cand[j].sx, sy = cand[j].sy;
+            const bool rin = sx >= X0 && sx <= X1 && sy >= Y0 && sy <= Y1;
+            if (64 * bk + lane < cand[j].nb) own_walk(G, lh, ls, X0, Y0, inside, sx, sy, rin, e.x, e.y);
+            e = en;
         }
     }
     __syncthreads();
