@@ -313,8 +313,8 @@ __global__ __launch_bounds__(256) void grid_owned_kernel(
     if (bbox[2] < 0 || bbox[3] < 0 || bbox[0] >= G.size_x || bbox[1] >= G.size_y || bx1 < bx0 || by1 < by0) return;
     const int ntx = bx1 - bx0 + 1, nty = by1 - by0 + 1, nt = ntx * nty;
     int splits = splits_req;
-    if (splits <= 0) {                      // about 32 scans per item (measured: 2048 scans, 64-128 shares per tile)
-        splits = S / 32;
+    if (splits <= 0) {                      // about 16 scans per item (measured: 2048 scans, 128 shares per tile)
+        splits = S / 16;
         if (splits > 128) splits = 128;
         if (splits < 1) splits = 1;
     }
