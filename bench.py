@@ -230,6 +230,17 @@ def extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p):
     """Secondary kernels of the path, timed the same way (not the headline)."""
     from laser_slam_amd import synth
     res = {}
+    # point-to-line ICP (CCanonicalMatcher / zhcsm's matcher), raw scans, 4096 pairs
+    Bp = 4096
+    d_raw = torch.from_numpy(raw).cuda()
+    d_o8 = torch.zeros(Bp, 8, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    capi.plicp_batch(ctx, Bp, d_raw, d_ri[:Bp].contiguous(), d_ai[:Bp].contiguous(), d_o8); ctx.sync()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); capi.plicp_batch(ctx, Bp, d_raw, d_ri[:Bp].contiguous(), d_ai[:Bp].contiguous(), d_o8); b.record()
+    torch.cuda.synchronize()
+    res["plicp_matches_per_s"] = Bp / (a.elapsed_time(b) * 1e-3)
+    res["plicp_mean_iterations"] = float(d_o8[:, 5].mean().item())
     pose = torch.zeros(B, 3, device="cuda")
 
     def timed(fn, reps=3):

@@ -253,6 +253,27 @@ int lsa_beam_model_scores(lsa_field* f, const float* d_prob, const float* d_pose
                           const uint8_t* d_obs_bad, int n_beams, float fov, float min_angle, float max_range,
                           float* d_score);
 
+/* ---- point-to-line ICP between two scans: CCanonicalMatcher, src/zhcsm/ZHCanonical_Matcher.{h,cpp}
+ *      (forwards to CSM's sm_icp — third-party, PARITY UNPINNED; the options are those the
+ *      reference sets, ZHCanonical_Matcher.cpp:96-155) ---- */
+typedef struct lsa_plicp_options {
+    double max_angular_correction_deg, max_linear_correction;     /* 45 deg, 0.5 m */
+    int32_t max_iterations;                                        /* 10 */
+    double epsilon_xy, epsilon_theta, max_correspondence_dist;    /* 1e-3 m, 1e-3 rad, 2 m */
+    int32_t restart;                                               /* 1 */
+    double restart_threshold_mean_error, restart_dt, restart_dtheta;   /* 0.01, 0.01 m, 0.0261799 rad */
+    double outliers_maxPerc, outliers_adaptive_order, outliers_adaptive_mult;   /* 0.95, 0.7, 2.0 */
+    int32_t outliers_remove_doubles;                               /* 1 */
+} lsa_plicp_options;
+int lsa_plicp_options_default(lsa_plicp_options* o);
+/* pairs (ref_idx[b], act_idx[b]) of the scan set d_r [S][points] (ranges in cm, as PMScan::r; bearings and
+ * range limits from the context's laser parameters); first guess 0.  d_out8[b] = x, y [m], theta [rad]
+ * of the current scan in the reference scan's frame, valid, total error, iterations, kept correspondences, 0 */
+int lsa_plicp_batch(lsa_ctx* c, int n_pairs, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
+                    const lsa_plicp_options* opt, double* d_out8);
+/* CCanonicalMatcher::FMatch(LDP, LDP) (ZHCanonical_Matcher.cpp:248-284) for one pair of host scans */
+int lsa_plicp_host(lsa_ctx* c, const float* h_ref_r, const float* h_cur_r, const lsa_plicp_options* opt, double h_out8[8]);
+
 /* ---- point-to-point ICP on 2D point clouds: CICPWarpper, src/zhicp/ZHIcp_Warpper.{h,cpp}
  *      (forwards to MRPT 0.9.6 CICP::Align, icpClassic — third-party, PARITY UNPINNED) ---- */
 typedef struct lsa_p2p_options {

@@ -105,6 +105,8 @@ def lib():
     L.lsa_pf_roughen.argtypes = [vp, C.c_int, C.c_double, vp, vp]
     L.lsa_simulate_scans.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp]
     L.lsa_beam_model_scores.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, vp]
+    L.lsa_plicp_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    L.lsa_plicp_host.argtypes = [vp, vp, vp, vp, vp]
     L.lsa_icp_goodness_scores.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp, vp]
     L.lsa_gather_poses.argtypes = [vp, vp, vp, C.c_int, vp]
     L.lsa_p2p_icp_host.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp]
@@ -464,6 +466,18 @@ def pf_resample(ctx, d_w, P, u0, n_total, first, M, d_parent):
 
 def gather_poses(ctx, d_src, d_parent, M, d_dst):
     check(lib().lsa_gather_poses(ctx.h, _dp(d_src), _dp(d_parent), M, _dp(d_dst)), "lsa_gather_poses")
+
+
+def plicp_batch(ctx, B, d_r, d_ref_idx, d_act_idx, d_out8):
+    """CCanonicalMatcher's point-to-line ICP for B pairs of the device scan set d_r (cm); d_out8 [B][8] doubles."""
+    check(lib().lsa_plicp_batch(ctx.h, B, _dp(d_r), _dp(d_ref_idx), _dp(d_act_idx), None, _dp(d_out8)), "lsa_plicp_batch")
+
+
+def plicp_host(ctx, ref_r, cur_r):
+    a, b = np.ascontiguousarray(ref_r, np.float32), np.ascontiguousarray(cur_r, np.float32)
+    out = np.zeros(8, np.float64)
+    check(lib().lsa_plicp_host(ctx.h, _hp(a), _hp(b), None, _hp(out)), "lsa_plicp_host")
+    return out
 
 
 def p2p_icp_host(ctx, ref_x, ref_y, cur_x, cur_y, init_pose):

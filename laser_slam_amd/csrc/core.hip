@@ -17,6 +17,7 @@
 #include "pose_kernels.hip"
 #include "sim_kernels.hip"
 #include "p2p_kernels.hip"
+#include "plicp_kernels.hip"
 
 static thread_local std::string g_err;
 
@@ -1137,6 +1138,65 @@ int lsa_gather_poses(lsa_ctx* c, const float* d_src, const int32_t* d_parent, in
     return LSA_OK;
 }
 
+
+// ---- point-to-line ICP between scans (CCanonicalMatcher -> CSM sm_icp) -------------------
+int lsa_plicp_options_default(lsa_plicp_options* o)                  // ZHCanonical_Matcher.cpp:96-155
+{
+    if (!o) return fail(LSA_E_ARG, "null argument");
+    o->max_angular_correction_deg = 45; o->max_linear_correction = 0.5; o->max_iterations = 10;
+    o->epsilon_xy = 0.001; o->epsilon_theta = 0.001; o->max_correspondence_dist = 2;
+    o->restart = 1; o->restart_threshold_mean_error = 0.01; o->restart_dt = 0.01; o->restart_dtheta = 0.0261799;
+    o->outliers_maxPerc = 0.95; o->outliers_adaptive_order = 0.7; o->outliers_adaptive_mult = 2.0;
+    o->outliers_remove_doubles = 1;
+    return LSA_OK;
+}
+
+int lsa_plicp_batch(lsa_ctx* c, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
+                    const lsa_plicp_options* opt, double* d_out8)
+{
+    if (!c || !d_r || !d_ref_idx || !d_act_idx || !d_out8) return fail(LSA_E_ARG, "null argument");
+    if (B <= 0) return LSA_OK;
+    lsa_plicp_options o;
+    if (opt) o = *opt; else lsa_plicp_options_default(&o);
+    if (o.max_iterations < 1 || !(o.max_correspondence_dist > 0)) return fail(LSA_E_ARG, "bad point-to-line ICP options");
+    HIP_TRY(hipSetDevice(c->device));
+    lsa::PlicpParam P{};
+    P.n = c->p.points; P.fi_min = c->p.fi_min; P.dfi = c->p.dfi; P.min_range_cm = c->p.min_range; P.max_range_cm = c->p.max_range;
+    P.max_angular_correction_deg = o.max_angular_correction_deg; P.max_linear_correction = o.max_linear_correction;
+    P.max_iterations = o.max_iterations; P.epsilon_xy = o.epsilon_xy; P.epsilon_theta = o.epsilon_theta;
+    P.max_correspondence_dist = o.max_correspondence_dist; P.restart = o.restart;
+    P.restart_threshold_mean_error = o.restart_threshold_mean_error; P.restart_dt = o.restart_dt; P.restart_dtheta = o.restart_dtheta;
+    P.outliers_maxPerc = o.outliers_maxPerc; P.outliers_adaptive_order = o.outliers_adaptive_order;
+    P.outliers_adaptive_mult = o.outliers_adaptive_mult; P.outliers_remove_doubles = o.outliers_remove_doubles;
+    static bool once = false;
+    if (!once) { once = true; HIP_TRY(hipFuncSetAttribute((const void*)lsa::plicp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
+    hipLaunchKernelGGL(lsa::plicp_kernel, dim3(B), dim3(lsa::PLICP_THREADS), lsa::plicp_lds_bytes(P.n), c->stream, P, B, d_r,
+                       d_ref_idx, d_act_idx, d_out8);
+    HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+
+// CCanonicalMatcher::FMatch(LDP, LDP) for one host pair: ranges in cm as in PMScan (the caller median-filters)
+int lsa_plicp_host(lsa_ctx* c, const float* ref_r, const float* cur_r, const lsa_plicp_options* opt, double out8[8])
+{
+    if (!c || !ref_r || !cur_r || !out8) return fail(LSA_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_staging(c); if (rc) return rc;
+    const int n = c->p.points;
+    HIP_TRY(hipMemcpyAsync(c->d_r, ref_r, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_r + n, cur_r, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    const int32_t idx[2] = {0, 1};
+    HIP_TRY(hipMemcpyAsync(c->d_idx, idx, sizeof idx, hipMemcpyHostToDevice, c->stream));
+    double* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_out, sizeof(double) * 8));
+    rc = lsa_plicp_batch(c, 1, c->d_r, c->d_idx, c->d_idx + 1, opt, d_out);
+    hipError_t e = hipSuccess;
+    if (rc == LSA_OK) { e = hipMemcpyAsync(out8, d_out, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream); if (e == hipSuccess) e = hipStreamSynchronize(c->stream); }
+    hipFree(d_out);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(LSA_E_HIP, "plicp", e);
+    return LSA_OK;
+}
 
 // ---- point-to-point ICP on point clouds (CICPWarpper) ----------------------------------
 int lsa_p2p_options_default(lsa_p2p_options* o)

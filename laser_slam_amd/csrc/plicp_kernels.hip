@@ -1,0 +1,312 @@
+// Point-to-line ICP between two laser scans on gfx950 - the arithmetic behind the reference's
+// CCanonicalMatcher (src/zhcsm/ZHCanonical_Matcher.{h,cpp}), which forwards to CSM's `sm_icp`
+// (A. Censi's C Scan Matcher, an un-vendored third-party library => PARITY UNPINNED).
+// This restates the published algorithm (A. Censi, "An ICP variant using a point-to-line metric",
+// ICRA 2008) in the structure of CSM's loop for exactly the options of ZHCanonical_Matcher.cpp:96-155;
+// the checker is oracle/plicp_oracle.c, whose header lists the steps.
+//
+// One 256-thread workgroup per scan pair, everything in double like CSM; both scans' Cartesian
+// points, the moved points and the correspondence records live in LDS (9 doubles-worth per beam).
+// Sums use a fixed-order tree, the order statistics of the trimming are found by rank counting.
+#include "lsa_device.h"
+
+namespace lsa {
+
+struct PlicpParam {
+    int n;
+    float fi_min, dfi;
+    int min_range_cm, max_range_cm;
+    double max_angular_correction_deg, max_linear_correction;
+    int max_iterations;
+    double epsilon_xy, epsilon_theta, max_correspondence_dist;
+    int restart;
+    double restart_threshold_mean_error, restart_dt, restart_dtheta;
+    double outliers_maxPerc, outliers_adaptive_order, outliers_adaptive_mult;
+    int outliers_remove_doubles;
+};
+
+constexpr int PLICP_THREADS = 256;
+__host__ __device__ inline int plicp_lds_bytes(int n) { int Np = (n + 63) & ~63; return Np * (8 * 8 + 4 + 4) + 1024; }
+
+struct PlicpLds {
+    double *rx, *ry, *sx, *sy, *wx, *wy, *d2, *dist;      // ref / sens / moved points, NN distance^2, segment distance
+    int* corr;                                             // j1 | j2 << 16, -1 = none
+    uint8_t *rvalid, *svalid;
+    unsigned long long* dj;                                // aliases `dist` during the doubles test
+    double* red;                                           // reduction scratch, broadcast slots, remembered hashes
+};
+
+__device__ __forceinline__ double plicp_block_sum(double v, double* red)
+{
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ __forceinline__ double plicp_dist2(double ax, double ay, double bx, double by) { return (ax - bx) * (ax - bx) + (ay - by) * (ay - by); }
+
+__device__ __forceinline__ double plicp_seg_dist(double ax, double ay, double bx, double by, double x, double y)
+{
+    const double t0 = ax - bx, t1 = ay - by;
+    const double one_on_r = 1 / sqrt(t0 * t0 + t1 * t1);
+    const double cs = t1 * one_on_r, sn = -t0 * one_on_r;
+    const double rho = cs * ax + sn * ay;
+    double qx = cs * rho + sn * sn * x - cs * sn * y;
+    double qy = sn * rho - cs * sn * x + cs * cs * y;
+    if (!((qx - ax) * (qx - bx) + (qy - ay) * (qy - by) < 0)) {
+        if (plicp_dist2(ax, ay, x, y) < plicp_dist2(bx, by, x, y)) { qx = ax; qy = ay; } else { qx = bx; qy = by; }
+    }
+    return sqrt(plicp_dist2(qx, qy, x, y));
+}
+
+__device__ bool plicp_quartic_largest_root(double a3, double a2, double a1, double a0, double& root)
+{
+    double m = fabs(a3);
+    m = fabs(a2) > m ? fabs(a2) : m; m = fabs(a1) > m ? fabs(a1) : m; m = fabs(a0) > m ? fabs(a0) : m;
+    double l = 1 + m;
+    for (int it = 0; it < 200; ++it) {
+        const double p = (((l + a3) * l + a2) * l + a1) * l + a0;
+        const double dp = ((4 * l + 3 * a3) * l + 2 * a2) * l + a1;
+        if (!(dp > 0)) break;
+        const double nl = l - p / dp;
+        if (!(nl < l)) { l = nl; break; }
+        if (l - nl <= 1e-15 * (fabs(l) + 1e-300)) { l = nl; break; }
+        l = nl;
+    }
+    root = l;
+    const double p = (((l + a3) * l + a2) * l + a1) * l + a0;
+    return isfinite(l) && fabs(p) <= 1e-6 * (1 + m * (1 + fabs(l)) * (1 + l * l));
+}
+
+// one icp_loop from q0; returns ok, x_new, total error, kept correspondences, iterations (all uniform)
+__device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double q0[3], double x_new[3], double& total_error,
+                           int& nvalid, int& iterations)
+{
+    const int n = P.n, tid = threadIdx.x;
+    const double PI = 3.14159265358979323846;
+    double x_old[3] = {q0[0], q0[1], q0[2]};
+    uint32_t* hashes = (uint32_t*)(L.red + 64);            // up to 64 remembered correspondence sets
+    const double min_theta = (double)(P.fi_min + P.dfi * 0), max_theta = (double)(P.fi_min + P.dfi * (n - 1));
+    const double angle_res = (max_theta - min_theta) / n;
+    bool ok = true;
+    int it;
+    for (it = 0; it < P.max_iterations; ++it) {
+        const double cs = cos(x_old[2]), sn = sin(x_old[2]);
+        // moved points and correspondences
+        int mine = 0;
+        for (int i = tid; i < n; i += PLICP_THREADS) {
+            int rec = -1;
+            double best = 0;
+            if (L.svalid[i]) {
+                const double wx = cs * L.sx[i] - sn * L.sy[i] + x_old[0], wy = sn * L.sx[i] + cs * L.sy[i] + x_old[1];
+                L.wx[i] = wx; L.wy[i] = wy;
+                const double delta = fabs(P.max_angular_correction_deg * (PI / 180.0)) + fabs(atan(P.max_linear_correction / sqrt(wx * wx + wy * wy)));
+                const int range = (int)ceil(delta / angle_res);
+                double start_theta = atan2(wy, wx);
+                if (start_theta < min_theta) start_theta += 2 * PI;
+                if (start_theta > max_theta) start_theta -= 2 * PI;
+                const int start_cell = (int)((start_theta - min_theta) / (max_theta - min_theta) * n);
+                int from = start_cell - range, to = start_cell + range;
+                from = from < 0 ? 0 : (from > n - 1 ? n - 1 : from); to = to < 0 ? 0 : (to > n - 1 ? n - 1 : to);
+                int j1 = -1;
+                const double lim = P.max_correspondence_dist * P.max_correspondence_dist;
+                for (int j = from; j <= to; ++j) {
+                    if (!L.rvalid[j]) continue;
+                    const double d = plicp_dist2(wx, wy, L.rx[j], L.ry[j]);
+                    if (d > lim) continue;
+                    if (j1 == -1 || d < best) { j1 = j; best = d; }
+                }
+                if (!(j1 == -1 || j1 == 0 || j1 == n - 1)) {
+                    int up = -1, down = -1;
+                    for (int j = j1 + 1; j < n; ++j) if (L.rvalid[j]) { up = j; break; }
+                    for (int j = j1 - 1; j >= 0; --j) if (L.rvalid[j]) { down = j; break; }
+                    int j2 = -1;
+                    if (up == -1) j2 = down;
+                    else if (down == -1) j2 = up;
+                    else j2 = plicp_dist2(wx, wy, L.rx[up], L.ry[up]) < plicp_dist2(wx, wy, L.rx[down], L.ry[down]) ? up : down;
+                    if (j2 >= 0) { rec = j1 | (j2 << 16); mine++; }
+                }
+            }
+            L.corr[i] = rec; L.d2[i] = best;
+        }
+        const int num = (int)plicp_block_sum((double)mine, L.red);
+        const double fail_perc = 0.05;
+        if (num < fail_perc * n) { ok = false; break; }
+        if (P.outliers_remove_doubles) {                    // keep the points within 3x the best distance of their reference point
+            for (int j = tid; j < n; j += PLICP_THREADS) L.dj[j] = (unsigned long long)__double_as_longlong(1000000.0);
+            __syncthreads();
+            for (int i = tid; i < n; i += PLICP_THREADS)
+                if (L.corr[i] >= 0) atomicMin(&L.dj[L.corr[i] & 0xffff], (unsigned long long)__double_as_longlong(L.d2[i]));   // d2 >= 0
+            __syncthreads();
+            for (int i = tid; i < n; i += PLICP_THREADS)
+                if (L.corr[i] >= 0 && L.d2[i] > 9.0 * __longlong_as_double((long long)L.dj[L.corr[i] & 0xffff])) L.corr[i] = -1;
+            __syncthreads();
+        }
+        // trimming: segment distances, their order statistics by rank counting
+        mine = 0;
+        for (int i = tid; i < n; i += PLICP_THREADS) {
+            double d = -1.0;
+            if (L.corr[i] >= 0) {
+                const int j1 = L.corr[i] & 0xffff, j2 = L.corr[i] >> 16;
+                d = plicp_seg_dist(L.rx[j1], L.ry[j1], L.rx[j2], L.ry[j2], L.wx[i], L.wy[i]);
+                mine++;
+            }
+            L.dist[i] = d;                                  // -1 = no correspondence
+        }
+        const int k = (int)plicp_block_sum((double)mine, L.red);
+        total_error = 0; nvalid = 0;
+        if (k > 0) {
+            int order = (int)floor(k * P.outliers_maxPerc), order2 = (int)floor(k * P.outliers_adaptive_order);
+            order = order < 0 ? 0 : (order > k - 1 ? k - 1 : order); order2 = order2 < 0 ? 0 : (order2 > k - 1 ? k - 1 : order2);
+            for (int i = tid; i < n; i += PLICP_THREADS) {
+                const double d = L.dist[i];
+                if (d < 0) continue;
+                int rank = 0;                               // position in the ascending order, ties by index
+                for (int j = 0; j < n; ++j) { const double e = L.dist[j]; rank += (e >= 0 && (e < d || (e == d && j < i))) ? 1 : 0; }
+                if (rank == order) L.red[8] = d;
+                if (rank == order2) L.red[9] = d;
+            }
+            __syncthreads();
+            const double limit1 = L.red[8], limit2 = P.outliers_adaptive_mult * L.red[9];
+            const double limit = limit1 < limit2 ? limit1 : limit2;
+            double err = 0;
+            mine = 0;
+            for (int i = tid; i < n; i += PLICP_THREADS) {
+                const double d = L.dist[i];
+                if (d < 0) continue;
+                if (d > limit) L.corr[i] = -1; else { mine++; err += d; }
+            }
+            nvalid = (int)plicp_block_sum((double)mine, L.red);
+            total_error = plicp_block_sum(err, L.red);
+        }
+        if (nvalid < fail_perc * n) { ok = false; break; }
+        // closed-form point-to-line step
+        double s[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // M upper triangle (10), g (4)
+        for (int i = tid; i < n; i += PLICP_THREADS) {
+            if (L.corr[i] < 0) continue;
+            const int j1 = L.corr[i] & 0xffff, j2 = L.corr[i] >> 16;
+            const double px = L.sx[i], py = L.sy[i], qx = L.rx[j1], qy = L.ry[j1];
+            const double d0 = L.rx[j1] - L.rx[j2], d1 = L.ry[j1] - L.ry[j2];
+            const double inv = 1 / sqrt(d0 * d0 + d1 * d1);
+            const double n0 = d1 * inv, n1 = -d0 * inv;
+            const double a[4] = {n0, n1, n0 * px + n1 * py, -n0 * py + n1 * px};
+            const double b = n0 * qx + n1 * qy;
+            int q = 0;
+            for (int r = 0; r < 4; ++r) for (int c = r; c < 4; ++c) s[q++] += a[r] * a[c];
+            for (int r = 0; r < 4; ++r) s[10 + r] += a[r] * b;
+        }
+        for (int q = 0; q < 14; ++q) s[q] = plicp_block_sum(s[q], L.red);
+        bool solved = nvalid >= 2;
+        if (solved) {
+            const double M00 = s[0], M01 = s[1], M02 = s[2], M03 = s[3], M11 = s[4], M12 = s[5], M13 = s[6], M22 = s[7], M23 = s[8], M33 = s[9];
+            const double detA = M00 * M11 - M01 * M01;
+            solved = fabs(detA) > 1e-300;
+            if (solved) {
+                const double iA00 = M11 / detA, iA01 = -M01 / detA, iA11 = M00 / detA;
+                const double B00 = M02, B01 = M03, B10 = M12, B11 = M13;
+                const double AiB00 = iA00 * B00 + iA01 * B10, AiB01 = iA00 * B01 + iA01 * B11;
+                const double AiB10 = iA01 * B00 + iA11 * B10, AiB11 = iA01 * B01 + iA11 * B11;
+                const double Aig0 = iA00 * s[10] + iA01 * s[11], Aig1 = iA01 * s[10] + iA11 * s[11];
+                const double S00 = M22 - (B00 * AiB00 + B10 * AiB10), S01 = M23 - (B00 * AiB01 + B10 * AiB11);
+                const double S10 = M23 - (B01 * AiB00 + B11 * AiB10), S11 = M33 - (B01 * AiB01 + B11 * AiB11);
+                const double h0 = s[12] - (B00 * Aig0 + B10 * Aig1), h1 = s[13] - (B01 * Aig0 + B11 * Aig1);
+                const double trS = S00 + S11, detS = S00 * S11 - S01 * S10;
+                const double ah0 = S11 * h0 - S01 * h1, ah1 = -S10 * h0 + S00 * h1;
+                const double hh = h0 * h0 + h1 * h1, hah = h0 * ah0 + h1 * ah1, aa = ah0 * ah0 + ah1 * ah1;
+                double l;
+                solved = plicp_quartic_largest_root(2 * trS, trS * trS + 2 * detS - hh, 2 * trS * detS - 2 * hah, detS * detS - aa, l);
+                if (solved) {
+                    const double det = l * l + trS * l + detS;
+                    solved = fabs(det) > 1e-300;
+                    if (solved) {
+                        const double cth = (ah0 + l * h0) / det, sth = (ah1 + l * h1) / det;
+                        x_new[0] = Aig0 - (AiB00 * cth + AiB01 * sth);
+                        x_new[1] = Aig1 - (AiB10 * cth + AiB11 * sth);
+                        x_new[2] = atan2(sth, cth);
+                        solved = isfinite(x_new[0]) && isfinite(x_new[1]) && isfinite(x_new[2]);
+                    }
+                }
+            }
+        }
+        if (!solved) { ok = false; break; }
+        const double dxw = x_new[0] - x_old[0], dyw = x_new[1] - x_old[1];
+        double dth = x_new[2] - x_old[2];
+        while (dth < -PI) dth += 2 * PI;
+        while (dth > PI) dth -= 2 * PI;
+        const double del0 = cs * dxw + sn * dyw, del1 = -sn * dxw + cs * dyw;
+        // loop detection on the correspondence set (one lane, the recurrence of the oracle)
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t hash = 0;
+            for (int i = 0; i < n; ++i) hash = hash * 31u + (uint32_t)(L.corr[i] >= 0 ? (L.corr[i] & 0xffff) + 1000 * (L.corr[i] >> 16) : -1);
+            int loop = 0;
+            for (int a = 0; a < it && a < 64; ++a) if (hashes[a] == hash) loop = 1;
+            if (it < 64) hashes[it] = hash;
+            ((int*)L.red)[20] = loop;
+        }
+        __syncthreads();
+        const bool loop = ((int*)L.red)[20] != 0;
+        __syncthreads();
+        if (loop) { it++; break; }
+        if (sqrt(del0 * del0 + del1 * del1) < P.epsilon_xy && fabs(dth) < P.epsilon_theta) { it++; break; }
+        x_old[0] = x_new[0]; x_old[1] = x_new[1]; x_old[2] = x_new[2];
+    }
+    iterations = it < P.max_iterations ? it : P.max_iterations;
+    return ok;
+}
+
+// scans: [S][n] ranges in cm (PMScan::r); out8[b] = {x, y, theta (m, m, rad), valid, error, iterations, kept, 0}
+__global__ __launch_bounds__(PLICP_THREADS) void plicp_kernel(PlicpParam P, int B, const float* __restrict__ g_r,
+                                                              const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
+                                                              double* __restrict__ out8)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = P.n, Np = (n + 63) & ~63, tid = threadIdx.x;
+    PlicpLds L;
+    L.rx = (double*)smem; L.ry = L.rx + Np; L.sx = L.ry + Np; L.sy = L.sx + Np; L.wx = L.sy + Np; L.wy = L.wx + Np;
+    L.d2 = L.wy + Np; L.dist = L.d2 + Np; L.dj = (unsigned long long*)L.dist;
+    L.corr = (int*)(L.dist + Np);
+    L.rvalid = (uint8_t*)(L.corr + Np); L.svalid = L.rvalid + Np;       // (2 Np bytes inside the 4 Np reserved)
+    L.red = (double*)(smem + (size_t)Np * (8 * 8 + 4 + 4));
+    const double min_reading = P.min_range_cm / 100., max_reading = P.max_range_cm / 100.;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < n; i += PLICP_THREADS) {                   // fromPMScan2LDP (:191-227) + ld_compute_cartesian
+            const double theta = (double)(P.fi_min + P.dfi * i);
+            for (int w = 0; w < 2; ++w) {
+                const double r = (double)g_r[(size_t)(w ? act_idx[b] : ref_idx[b]) * n + i];
+                bool valid = !(r <= P.min_range_cm || r >= P.max_range_cm);
+                const double rm = valid ? r / 100.0 : -1.0;
+                if (valid && !(rm > min_reading && rm < max_reading)) valid = false;
+                const double x = cos(theta) * rm, y = sin(theta) * rm;
+                if (w) { L.sx[i] = x; L.sy[i] = y; L.svalid[i] = valid; } else { L.rx[i] = x; L.ry[i] = y; L.rvalid[i] = valid; }
+            }
+        }
+        __syncthreads();
+        const double q0[3] = {0, 0, 0};
+        double x[3] = {0, 0, 0}, error = 0, res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int nvalid = 0, iters = 0;
+        if (plicp_loop(P, L, q0, x, error, nvalid, iters)) {
+            double best_error = error, best[3] = {x[0], x[1], x[2]};
+            if (P.restart && error / nvalid > P.restart_threshold_mean_error) {
+                const double dt = P.restart_dt, dth = P.restart_dtheta;
+                for (int a = 0; a < 6; ++a) {
+                    const double start[3] = {x[0] + (a == 0 ? dt : a == 1 ? -dt : 0.0), x[1] + (a == 2 ? dt : a == 3 ? -dt : 0.0),
+                                             x[2] + (a == 4 ? dth : a == 5 ? -dth : 0.0)};
+                    double xa[3] = {0, 0, 0}, my_error = 0;
+                    int my_valid = 0, my_iters = 0;
+                    __syncthreads();
+                    if (!plicp_loop(P, L, start, xa, my_error, my_valid, my_iters)) continue;
+                    iters += my_iters;
+                    if (my_error < best_error) { best_error = my_error; best[0] = xa[0]; best[1] = xa[1]; best[2] = xa[2]; }
+                }
+            }
+            res[0] = best[0]; res[1] = best[1]; res[2] = best[2]; res[3] = 1; res[4] = best_error; res[5] = iters; res[6] = nvalid;
+        } else res[5] = iters;
+        if (tid < 8) out8[8 * (size_t)b + tid] = res[tid];
+    }
+}
+
+} // namespace lsa

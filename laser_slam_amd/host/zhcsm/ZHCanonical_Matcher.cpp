@@ -77,35 +77,27 @@ void CCanonicalMatcher::median_filter(struct _PMScan* ls)
     must(lsa_preprocess_stages_host(m_ctx, ls->r, ls->bad, ls->seg, LSA_PRE_MEDIAN), "median_filter");
 }
 
-// validity as fromPMScan2LDP (:193-227): r in (min_range, max_range); then segment + match
+// fromPMScan2LDP + FMatch(LDP, LDP) (:191-284): point-to-line ICP with the reference's sm_icp options on
+// the device (lsa_plicp_host: validity r in (min_range, max_range), ranges cm -> m, first guess 0);
+// the pose comes back in metres and is stored in cm like the reference does (:240-242)
 float CCanonicalMatcher::matchPair(struct _PMScan* ref, struct _PMScan* cur)
 {
     ensure(m_ctx, m_pParam);
-    const int n = m_pParam->pm_l_points;
-    struct _PMScan* s[2] = {ref, cur};
-    for (int k = 0; k < 2; ++k) {
-        for (int i = 0; i < n; ++i)
-            s[k]->bad[i] = (s[k]->r[i] <= m_pParam->pm_min_range || s[k]->r[i] >= m_pParam->pm_max_range) ? PM_RANGE : 0;
-        must(lsa_preprocess_stages_host(m_ctx, s[k]->r, s[k]->bad, s[k]->seg, LSA_PRE_SEGMENT), "segment");
-    }
-    const float zero[3] = {0, 0, 0};
-    float pose[3] = {0, 0, 0}, ret = 0;
-    int32_t st = 0;
-    must(lsa_match_host(m_ctx, LSA_MATCH_ICP, ref->r, ref->bad, zero, cur->r, cur->bad, cur->seg, zero, pose, &ret, &st),
-         "lsa_match_host");
-    if (st != LSA_ST_OK) {
+    double out[8];
+    must(lsa_plicp_host(m_ctx, ref->r, cur->r, 0, out), "lsa_plicp_host");
+    if (out[3] == 0.0) {
         cout << "icp_failed!" << endl;
         return -1;
     }
-    cur->rx = pose[0]; cur->ry = pose[1]; cur->th = pose[2];
+    cur->rx = (float)(out[0] * 100.); cur->ry = (float)(out[1] * 100.); cur->th = (float)out[2];
     if (m_doCov) {
-        float exy[2] = {0, 0};
-        int32_t na = 0;
-        must(lsa_error_index2_host(m_ctx, ref->r, ref->bad, zero, cur->r, cur->bad, cur->seg, pose, exy, &na), "error_index2");
+        // sm_icp's covariance (do_compute_covariance, Censi's ICRA'07 estimate) is not restated; a diagonal
+        // stand-in from the mean point-to-line residual keeps FMatchKeyFrame2 usable (documented deviation)
+        const double mean_err = out[6] > 0 ? out[4] / out[6] : 0.0;       // [m]
         for (int i = 0; i < 9; ++i) m_cov[i] = 0;
-        m_cov[0] = exy[0]; m_cov[4] = exy[1];                         // [m^2]
-        const double mean_r = 5.0;                                    // lever arm for the heading variance [m]
-        m_cov[8] = (exy[0] + exy[1]) / (mean_r * mean_r);
+        m_cov[0] = m_cov[4] = mean_err * mean_err;
+        const double lever = 5.0;                                          // [m]
+        m_cov[8] = 2.0 * mean_err * mean_err / (lever * lever);
     }
     return 0;
 }

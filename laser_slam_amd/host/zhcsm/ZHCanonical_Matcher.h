@@ -4,10 +4,11 @@
 // third-party library (src/CMakeLists.txt:7-9, no version pin) — its arithmetic cannot be
 // pinned here ("parity unpinned").  This class keeps the PMScan-facing
 // call signatures, units (cm / rad in, cm / rad out), return codes (0 ok, -1 failed,
-// 2 = first key frame stored) and ownership rules, and runs the core's windowed
-// point-to-segment ICP (the same family: closest point + point-to-line interpolation)
-// on the device.  The laser_data*-typed overloads of the reference expose CSM's own
-// types and are not provided.
+// 2 = first key frame stored) and ownership rules, and runs the core's restatement of the
+// published point-to-line ICP with the reference's options (csrc/plicp_kernels.hip,
+// ZHCanonical_Matcher.cpp:96-155) on the device.  The laser_data*-typed overloads of the
+// reference expose CSM's own types and are not provided; sm_icp's covariance is replaced by a
+// diagonal stand-in (see matchPair).
 #ifndef ZHCANONICAL_H
 #define ZHCANONICAL_H
 #include <cmath>

@@ -143,6 +143,20 @@ void orc_pf_estimate(const float* poses, const float* score, const int* index, i
 void orc_pf_predict(int n, const double mean[3], const double sigma[3], const float* normals, float* poses);
 void orc_pf_roughen(int n, double K, const float* normals, float* poses);
 
+/* point-to-line ICP as configured by CCanonicalMatcher (CSM absent: PARITY UNPINNED), plicp_oracle.c */
+typedef struct orc_plicp_params {
+    double max_angular_correction_deg, max_linear_correction;
+    int max_iterations;
+    double epsilon_xy, epsilon_theta, max_correspondence_dist;
+    int restart;
+    double restart_threshold_mean_error, restart_dt, restart_dtheta;
+    double outliers_maxPerc, outliers_adaptive_order, outliers_adaptive_mult;
+    int outliers_remove_doubles;
+} orc_plicp_params;
+void orc_plicp_params_default(orc_plicp_params* P);
+void orc_plicp(const float* ref_r_cm, const float* cur_r_cm, int n, float fi_min, float dfi, int min_range_cm,
+               int max_range_cm, const orc_plicp_params* P, double out[8]);
+
 /* classic point-to-point ICP with CICPWarpper's options (MRPT absent: PARITY UNPINNED), p2p_oracle.c */
 void orc_p2p_icp(const float* rx, const float* ry, int n1, const float* cx, const float* cy, int n2,
                  const double init[3], int max_iter, float thr_d, float thr_a, float alfa, float smallest,

@@ -530,3 +530,22 @@ def icp_goodness(prob, cx, cy, offx, offy, res, poses, obs_x, obs_y, fov, min_an
                             C.c_double(res), _p(poses), len(poses), _p(obs_x), _p(obs_y), len(obs_x),
                             C.c_float(fov), C.c_float(min_angle), C.c_float(max_range), _p(w), _p(rel))
     return w, rel
+
+
+class _PlicpParams(C.Structure):
+    _fields_ = [("max_angular_correction_deg", C.c_double), ("max_linear_correction", C.c_double), ("max_iterations", C.c_int),
+                ("epsilon_xy", C.c_double), ("epsilon_theta", C.c_double), ("max_correspondence_dist", C.c_double),
+                ("restart", C.c_int), ("restart_threshold_mean_error", C.c_double), ("restart_dt", C.c_double),
+                ("restart_dtheta", C.c_double), ("outliers_maxPerc", C.c_double), ("outliers_adaptive_order", C.c_double),
+                ("outliers_adaptive_mult", C.c_double), ("outliers_remove_doubles", C.c_int)]
+
+
+def plicp(ref_r_cm, cur_r_cm, fi_min, dfi, min_range_cm, max_range_cm):
+    """CCanonicalMatcher's point-to-line ICP (oracle/plicp_oracle.c): 8-double result record."""
+    P = _PlicpParams()
+    _orc().orc_plicp_params_default(C.byref(P))
+    a = np.ascontiguousarray(ref_r_cm, f32); b = np.ascontiguousarray(cur_r_cm, f32)
+    out = np.zeros(8, np.float64)
+    _orc().orc_plicp(_p(a), _p(b), len(a), C.c_float(fi_min), C.c_float(dfi), int(min_range_cm), int(max_range_cm),
+                     C.byref(P), _p(out))
+    return out

@@ -87,6 +87,20 @@ def test_cpolarmatch_dropin(name, exe):
     assert int(by("corridor")[0][1]) in (0, 1, -2, -3)
     csm = by("csm")[0]
     assert float(csm[1]) == 2.0 and float(csm[2]) in (0.0, -1.0)          # first frame stored, then a match
+    if float(csm[2]) == 0.0:
+        # CCanonicalMatcher: median filter, then the point-to-line ICP with the reference's options
+        # (parity unpinned: against oracle/plicp_oracle.c), stored in cm / rad
+        from oracle_lib import Oracle, plicp
+        o = Oracle(laser)
+        r_all, _, _, bad_all, _ = o.read_carmen(os.path.join(GOLDEN, fn), tag)
+        gp = golden_param(g)
+        o.set_fimin_maxrange(np.float32(gp["fi_min"]), int(gp["max_range"]))
+        ra, rb = o.median(r_all[0]), o.median(r_all[1])
+        P = o.param_dict()
+        want = plicp(ra, rb, P["fi_min"], P["dfi"], P["min_range"], P["max_range"])
+        got = np.array([hexf(t) for t in csm[3:6]], np.float32)
+        assert want[3] == 1.0
+        assert np.allclose(got, [want[0] * 100, want[1] * 100, want[2]], rtol=0, atol=2e-4)
     se2 = [float.fromhex(t) for t in by("se2")[0][1:]]
     assert np.allclose(se2[3:], [0.25, -0.5, 0.125], atol=1e-12)          # p (-) (p (+) q) == q
 

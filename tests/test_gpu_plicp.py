@@ -1,0 +1,47 @@
+"""GPU: point-to-line ICP (CCanonicalMatcher's arithmetic) against oracle/plicp_oracle.c.
+PARITY UNPINNED (CSM absent): the oracle restates the published algorithm with the reference's options;
+device and host differ only in the order of the normal-equation sums and in libm vs ocml last bits."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_beams", [361, 1081])
+def test_plicp_matches_oracle_and_recovers_motion(n_beams):
+    import torch
+    assert torch.cuda.is_available()
+    torch.zeros(1, device="cuda")
+    from laser_slam_amd import capi, synth
+    from oracle_lib import plicp
+    kw = dict(points=n_beams, fov_deg=270, max_range=3000, min_valid=n_beams // 4, window=n_beams // 6,
+              fi_min_deg=-135, fi_max_deg=135)
+    p = capi.param_make(**kw)
+    ctx = capi.Context(p)
+    raw, poses = synth.make_scans(10, n_beams=n_beams)
+    raw[3, 40:60] = 3001.0                      # a block of out-of-range readings
+    raw[6, ::7] = 5.0                           # readings below the minimum range
+    S = raw.shape[0]
+    ref_idx = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 0, 2], np.int32); act_idx = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 3, 0], np.int32)
+    B = len(ref_idx)
+    d_r = torch.from_numpy(raw).cuda()
+    d_ri, d_ai = torch.from_numpy(ref_idx).cuda(), torch.from_numpy(act_idx).cuda()
+    d_out = torch.zeros(B, 8, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    capi.plicp_batch(ctx, B, d_r, d_ri, d_ai, d_out)
+    ctx.sync()
+    got = d_out.cpu().numpy()
+    for b in range(B):
+        want = plicp(raw[ref_idx[b]], raw[act_idx[b]], p.fi_min, p.dfi, p.min_range, p.max_range)
+        assert got[b, 3] == want[3] == 1.0
+        assert np.allclose(got[b, :3], want[:3], atol=2e-6), (b, got[b], want)
+        assert abs(got[b, 6] - want[6]) <= 2 and abs(got[b, 4] - want[4]) <= 1e-3 * want[4] + 1e-6
+        # the true motion of the synthetic robot
+        x0, y0, t0 = poses[ref_idx[b]]; x1, y1, t1 = poses[act_idx[b]]
+        c, s = np.cos(-t0), np.sin(-t0)
+        true = np.array([c * (x1 - x0) - s * (y1 - y0), s * (x1 - x0) + c * (y1 - y0), t1 - t0])
+        assert np.abs(got[b, :2] - true[:2]).max() < 0.03 and abs(got[b, 2] - true[2]) < 0.01
+    # host entry point
+    one = capi.plicp_host(ctx, raw[0], raw[1])
+    assert np.array_equal(one, got[0])
+    ctx.close()
