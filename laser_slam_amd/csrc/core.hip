@@ -110,6 +110,17 @@ int lsa_debug_nn_stats(unsigned long long* out8 /* 24 entries */)
 }
 #endif
 
+#ifdef LSA_PLICP_STAMPS
+int lsa_debug_plicp_cycles(unsigned long long* out8)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(lsa::lsa_plicp_cycles), sizeof(unsigned long long) * 8));
+    unsigned long long z[8] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lsa::lsa_plicp_cycles), z, sizeof z));
+    return LSA_OK;
+}
+#endif
+
 const char* lsa_version(void) { return "laser_slam_amd 0.1 (gfx950)"; }
 
 const char* lsa_last_error(void) { return g_err.c_str(); }

@@ -7,7 +7,8 @@
 //
 // One 256-thread workgroup per scan pair, everything in double like CSM; both scans' Cartesian
 // points, the moved points and the correspondence records live in LDS (9 doubles-worth per beam).
-// Sums use a fixed-order tree, the order statistics of the trimming are found by rank counting.
+// Sums use a fixed-order tree, the order statistics of the trimming come from a radix select, and the
+// window scan of the correspondence search is pruned exactly by a bearing bound.
 #include "lsa_device.h"
 
 namespace lsa {
@@ -26,7 +27,13 @@ struct PlicpParam {
 };
 
 constexpr int PLICP_THREADS = 256;
-__host__ __device__ inline int plicp_lds_bytes(int n) { int Np = (n + 63) & ~63; return Np * (8 * 8 + 4 + 4) + 1024; }
+#ifdef LSA_PLICP_STAMPS      // diagnostic build only: cycles per phase, summed over workgroups by thread 0
+__device__ unsigned long long lsa_plicp_cycles[8];
+#define PSTAMP(slot) do { if (threadIdx.x == 0) { unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&lsa_plicp_cycles[slot], t_ - pt_); pt_ = t_; } } while (0)
+#else
+#define PSTAMP(slot) do {} while (0)
+#endif
+__host__ __device__ inline int plicp_lds_bytes(int n) { int Np = (n + 63) & ~63; return Np * (8 * 8 + 4 + 4) + 1024 + 1088; }
 
 struct PlicpLds {
     double *rx, *ry, *sx, *sy, *wx, *wy, *d2, *dist;      // ref / sens / moved points, NN distance^2, segment distance
@@ -34,6 +41,7 @@ struct PlicpLds {
     uint8_t *rvalid, *svalid;
     unsigned long long* dj;                                // aliases `dist` during the doubles test
     double* red;                                           // reduction scratch, broadcast slots, remembered hashes
+    int* hist;                                             // 264 ints of the radix select
 };
 
 __device__ __forceinline__ double plicp_block_sum(double v, double* red)
@@ -46,6 +54,67 @@ __device__ __forceinline__ double plicp_block_sum(double v, double* red)
 }
 
 __device__ __forceinline__ double plicp_dist2(double ax, double ay, double bx, double by) { return (ax - bx) * (ax - bx) + (ay - by) * (ay - by); }
+
+// the same fixed-order tree for K values at once (two barriers instead of 2 K)
+template <int K>
+__device__ __forceinline__ void plicp_block_sums(double (&v)[K], double* red)
+{
+    #pragma unroll
+    for (int q = 0; q < K; ++q) for (int o = 32; o; o >>= 1) v[q] += __shfl_xor(v[q], o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        #pragma unroll
+        for (int q = 0; q < K; ++q) red[24 + (threadIdx.x >> 6) * K + q] = v[q];
+    }
+    __syncthreads();
+    #pragma unroll
+    for (int q = 0; q < K; ++q) v[q] = red[24 + q] + red[24 + K + q] + red[24 + 2 * K + q] + red[24 + 3 * K + q];
+}
+
+// value of ascending rank k among the non-negative entries of dist[0..n) (negative = absent): radix
+// select on the bit patterns, 8 bits per round with a 256-bin LDS histogram (one bin per thread), the
+// thread's own keys kept in registers.  Exact: the result is the bit pattern of an element.
+// `hist` = 256 + 8 ints of scratch.  n <= 5 * PLICP_THREADS.
+__device__ double plicp_select(const double* dist, int n, int k, int* hist)
+{
+    unsigned long long key[5];
+    #pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int i = threadIdx.x + u * PLICP_THREADS;
+        const double d = i < n ? dist[i] : -1.0;
+        key[u] = d < 0 ? ~0ull : (unsigned long long)__double_as_longlong(d);
+    }
+    unsigned long long prefix = 0, decided = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int sh = 56; sh >= 0; sh -= 8) {
+        __syncthreads();
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+        #pragma unroll
+        for (int u = 0; u < 5; ++u)
+            if (key[u] != ~0ull && (key[u] & decided) == prefix) atomicAdd(&hist[(int)((key[u] >> sh) & 255)], 1);
+        __syncthreads();
+        // inclusive prefix over the 256 bins: within the wave by shuffles, across waves through 4 slots
+        const int c = hist[threadIdx.x];
+        int incl = c;
+        #pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        if (lane == 63) hist[256 + wave] = incl;
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wave; ++w) off += hist[256 + w];
+        incl += off;
+        // the bin where the running count passes k (exactly one thread)
+        if (k < incl && k >= incl - c) { hist[260] = (int)threadIdx.x; hist[261] = incl - c; }
+        __syncthreads();
+        const int b = hist[260];
+        k -= hist[261];
+        prefix |= (unsigned long long)b << sh;
+        decided |= 255ull << sh;
+    }
+    return __longlong_as_double((long long)prefix);
+}
+
 
 __device__ __forceinline__ double plicp_seg_dist(double ax, double ay, double bx, double by, double x, double y)
 {
@@ -65,7 +134,10 @@ __device__ bool plicp_quartic_largest_root(double a3, double a2, double a1, doub
 {
     double m = fabs(a3);
     m = fabs(a2) > m ? fabs(a2) : m; m = fabs(a1) > m ? fabs(a1) : m; m = fabs(a0) > m ? fabs(a0) : m;
-    double l = 1 + m;
+    // Fujiwara's bound on the root moduli: 2 max(|a3|, |a2|^(1/2), |a1|^(1/3), |a0 / 2|^(1/4)) - much closer than Cauchy's
+    double fb = fabs(a3);
+    { const double t2 = sqrt(fabs(a2)), t1 = cbrt(fabs(a1)), t0 = sqrt(sqrt(fabs(a0) * 0.5)); fb = t2 > fb ? t2 : fb; fb = t1 > fb ? t1 : fb; fb = t0 > fb ? t0 : fb; }
+    double l = 2 * fb * (1 + 1e-12) + 1e-300;
     for (int it = 0; it < 200; ++it) {
         const double p = (((l + a3) * l + a2) * l + a1) * l + a0;
         const double dp = ((4 * l + 3 * a3) * l + 2 * a2) * l + a1;
@@ -87,11 +159,14 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
     const int n = P.n, tid = threadIdx.x;
     const double PI = 3.14159265358979323846;
     double x_old[3] = {q0[0], q0[1], q0[2]};
-    uint32_t* hashes = (uint32_t*)(L.red + 64);            // up to 64 remembered correspondence sets
+    uint32_t* hashes = (uint32_t*)(L.red + 96);            // up to 64 remembered correspondence sets (red: 0-3 sums, 10 flag, 12-19 histogram, 22-23 hash parts, 24-79 sums<14>)
     const double min_theta = (double)(P.fi_min + P.dfi * 0), max_theta = (double)(P.fi_min + P.dfi * (n - 1));
     const double angle_res = (max_theta - min_theta) / n;
     bool ok = true;
     int it;
+#ifdef LSA_PLICP_STAMPS
+    unsigned long long pt_ = __builtin_readcyclecounter();
+#endif
     for (it = 0; it < P.max_iterations; ++it) {
         const double cs = cos(x_old[2]), sn = sin(x_old[2]);
         // moved points and correspondences
@@ -102,21 +177,84 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
             if (L.svalid[i]) {
                 const double wx = cs * L.sx[i] - sn * L.sy[i] + x_old[0], wy = sn * L.sx[i] + cs * L.sy[i] + x_old[1];
                 L.wx[i] = wx; L.wy[i] = wy;
-                const double delta = fabs(P.max_angular_correction_deg * (PI / 180.0)) + fabs(atan(P.max_linear_correction / sqrt(wx * wx + wy * wy)));
-                const int range = (int)ceil(delta / angle_res);
-                double start_theta = atan2(wy, wx);
-                if (start_theta < min_theta) start_theta += 2 * PI;
-                if (start_theta > max_theta) start_theta -= 2 * PI;
-                const int start_cell = (int)((start_theta - min_theta) / (max_theta - min_theta) * n);
-                int from = start_cell - range, to = start_cell + range;
-                from = from < 0 ? 0 : (from > n - 1 ? n - 1 : from); to = to < 0 ? 0 : (to > n - 1 ? n - 1 : to);
                 int j1 = -1;
                 const double lim = P.max_correspondence_dist * P.max_correspondence_dist;
-                for (int j = from; j <= to; ++j) {
-                    if (!L.rvalid[j]) continue;
-                    const double d = plicp_dist2(wx, wy, L.rx[j], L.ry[j]);
-                    if (d > lim) continue;
-                    if (j1 == -1 || d < best) { j1 = j; best = d; }
+                // The reference scans the window start_cell +- ceil((45 deg + atan(0.5 m / rho)) / res) around the
+                // point's bearing.  Exact pruning of that scan: a reference point on a ray at angular distance a
+                // from the bearing is at least rho sin(a) away (rho, if a >= 90 deg), so only rays within
+                // asin(sqrt(bound) / rho) of the bearing - or of its images one turn away - can hold the minimum;
+                // bound = the smaller of the correspondence limit and the distance of two seeds (the ray at the
+                // bearing, last iteration's match).  Fast path (nearly every point): the bearing lies inside the
+                // scan's field of view and the pruned range is well inside the +-45 deg that every window has, so
+                // the window itself never matters and single precision suffices for the range's centre and half
+                // width (the margins cover its error); the distances are always evaluated in double.
+                const int prev = L.corr[i] >= 0 ? (L.corr[i] & 0xffff) : -1;
+                const float wxf = (float)wx, wyf = (float)wy;
+                const float rho_f = sqrtf(wxf * wxf + wyf * wyf) * 0.99999f;
+                const float phi_f = atan2f(wyf, wxf);
+                const int c0f = (int)rintf((phi_f - (float)min_theta) / P.dfi);
+                const int range_min = (int)(fabs(P.max_angular_correction_deg * (PI / 180.0)) / angle_res);
+                bool fast = phi_f > (float)min_theta + 1e-3f && phi_f < (float)max_theta - 1e-3f && c0f >= 0 && c0f <= n - 1;
+                int lo0 = 0, hi0 = -1, nseg = 1, lo1 = 0, hi1 = -1, lo2 = 0, hi2 = -1;
+                if (fast) {
+                    double bound = lim;
+                    if (L.rvalid[c0f]) { const double d = plicp_dist2(wx, wy, L.rx[c0f], L.ry[c0f]); bound = d < bound ? d : bound; }
+                    if (prev >= 0 && abs(prev - c0f) <= range_min - 8 && L.rvalid[prev]) { const double d = plicp_dist2(wx, wy, L.rx[prev], L.ry[prev]); bound = d < bound ? d : bound; }
+                    const float tq = sqrtf((float)bound) * 1.0001f / rho_f;
+                    const int M = tq < 1.0f ? (int)((tq + 0.5708f * tq * tq * tq) / P.dfi) + 5 : n;      // asin t <= t + (pi/2 - 1) t^3
+                    fast = M + 8 <= range_min;
+                    lo0 = c0f - M > 0 ? c0f - M : 0; hi0 = c0f + M < n - 1 ? c0f + M : n - 1;
+                }
+                if (!fast) {
+                    const double rho = sqrt(wx * wx + wy * wy);
+                    const double phi = atan2(wy, wx);
+                    const double delta = fabs(P.max_angular_correction_deg * (PI / 180.0)) + fabs(atan(P.max_linear_correction / rho));
+                    const int range = (int)ceil(delta / angle_res);
+                    double start_theta = phi;
+                    if (start_theta < min_theta) start_theta += 2 * PI;
+                    if (start_theta > max_theta) start_theta -= 2 * PI;
+                    const int start_cell = (int)((start_theta - min_theta) / (max_theta - min_theta) * n);
+                    int from = start_cell - range, to = start_cell + range;
+                    from = from < 0 ? 0 : (from > n - 1 ? n - 1 : from); to = to < 0 ? 0 : (to > n - 1 ? n - 1 : to);
+                    double bound = lim;
+                    const int cen = start_cell < from ? from : (start_cell > to ? to : start_cell);
+                    if (L.rvalid[cen]) { const double d = plicp_dist2(wx, wy, L.rx[cen], L.ry[cen]); bound = d < bound ? d : bound; }
+                    if (prev >= from && prev <= to && L.rvalid[prev]) { const double d = plicp_dist2(wx, wy, L.rx[prev], L.ry[prev]); bound = d < bound ? d : bound; }
+                    const double sb = sqrt(bound) * (1.0 + 1e-9) + 1e-12;
+                    lo0 = from; hi0 = to;
+                    if (sb < rho) {
+                        const double tq = sb / rho;                                      // asin t <= t + (pi/2 - 1) t^3 on [0, 1]
+                        const int M = (int)((tq + 0.5708 * tq * tq * tq) / (double)P.dfi) + 3;   // bearings are float(fi_min + dfi j): margin
+                        const int T = (int)rint(2 * PI / (double)P.dfi);
+                        const int c0 = (int)rint((phi - min_theta) / (double)P.dfi);
+                        // images c0 - T, c0, c0 + T in increasing order, each clipped to [from, to] and past the previous one
+                        int done = from - 1;
+                        lo0 = c0 - T - M > done + 1 ? c0 - T - M : done + 1; hi0 = c0 - T + M < to ? c0 - T + M : to; if (hi0 > done) done = hi0;
+                        lo1 = c0 - M > done + 1 ? c0 - M : done + 1;         hi1 = c0 + M < to ? c0 + M : to;         if (hi1 > done) done = hi1;
+                        lo2 = c0 + T - M > done + 1 ? c0 + T - M : done + 1; hi2 = c0 + T + M < to ? c0 + T + M : to;
+                        nseg = 3;
+                    }
+                }
+#ifdef LSA_PLICP_STAMPS
+                atomicAdd(&lsa_plicp_cycles[6], fast ? 0ull : 1ull);
+                atomicAdd(&lsa_plicp_cycles[7], (unsigned long long)((hi0 >= lo0 ? hi0 - lo0 + 1 : 0) + (hi1 >= lo1 ? hi1 - lo1 + 1 : 0) + (hi2 >= lo2 ? hi2 - lo2 + 1 : 0)));
+#endif
+                for (int sg = 0; sg < nseg; ++sg) {
+                    const int a = sg == 0 ? lo0 : sg == 1 ? lo1 : lo2, e = sg == 0 ? hi0 : sg == 1 ? hi1 : hi2;
+                    // (invalid reference rays carry coordinates of 1e150: their distance exceeds every limit)
+                    int j = a;
+                    for (; j + 3 <= e; j += 4) {
+                        const double d0 = plicp_dist2(wx, wy, L.rx[j], L.ry[j]), d1 = plicp_dist2(wx, wy, L.rx[j + 1], L.ry[j + 1]);
+                        const double d2 = plicp_dist2(wx, wy, L.rx[j + 2], L.ry[j + 2]), d3 = plicp_dist2(wx, wy, L.rx[j + 3], L.ry[j + 3]);
+                        if (!(d0 > lim) && (j1 == -1 || d0 < best)) { j1 = j; best = d0; }
+                        if (!(d1 > lim) && (j1 == -1 || d1 < best)) { j1 = j + 1; best = d1; }
+                        if (!(d2 > lim) && (j1 == -1 || d2 < best)) { j1 = j + 2; best = d2; }
+                        if (!(d3 > lim) && (j1 == -1 || d3 < best)) { j1 = j + 3; best = d3; }
+                    }
+                    for (; j <= e; ++j) {
+                        const double d = plicp_dist2(wx, wy, L.rx[j], L.ry[j]);
+                        if (!(d > lim) && (j1 == -1 || d < best)) { j1 = j; best = d; }
+                    }
                 }
                 if (!(j1 == -1 || j1 == 0 || j1 == n - 1)) {
                     int up = -1, down = -1;
@@ -132,6 +270,7 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
             L.corr[i] = rec; L.d2[i] = best;
         }
         const int num = (int)plicp_block_sum((double)mine, L.red);
+        PSTAMP(0);
         const double fail_perc = 0.05;
         if (num < fail_perc * n) { ok = false; break; }
         if (P.outliers_remove_doubles) {                    // keep the points within 3x the best distance of their reference point
@@ -144,7 +283,8 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
                 if (L.corr[i] >= 0 && L.d2[i] > 9.0 * __longlong_as_double((long long)L.dj[L.corr[i] & 0xffff])) L.corr[i] = -1;
             __syncthreads();
         }
-        // trimming: segment distances, their order statistics by rank counting
+        PSTAMP(1);
+        // trimming: segment distances, their order statistics
         mine = 0;
         for (int i = tid; i < n; i += PLICP_THREADS) {
             double d = -1.0;
@@ -160,16 +300,8 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
         if (k > 0) {
             int order = (int)floor(k * P.outliers_maxPerc), order2 = (int)floor(k * P.outliers_adaptive_order);
             order = order < 0 ? 0 : (order > k - 1 ? k - 1 : order); order2 = order2 < 0 ? 0 : (order2 > k - 1 ? k - 1 : order2);
-            for (int i = tid; i < n; i += PLICP_THREADS) {
-                const double d = L.dist[i];
-                if (d < 0) continue;
-                int rank = 0;                               // position in the ascending order, ties by index
-                for (int j = 0; j < n; ++j) { const double e = L.dist[j]; rank += (e >= 0 && (e < d || (e == d && j < i))) ? 1 : 0; }
-                if (rank == order) L.red[8] = d;
-                if (rank == order2) L.red[9] = d;
-            }
-            __syncthreads();
-            const double limit1 = L.red[8], limit2 = P.outliers_adaptive_mult * L.red[9];
+            const double limit1 = plicp_select(L.dist, n, order, L.hist);
+            const double limit2 = P.outliers_adaptive_mult * plicp_select(L.dist, n, order2, L.hist);
             const double limit = limit1 < limit2 ? limit1 : limit2;
             double err = 0;
             mine = 0;
@@ -181,6 +313,7 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
             nvalid = (int)plicp_block_sum((double)mine, L.red);
             total_error = plicp_block_sum(err, L.red);
         }
+        PSTAMP(2);
         if (nvalid < fail_perc * n) { ok = false; break; }
         // closed-form point-to-line step
         double s[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // M upper triangle (10), g (4)
@@ -197,7 +330,8 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
             for (int r = 0; r < 4; ++r) for (int c = r; c < 4; ++c) s[q++] += a[r] * a[c];
             for (int r = 0; r < 4; ++r) s[10 + r] += a[r] * b;
         }
-        for (int q = 0; q < 14; ++q) s[q] = plicp_block_sum(s[q], L.red);
+        plicp_block_sums<14>(s, L.red);
+        PSTAMP(3);
         bool solved = nvalid >= 2;
         if (solved) {
             const double M00 = s[0], M01 = s[1], M02 = s[2], M03 = s[3], M11 = s[4], M12 = s[5], M13 = s[6], M22 = s[7], M23 = s[8], M33 = s[9];
@@ -230,6 +364,7 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
                 }
             }
         }
+        PSTAMP(4);
         if (!solved) { ok = false; break; }
         const double dxw = x_new[0] - x_old[0], dyw = x_new[1] - x_old[1];
         double dth = x_new[2] - x_old[2];
@@ -237,10 +372,21 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
         while (dth > PI) dth -= 2 * PI;
         const double del0 = cs * dxw + sn * dyw, del1 = -sn * dxw + cs * dyw;
         // loop detection on the correspondence set (one lane, the recurrence of the oracle)
+        // hash = sum v_i 31^(n-1-i) mod 2^32 (the oracle's recurrence hash = hash * 31 + v_i, summed in parallel)
+        uint32_t hpart = 0;
+        for (int i = tid; i < n; i += PLICP_THREADS) {
+            const uint32_t v = (uint32_t)(L.corr[i] >= 0 ? (L.corr[i] & 0xffff) + 1000 * (L.corr[i] >> 16) : -1);
+            uint32_t pw = 1, bs = 31;
+            for (int e = n - 1 - i; e; e >>= 1) { if (e & 1) pw *= bs; bs *= bs; }
+            hpart += v * pw;
+        }
+        for (int o = 32; o; o >>= 1) hpart += __shfl_xor(hpart, o);
+        __syncthreads();
+        if ((tid & 63) == 0) ((uint32_t*)L.red)[44 + (tid >> 6)] = hpart;
         __syncthreads();
         if (tid == 0) {
-            uint32_t hash = 0;
-            for (int i = 0; i < n; ++i) hash = hash * 31u + (uint32_t)(L.corr[i] >= 0 ? (L.corr[i] & 0xffff) + 1000 * (L.corr[i] >> 16) : -1);
+            const uint32_t* hp = (const uint32_t*)L.red + 44;
+            const uint32_t hash = hp[0] + hp[1] + hp[2] + hp[3];
             int loop = 0;
             for (int a = 0; a < it && a < 64; ++a) if (hashes[a] == hash) loop = 1;
             if (it < 64) hashes[it] = hash;
@@ -249,6 +395,7 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
         __syncthreads();
         const bool loop = ((int*)L.red)[20] != 0;
         __syncthreads();
+        PSTAMP(5);
         if (loop) { it++; break; }
         if (sqrt(del0 * del0 + del1 * del1) < P.epsilon_xy && fabs(dth) < P.epsilon_theta) { it++; break; }
         x_old[0] = x_new[0]; x_old[1] = x_new[1]; x_old[2] = x_new[2];
@@ -258,7 +405,7 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
 }
 
 // scans: [S][n] ranges in cm (PMScan::r); out8[b] = {x, y, theta (m, m, rad), valid, error, iterations, kept, 0}
-__global__ __launch_bounds__(PLICP_THREADS) void plicp_kernel(PlicpParam P, int B, const float* __restrict__ g_r,
+__global__ __launch_bounds__(PLICP_THREADS, 2) void plicp_kernel(PlicpParam P, int B, const float* __restrict__ g_r,
                                                               const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
                                                               double* __restrict__ out8)
 {
@@ -270,6 +417,7 @@ __global__ __launch_bounds__(PLICP_THREADS) void plicp_kernel(PlicpParam P, int 
     L.corr = (int*)(L.dist + Np);
     L.rvalid = (uint8_t*)(L.corr + Np); L.svalid = L.rvalid + Np;       // (2 Np bytes inside the 4 Np reserved)
     L.red = (double*)(smem + (size_t)Np * (8 * 8 + 4 + 4));
+    L.hist = (int*)(smem + (size_t)Np * (8 * 8 + 4 + 4) + 1024);
     const double min_reading = P.min_range_cm / 100., max_reading = P.max_range_cm / 100.;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
@@ -281,9 +429,11 @@ __global__ __launch_bounds__(PLICP_THREADS) void plicp_kernel(PlicpParam P, int 
                 const double rm = valid ? r / 100.0 : -1.0;
                 if (valid && !(rm > min_reading && rm < max_reading)) valid = false;
                 const double x = cos(theta) * rm, y = sin(theta) * rm;
-                if (w) { L.sx[i] = x; L.sy[i] = y; L.svalid[i] = valid; } else { L.rx[i] = x; L.ry[i] = y; L.rvalid[i] = valid; }
+                if (w) { L.sx[i] = x; L.sy[i] = y; L.svalid[i] = valid; }
+                else { L.rx[i] = valid ? x : 1e150; L.ry[i] = valid ? y : 1e150; L.rvalid[i] = valid; }     // (never read when invalid, except by the window scan)
             }
         }
+        for (int i = tid; i < n; i += PLICP_THREADS) L.corr[i] = -1;      // no previous match to seed the search with
         __syncthreads();
         const double q0[3] = {0, 0, 0};
         double x[3] = {0, 0, 0}, error = 0, res[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -152,7 +152,7 @@ static void kill_outliers_trim(const orc_plicp_params* P, const scan_t* ref, con
     free(dist);
 }
 
-/* largest real root of l^4 + a3 l^3 + a2 l^2 + a1 l + a0 (Newton from above the Cauchy bound: to the right
+/* largest real root of l^4 + a3 l^3 + a2 l^2 + a1 l + a0 (Newton from above a bound on the root moduli: to the right
  * of every real root a monic quartic and its derivatives are positive, so the iteration descends
  * monotonically onto the largest one) */
 static int quartic_largest_root(double a3, double a2, double a1, double a0, double* root)
@@ -161,7 +161,15 @@ static int quartic_largest_root(double a3, double a2, double a1, double a0, doub
     if (fabs(a2) > m) m = fabs(a2);
     if (fabs(a1) > m) m = fabs(a1);
     if (fabs(a0) > m) m = fabs(a0);
-    double l = 1 + m;
+    /* Fujiwara's bound on the root moduli: 2 max(|a3|, |a2|^(1/2), |a1|^(1/3), |a0 / 2|^(1/4)) */
+    double fb = fabs(a3);
+    {
+        const double t2 = sqrt(fabs(a2)), t1 = cbrt(fabs(a1)), t0 = sqrt(sqrt(fabs(a0) * 0.5));
+        if (t2 > fb) fb = t2;
+        if (t1 > fb) fb = t1;
+        if (t0 > fb) fb = t0;
+    }
+    double l = 2 * fb * (1 + 1e-12) + 1e-300;
     for (int it = 0; it < 200; ++it) {
         const double p = (((l + a3) * l + a2) * l + a1) * l + a0;
         const double dp = ((4 * l + 3 * a3) * l + 2 * a2) * l + a1;

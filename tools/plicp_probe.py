@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Diagnostic: one batch of CCanonicalMatcher's point-to-line ICP (for rocprofv3 --pmc runs)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from laser_slam_amd import capi, synth
+if len(sys.argv) > 1:
+    capi.LIB_PATH = os.path.abspath(sys.argv[1])
+import torch
+raw = np.concatenate([synth.make_scans(200, noise_seed=12345 + j)[0] for j in range(2)], 0)
+p = capi.param_make(**synth.SYN1081); ctx = capi.Context(p, 0)
+B = 4096
+idx = np.arange(B) % (len(raw) - 1); idx = np.where(idx % 200 == 199, idx - 1, idx).astype(np.int32)
+d_r = torch.from_numpy(raw).cuda(); ri = torch.from_numpy(idx).cuda(); ai = ri + 1
+out = torch.zeros(B, 8, dtype=torch.float64, device="cuda"); torch.cuda.synchronize()
+capi.plicp_batch(ctx, B, d_r, ri, ai, out); ctx.sync()
+t0 = time.perf_counter(); capi.plicp_batch(ctx, B, d_r, ri, ai, out); ctx.sync(); dt = time.perf_counter() - t0
+print("plicp: %.0f matches/s, mean iterations %.2f, valid %.3f" % (B / dt, float(out[:, 5].mean()), float(out[:, 3].mean())))
+if hasattr(capi.lib(), "lsa_debug_plicp_cycles"):
+    import ctypes as C
+    buf = (C.c_ulonglong * 8)()
+    capi.lib().lsa_debug_plicp_cycles(buf)
+    v = np.array(list(buf), np.float64) / (2 * B) / float(out[:, 5].mean())
+    print("cycles per iteration: nn=%.0f doubles=%.0f trim=%.0f sums=%.0f solve=%.0f hash/stop=%.0f | per iteration: slow-path points %.1f, candidates %.0f" % tuple(v[:8]))
