@@ -205,7 +205,11 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
                     fast = M + 8 <= range_min;
                     lo0 = c0f - M > 0 ? c0f - M : 0; hi0 = c0f + M < n - 1 ? c0f + M : n - 1;
                 }
+#ifdef LSA_PLICP_DIAG_NOSLOW
+                if (false) {
+#else
                 if (!fast) {
+#endif
                     const double rho = sqrt(wx * wx + wy * wy);
                     const double phi = atan2(wy, wx);
                     const double delta = fabs(P.max_angular_correction_deg * (PI / 180.0)) + fabs(atan(P.max_linear_correction / rho));
@@ -235,14 +239,13 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
                         nseg = 3;
                     }
                 }
-#ifdef LSA_PLICP_STAMPS
-                atomicAdd(&lsa_plicp_cycles[6], fast ? 0ull : 1ull);
-                atomicAdd(&lsa_plicp_cycles[7], (unsigned long long)((hi0 >= lo0 ? hi0 - lo0 + 1 : 0) + (hi1 >= lo1 ? hi1 - lo1 + 1 : 0) + (hi2 >= lo2 ? hi2 - lo2 + 1 : 0)));
-#endif
                 for (int sg = 0; sg < nseg; ++sg) {
                     const int a = sg == 0 ? lo0 : sg == 1 ? lo1 : lo2, e = sg == 0 ? hi0 : sg == 1 ? hi1 : hi2;
                     // (invalid reference rays carry coordinates of 1e150: their distance exceeds every limit)
                     int j = a;
+#ifdef LSA_PLICP_DIAG_NOSCAN
+                    j = e + 1;
+#endif
                     for (; j + 3 <= e; j += 4) {
                         const double d0 = plicp_dist2(wx, wy, L.rx[j], L.ry[j]), d1 = plicp_dist2(wx, wy, L.rx[j + 1], L.ry[j + 1]);
                         const double d2 = plicp_dist2(wx, wy, L.rx[j + 2], L.ry[j + 2]), d3 = plicp_dist2(wx, wy, L.rx[j + 3], L.ry[j + 3]);
