@@ -6,7 +6,7 @@
 // the checker is oracle/plicp_oracle.c, whose header lists the steps.
 //
 // One 256-thread workgroup per scan pair, everything in double like CSM; both scans' Cartesian
-// points, the moved points and the correspondence records live in LDS (9 doubles-worth per beam).
+// points and the correspondence records live in LDS (60 B per beam).
 // Sums use a fixed-order tree, the order statistics of the trimming come from a radix select, and the
 // window scan of the correspondence search is pruned exactly by a bearing bound.
 #include "lsa_device.h"
@@ -33,15 +33,16 @@ __device__ unsigned long long lsa_plicp_cycles[8];
 #else
 #define PSTAMP(slot) do {} while (0)
 #endif
-__host__ __device__ inline int plicp_lds_bytes(int n) { int Np = (n + 63) & ~63; return Np * (8 * 8 + 4 + 4) + 1024 + 1088; }
+__host__ __device__ inline int plicp_lds_bytes(int n) { int Np = (n + 63) & ~63; return Np * (6 * 8 + 4 + 4 + 4) + 1024 + 2 * 1088; }
 
 struct PlicpLds {
-    double *rx, *ry, *sx, *sy, *wx, *wy, *d2, *dist;      // ref / sens / moved points, NN distance^2, segment distance
+    double *rx, *ry, *sx, *sy, *d2, *dist;                // ref / sens points, NN distance^2, segment distance
+    uint16_t *nup, *ndown;                                 // next valid reference ray above / below (0xffff = none)
     int* corr;                                             // j1 | j2 << 16, -1 = none
     uint8_t *rvalid, *svalid;
     unsigned long long* dj;                                // aliases `dist` during the doubles test
     double* red;                                           // reduction scratch, broadcast slots, remembered hashes
-    int* hist;                                             // 264 ints of the radix select
+    int* hist;                                             // 2 x 264 ints of the radix select
 };
 
 __device__ __forceinline__ double plicp_block_sum(double v, double* red)
@@ -71,11 +72,11 @@ __device__ __forceinline__ void plicp_block_sums(double (&v)[K], double* red)
     for (int q = 0; q < K; ++q) v[q] = red[24 + q] + red[24 + K + q] + red[24 + 2 * K + q] + red[24 + 3 * K + q];
 }
 
-// value of ascending rank k among the non-negative entries of dist[0..n) (negative = absent): radix
-// select on the bit patterns, 8 bits per round with a 256-bin LDS histogram (one bin per thread), the
-// thread's own keys kept in registers.  Exact: the result is the bit pattern of an element.
-// `hist` = 256 + 8 ints of scratch.  n <= 5 * PLICP_THREADS.
-__device__ double plicp_select(const double* dist, int n, int k, int* hist)
+// values of ascending ranks k0 and k1 among the non-negative entries of dist[0..n) (negative = absent):
+// radix select on the bit patterns, 8 bits per round, one 256-bin LDS histogram per rank (one bin per
+// thread), the thread's own keys kept in registers.  Exact: the results are bit patterns of elements.
+// `hist` = 2 * (256 + 8) ints of scratch.  n <= 5 * PLICP_THREADS.
+__device__ void plicp_select2(const double* dist, int n, int k0, int k1, int* hist, double& v0, double& v1)
 {
     unsigned long long key[5];
     #pragma unroll
@@ -84,35 +85,42 @@ __device__ double plicp_select(const double* dist, int n, int k, int* hist)
         const double d = i < n ? dist[i] : -1.0;
         key[u] = d < 0 ? ~0ull : (unsigned long long)__double_as_longlong(d);
     }
-    unsigned long long prefix = 0, decided = 0;
+    unsigned long long prefix[2] = {0, 0}, decided = 0;
+    int k[2] = {k0, k1};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int sh = 56; sh >= 0; sh -= 8) {
         __syncthreads();
-        hist[threadIdx.x] = 0;
+        hist[threadIdx.x] = 0; hist[264 + threadIdx.x] = 0;
         __syncthreads();
         #pragma unroll
-        for (int u = 0; u < 5; ++u)
-            if (key[u] != ~0ull && (key[u] & decided) == prefix) atomicAdd(&hist[(int)((key[u] >> sh) & 255)], 1);
+        for (int u = 0; u < 5; ++u) {
+            if (key[u] == ~0ull) continue;
+            const int bin = (int)((key[u] >> sh) & 255);
+            if ((key[u] & decided) == prefix[0]) atomicAdd(&hist[bin], 1);
+            if ((key[u] & decided) == prefix[1]) atomicAdd(&hist[264 + bin], 1);
+        }
         __syncthreads();
-        // inclusive prefix over the 256 bins: within the wave by shuffles, across waves through 4 slots
-        const int c = hist[threadIdx.x];
-        int incl = c;
+        // inclusive prefix over the 256 bins of either histogram: shuffles inside the wave, 4 slots across
+        int c[2] = {hist[threadIdx.x], hist[264 + threadIdx.x]}, incl[2] = {c[0], c[1]};
         #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-        if (lane == 63) hist[256 + wave] = incl;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int a0 = __shfl_up(incl[0], o), a1 = __shfl_up(incl[1], o);
+            if (lane >= o) { incl[0] += a0; incl[1] += a1; }
+        }
+        if (lane == 63) { hist[256 + wave] = incl[0]; hist[264 + 256 + wave] = incl[1]; }
         __syncthreads();
-        int off = 0;
-        for (int w = 0; w < wave; ++w) off += hist[256 + w];
-        incl += off;
-        // the bin where the running count passes k (exactly one thread)
-        if (k < incl && k >= incl - c) { hist[260] = (int)threadIdx.x; hist[261] = incl - c; }
+        for (int w = 0; w < wave; ++w) { incl[0] += hist[256 + w]; incl[1] += hist[264 + 256 + w]; }
+        // the bin where the running count passes k (exactly one thread per rank)
+        #pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (k[q] < incl[q] && k[q] >= incl[q] - c[q]) { hist[264 * q + 260] = (int)threadIdx.x; hist[264 * q + 261] = incl[q] - c[q]; }
         __syncthreads();
-        const int b = hist[260];
-        k -= hist[261];
-        prefix |= (unsigned long long)b << sh;
+        #pragma unroll
+        for (int q = 0; q < 2; ++q) { prefix[q] |= (unsigned long long)hist[264 * q + 260] << sh; k[q] -= hist[264 * q + 261]; }
         decided |= 255ull << sh;
     }
-    return __longlong_as_double((long long)prefix);
+    v0 = __longlong_as_double((long long)prefix[0]);
+    v1 = __longlong_as_double((long long)prefix[1]);
 }
 
 
@@ -176,7 +184,6 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
             double best = 0;
             if (L.svalid[i]) {
                 const double wx = cs * L.sx[i] - sn * L.sy[i] + x_old[0], wy = sn * L.sx[i] + cs * L.sy[i] + x_old[1];
-                L.wx[i] = wx; L.wy[i] = wy;
                 int j1 = -1;
                 const double lim = P.max_correspondence_dist * P.max_correspondence_dist;
                 // The reference scans the window start_cell +- ceil((45 deg + atan(0.5 m / rho)) / res) around the
@@ -199,11 +206,28 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
                 if (fast) {
                     double bound = lim;
                     if (L.rvalid[c0f]) { const double d = plicp_dist2(wx, wy, L.rx[c0f], L.ry[c0f]); bound = d < bound ? d : bound; }
+                    else {      // the nearest valid rays on either side of an invalid one (inside the +-45 deg of every window)
+                        const int su = L.nup[c0f], sd = L.ndown[c0f];
+                        if (su != 0xffff && su - c0f <= range_min - 8) { const double d = plicp_dist2(wx, wy, L.rx[su], L.ry[su]); bound = d < bound ? d : bound; }
+                        if (sd != 0xffff && c0f - sd <= range_min - 8) { const double d = plicp_dist2(wx, wy, L.rx[sd], L.ry[sd]); bound = d < bound ? d : bound; }
+                    }
                     if (prev >= 0 && abs(prev - c0f) <= range_min - 8 && L.rvalid[prev]) { const double d = plicp_dist2(wx, wy, L.rx[prev], L.ry[prev]); bound = d < bound ? d : bound; }
+                    // a poor bound (a quarter of the point's range or more) would mean a scan of hundreds of rays that
+                    // the whole wave waits for: a few more seeds at growing offsets usually find something closer
+                    if (__ballot(bound > 0.0625 * (double)(rho_f * rho_f))) {
+                        #pragma unroll
+                        for (int o = 2; o <= 32; o *= 2) {
+                            const int ja = c0f - o, jb = c0f + o;
+                            if (ja >= 0) { const double d = plicp_dist2(wx, wy, L.rx[ja], L.ry[ja]); bound = d < bound ? d : bound; }   // (invalid rays: 1e150)
+                            if (jb <= n - 1) { const double d = plicp_dist2(wx, wy, L.rx[jb], L.ry[jb]); bound = d < bound ? d : bound; }
+                        }
+                    }
                     const float tq = sqrtf((float)bound) * 1.0001f / rho_f;
                     const int M = tq < 1.0f ? (int)((tq + 0.5708f * tq * tq * tq) / P.dfi) + 5 : n;      // asin t <= t + (pi/2 - 1) t^3
                     fast = M + 8 <= range_min;
                     lo0 = c0f - M > 0 ? c0f - M : 0; hi0 = c0f + M < n - 1 ? c0f + M : n - 1;
+                    // (Scanning in rings outwards from the bearing with a half width that shrinks as closer points
+                    //  turn up was measured slower than this one ascending scan from the seeds' bound.)
                 }
 #ifdef LSA_PLICP_DIAG_NOSLOW
                 if (false) {
@@ -239,6 +263,14 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
                         nseg = 3;
                     }
                 }
+#ifdef LSA_PLICP_COUNTS
+                {
+                    const int cand = (hi0 >= lo0 ? hi0 - lo0 + 1 : 0) + (hi1 >= lo1 ? hi1 - lo1 + 1 : 0) + (hi2 >= lo2 ? hi2 - lo2 + 1 : 0);
+                    atomicAdd(&lsa_plicp_cycles[6], fast ? 0ull : (nseg == 3 ? 1ull : 1ull << 20));          // slow bounded | slow unbounded << 20
+                    atomicAdd(&lsa_plicp_cycles[7], (unsigned long long)cand | ((unsigned long long)(cand > 64) << 32));
+                }
+#endif
+                PSTAMP(6);
                 for (int sg = 0; sg < nseg; ++sg) {
                     const int a = sg == 0 ? lo0 : sg == 1 ? lo1 : lo2, e = sg == 0 ? hi0 : sg == 1 ? hi1 : hi2;
                     // (invalid reference rays carry coordinates of 1e150: their distance exceeds every limit)
@@ -259,10 +291,9 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
                         if (!(d > lim) && (j1 == -1 || d < best)) { j1 = j; best = d; }
                     }
                 }
+                PSTAMP(7);
                 if (!(j1 == -1 || j1 == 0 || j1 == n - 1)) {
-                    int up = -1, down = -1;
-                    for (int j = j1 + 1; j < n; ++j) if (L.rvalid[j]) { up = j; break; }
-                    for (int j = j1 - 1; j >= 0; --j) if (L.rvalid[j]) { down = j; break; }
+                    const int up = L.nup[j1] == 0xffff ? -1 : (int)L.nup[j1], down = L.ndown[j1] == 0xffff ? -1 : (int)L.ndown[j1];
                     int j2 = -1;
                     if (up == -1) j2 = down;
                     else if (down == -1) j2 = up;
@@ -293,7 +324,7 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
             double d = -1.0;
             if (L.corr[i] >= 0) {
                 const int j1 = L.corr[i] & 0xffff, j2 = L.corr[i] >> 16;
-                d = plicp_seg_dist(L.rx[j1], L.ry[j1], L.rx[j2], L.ry[j2], L.wx[i], L.wy[i]);
+                d = plicp_seg_dist(L.rx[j1], L.ry[j1], L.rx[j2], L.ry[j2], cs * L.sx[i] - sn * L.sy[i] + x_old[0], sn * L.sx[i] + cs * L.sy[i] + x_old[1]);
                 mine++;
             }
             L.dist[i] = d;                                  // -1 = no correspondence
@@ -303,8 +334,9 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
         if (k > 0) {
             int order = (int)floor(k * P.outliers_maxPerc), order2 = (int)floor(k * P.outliers_adaptive_order);
             order = order < 0 ? 0 : (order > k - 1 ? k - 1 : order); order2 = order2 < 0 ? 0 : (order2 > k - 1 ? k - 1 : order2);
-            const double limit1 = plicp_select(L.dist, n, order, L.hist);
-            const double limit2 = P.outliers_adaptive_mult * plicp_select(L.dist, n, order2, L.hist);
+            double limit1, limit2;
+            plicp_select2(L.dist, n, order, order2, L.hist, limit1, limit2);
+            limit2 *= P.outliers_adaptive_mult;
             const double limit = limit1 < limit2 ? limit1 : limit2;
             double err = 0;
             mine = 0;
@@ -415,12 +447,13 @@ __global__ __launch_bounds__(PLICP_THREADS, 2) void plicp_kernel(PlicpParam P, i
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = P.n, Np = (n + 63) & ~63, tid = threadIdx.x;
     PlicpLds L;
-    L.rx = (double*)smem; L.ry = L.rx + Np; L.sx = L.ry + Np; L.sy = L.sx + Np; L.wx = L.sy + Np; L.wy = L.wx + Np;
-    L.d2 = L.wy + Np; L.dist = L.d2 + Np; L.dj = (unsigned long long*)L.dist;
+    L.rx = (double*)smem; L.ry = L.rx + Np; L.sx = L.ry + Np; L.sy = L.sx + Np;
+    L.d2 = L.sy + Np; L.dist = L.d2 + Np; L.dj = (unsigned long long*)L.dist;
     L.corr = (int*)(L.dist + Np);
     L.rvalid = (uint8_t*)(L.corr + Np); L.svalid = L.rvalid + Np;       // (2 Np bytes inside the 4 Np reserved)
-    L.red = (double*)(smem + (size_t)Np * (8 * 8 + 4 + 4));
-    L.hist = (int*)(smem + (size_t)Np * (8 * 8 + 4 + 4) + 1024);
+    L.nup = (uint16_t*)(L.rvalid + 4 * Np); L.ndown = L.nup + Np;
+    L.red = (double*)(smem + (size_t)Np * (6 * 8 + 4 + 4 + 4));
+    L.hist = (int*)(smem + (size_t)Np * (6 * 8 + 4 + 4 + 4) + 1024);
     const double min_reading = P.min_range_cm / 100., max_reading = P.max_range_cm / 100.;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
@@ -435,6 +468,14 @@ __global__ __launch_bounds__(PLICP_THREADS, 2) void plicp_kernel(PlicpParam P, i
                 if (w) { L.sx[i] = x; L.sy[i] = y; L.svalid[i] = valid; }
                 else { L.rx[i] = valid ? x : 1e150; L.ry[i] = valid ? y : 1e150; L.rvalid[i] = valid; }     // (never read when invalid, except by the window scan)
             }
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += PLICP_THREADS) {                    // ld_next_valid_up / _down as tables
+            int up = j + 1, down = j - 1;
+            while (up < n && !L.rvalid[up]) ++up;
+            while (down >= 0 && !L.rvalid[down]) --down;
+            L.nup[j] = up < n ? (uint16_t)up : (uint16_t)0xffff;
+            L.ndown[j] = down >= 0 ? (uint16_t)down : (uint16_t)0xffff;
         }
         for (int i = tid; i < n; i += PLICP_THREADS) L.corr[i] = -1;      // no previous match to seed the search with
         __syncthreads();

@@ -22,4 +22,9 @@ if hasattr(capi.lib(), "lsa_debug_plicp_cycles"):
     buf = (C.c_ulonglong * 8)()
     capi.lib().lsa_debug_plicp_cycles(buf)
     v = np.array(list(buf), np.float64) / (2 * B) / float(out[:, 5].mean())
-    print("cycles per iteration: nn=%.0f doubles=%.0f trim=%.0f sums=%.0f solve=%.0f hash/stop=%.0f | per iteration: slow-path points %.1f, candidates %.0f" % tuple(v[:8]))
+    print("cycles per iteration: nn=%.0f doubles=%.0f trim=%.0f sums=%.0f solve=%.0f hash/stop=%.0f | inside nn: plan+seeds %.0f, window scan %.0f (the rest of nn: second point, records)" % tuple(v[:8]))
+    raw6, raw7 = int(buf[6]), int(buf[7])
+    if os.environ.get("LSA_PLICP_COUNTS"):
+        its = 2 * B * float(out[:, 5].mean())
+        print("per iteration: slow bounded %.1f, slow unbounded %.1f, candidates %.0f, points with > 64 candidates %.1f"
+              % ((raw6 & 0xfffff) / its, (raw6 >> 20) / its, (raw7 & 0xffffffff) / its, (raw7 >> 32) / its))
