@@ -230,8 +230,8 @@ def extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p):
     """Secondary kernels of the path, timed the same way (not the headline)."""
     from laser_slam_amd import synth
     res = {}
-    # point-to-line ICP (CCanonicalMatcher / zhcsm's matcher), raw scans, 4096 pairs
-    Bp = 4096
+    # point-to-line ICP (CCanonicalMatcher / zhcsm's matcher), raw scans, 8192 pairs
+    Bp = 8192
     d_raw = torch.from_numpy(raw).cuda()
     d_o8 = torch.zeros(Bp, 8, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
