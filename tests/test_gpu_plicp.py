@@ -45,3 +45,33 @@ def test_plicp_matches_oracle_and_recovers_motion(n_beams):
     one = capi.plicp_host(ctx, raw[0], raw[1])
     assert np.array_equal(one, got[0])
     ctx.close()
+
+
+def test_plicp_restart_path():
+    """Noisier scans (3 cm) push the mean error over 1 cm: the loop is rerun from six perturbed starts and the
+    lowest total error wins - device against oracle on the whole record."""
+    import torch
+    from laser_slam_amd import capi, synth
+    from oracle_lib import plicp
+    n_beams = 541
+    kw = dict(points=n_beams, fov_deg=270, max_range=3000, min_valid=100, window=50, fi_min_deg=-135, fi_max_deg=135)
+    p = capi.param_make(**kw)
+    ctx = capi.Context(p)
+    raw, _ = synth.make_scans(8, n_beams=n_beams, sigma_m=0.03)
+    B = 7
+    ri = np.arange(B, dtype=np.int32); ai = ri + 1
+    d_out = torch.zeros(B, 8, dtype=torch.float64, device="cuda")
+    d_r = torch.from_numpy(raw).cuda()
+    torch.cuda.synchronize()
+    capi.plicp_batch(ctx, B, d_r, torch.from_numpy(ri).cuda(), torch.from_numpy(ai).cuda(), d_out)
+    ctx.sync()
+    got = d_out.cpu().numpy()
+    restarted = 0
+    for b in range(B):
+        want = plicp(raw[b], raw[b + 1], p.fi_min, p.dfi, p.min_range, p.max_range)
+        assert got[b, 3] == want[3] == 1.0
+        assert got[b, 5] == want[5]                                   # same number of iterations over all the loops
+        assert np.allclose(got[b, :3], want[:3], atol=5e-6) and abs(got[b, 4] - want[4]) <= 1e-6 * want[4]
+        restarted += want[5] > 10
+    assert restarted >= B // 2
+    ctx.close()
