@@ -197,6 +197,40 @@ def test_match_vs_oracle_shuffled_pairs(name, torch_mod):
     ctx.close()
 
 
+def test_match_soak_vs_oracle(torch_mod):
+    """A wider net than the golden sets: 900 pairs of synthetic 1081-beam scans (several noise seeds; scans
+    0-3 apart, both directions) with random initial poses, both matchers, against the CPU oracle: every
+    status equal and every pose bit-identical."""
+    torch = torch_mod
+    from laser_slam_amd import capi, synth
+    from oracle_lib import SYN1081, Oracle
+    rng = np.random.default_rng(2024)
+    raws = [synth.make_scans(40, noise_seed=synth.WORLD_SEED + 100 + j)[0] for j in range(3)]
+    raw = np.concatenate(raws, 0)
+    o = Oracle(**SYN1081)
+    ctx = capi.Context(capi.param_make(**synth.SYN1081))
+    pre = [o.preprocess(raw[k]) for k in range(len(raw))]
+    r = np.stack([q[0] for q in pre]); bad = np.stack([q[1] for q in pre]); seg = np.stack([q[2] for q in pre])
+    B = 450
+    base = rng.integers(0, 3, B) * 40
+    a = rng.integers(0, 40, B); b = np.clip(a + rng.integers(-3, 4, B), 0, 39)
+    ref_idx, act_idx = base + a, base + b
+    # init = (ref pose, act pose) as the callers pass them: a random world pose and a perturbed relative guess
+    init = np.zeros((B, 6), np.float32)
+    init[:, 0:2] = rng.uniform(-300, 300, (B, 2)); init[:, 2] = rng.uniform(-3, 3, B)
+    init[:, 3:5] = init[:, 0:2] + rng.uniform(-25, 25, (B, 2)); init[:, 5] = init[:, 2] + rng.uniform(-0.05, 0.05, B)
+    init[: B // 3] = 0                                     # a third with the zero guess of the front end
+    bad_pairs = 0
+    for which in (0, 1):
+        out = run_match(torch, ctx, which, r, bad, seg, ref_idx, act_idx, init=init, want_err=False)
+        for k in range(B):
+            st, pose, _, _ = o.match(which, pre[ref_idx[k]], pre[act_idx[k]], init[k, :3], init[k, 3:])
+            if st != out["status"][k] or (st == 0 and not same_bits(pose, out["pose"][k])):
+                bad_pairs += 1
+    assert bad_pairs == 0
+    ctx.close()
+
+
 @pytest.mark.parametrize("n_beams,window", [(64, 20), (200, 40), (777, 150), (1000, 200), (1280, 200)])
 def test_match_vs_oracle_other_beam_counts(n_beams, window, torch_mod):
     """Beam counts outside the presets run the size-generic kernel (the presets' sizes are compiled
