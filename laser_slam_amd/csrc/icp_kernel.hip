@@ -290,9 +290,14 @@ __device__ __forceinline__ void nn_plan(const DevParam& P, const Lds& L, int i, 
 __device__ __forceinline__ void nn_flat(const Lds& L, int N, NnBeam& b)
 {
     static_assert(NN_FLAT == 8, "nn_flat is written for eight rays");
+#ifdef LSA_DIAG_OLD_FLAT
+    #pragma unroll
+    for (int o = 0; o < NN_FLAT; ++o) nn_eval_pred(L, N, b.p, b.s0 + o, b.flat && b.s0 + o <= b.e0, b.best, b.best_j);
+    return;
+#endif
     const int base = b.s0 < N - 8 ? (b.s0 > 0 ? b.s0 : 0) : N - 8;
     const int off = b.s0 - base;                                       // 0 unless clamped
-    const int cnt = b.flat ? b.e0 - b.s0 + 1 : 0;                      // <= 8
+    const int cnt = b.flat && b.e0 >= b.s0 ? b.e0 - b.s0 + 1 : 0;      // 0 .. 8 (an empty range may have e0 < s0 - 1)
     const uint32_t act = good_window(L, base) & (((1u << cnt) - 1u) << off) & 0xffu;
     const float2* r = L.ref_xy + base;
     #pragma unroll
@@ -463,12 +468,22 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt
         __syncthreads();
         const int seg = k - 64 * wave < 64 ? k - 64 * wave : 64;        // records of this wave (may be <= 0)
         int rank = 0;
+#ifdef LSA_DIAG_OLD_FIRSTK
+        if (tid < k) Pc[count_split(cd, k, d, tid + 1)] = rec;
+        __syncthreads();
+        if (false) {
+#else
         if (tid < k) {
+#endif
             rank = count_split(cd + 64 * wave, seg, d, lane + 1);
             ce[64 * wave + rank] = d;
         }
         __syncthreads();
+#ifdef LSA_DIAG_OLD_FIRSTK
+        if (false) {
+#else
         if (tid < k) {
+#endif
             const int t1 = (int)f2u(d);
             const int* srt = (const int*)ce;
             for (int b = 0; 64 * b < k; ++b) {

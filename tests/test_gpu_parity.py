@@ -197,6 +197,37 @@ def test_match_vs_oracle_shuffled_pairs(name, torch_mod):
     ctx.close()
 
 
+@pytest.mark.parametrize("name", ["mit", "fr079", "intel", "indoor"])
+def test_match_wide_pairs_vs_oracle(name, torch_mod):
+    """Every pair of the log head up to 6 scans apart (rotations of tens of degrees: bearings far outside the
+    search window, empty candidate ranges, many failures), a third with random priors, both matchers,
+    against the CPU oracle.  (This is the test that caught an empty-range bug in the straight-line NN path.)"""
+    torch = torch_mod
+    from oracle_lib import Oracle
+    g = load(name)
+    ctx, p = make_ctx(name, g)
+    o = Oracle(SETS[name][0]); o.set_fimin_maxrange(np.float32(p.fi_min), p.max_range)
+    r, bad, seg = (np.ascontiguousarray(g[k]) for k in ("pre_r", "pre_bad", "pre_seg"))
+    S = r.shape[0]
+    pairs = [(i, j) for i in range(S) for j in range(max(0, i - 6), min(S, i + 7))]
+    ref_idx = np.array([a for a, _ in pairs], np.int32); act_idx = np.array([b for _, b in pairs], np.int32)
+    B = len(pairs)
+    rng = np.random.default_rng(3)
+    init = np.zeros((B, 6), np.float32)
+    init[:, 0:2] = rng.uniform(-200, 200, (B, 2)); init[:, 2] = rng.uniform(-3, 3, B)
+    init[:, 3:5] = init[:, 0:2] + rng.uniform(-40, 40, (B, 2)); init[:, 5] = init[:, 2] + rng.uniform(-0.15, 0.15, B)
+    init[np.arange(B) % 3 != 1] = 0
+    for which in (0, 1):
+        out = run_match(torch, ctx, which, r, bad, seg, ref_idx, act_idx, init=init, want_err=False)
+        mism = 0
+        for k in range(B):
+            st, pose, _, _ = o.match(which, (r[ref_idx[k]], bad[ref_idx[k]], seg[ref_idx[k]]),
+                                     (r[act_idx[k]], bad[act_idx[k]], seg[act_idx[k]]), init[k, :3], init[k, 3:])
+            mism += (st != out["status"][k]) or (st == 0 and not same_bits(pose, out["pose"][k]))
+        assert mism == 0, (name, which, mism)
+    ctx.close()
+
+
 def test_match_soak_vs_oracle(torch_mod):
     """A wider net than the golden sets: 900 pairs of synthetic 1081-beam scans (several noise seeds; scans
     0-3 apart, both directions) with random initial poses, both matchers, against the CPU oracle: every
