@@ -16,7 +16,7 @@ o = Oracle(**SYN1081)
 pre = [o.preprocess(raw[k]) for k in range(len(raw))]
 r = np.stack([q[0] for q in pre]); bad = np.stack([q[1] for q in pre]); seg = np.stack([q[2] for q in pre])
 base = rng.integers(0, 6, B) * 60
-a = rng.integers(0, 60, B); b = np.clip(a + rng.integers(-4, 5, B), 0, 59)
+a = rng.integers(0, 60, B); b = np.clip(a + rng.integers(-12, 13, B), 0, 59)
 ri, ai = (base + a).astype(np.int32), (base + b).astype(np.int32)
 init = np.zeros((B, 6), np.float32)
 init[:, 0:2] = rng.uniform(-300, 300, (B, 2)); init[:, 2] = rng.uniform(-3, 3, B)
