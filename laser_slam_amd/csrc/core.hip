@@ -50,6 +50,7 @@ struct lsa_ctx {
     float* d_small = nullptr;    // init pose[6] | pose[3] | ret | exy[2]
     int* d_ismall = nullptr;     // n_assoc | status | iters
     int staged_n = 0;
+    double* d_trig = nullptr;    // point-to-line ICP: cos | sin of the beam bearings in double, 2*N (host libm, as CSM's ld_compute_cartesian on the CPU)
 };
 
 static lsa::DevParam dev_param(const lsa_ctx* c)
@@ -117,6 +118,18 @@ int lsa_debug_plicp_cycles(unsigned long long* out8)
     HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(lsa::lsa_plicp_cycles), sizeof(unsigned long long) * 8));
     unsigned long long z[8] = {0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lsa::lsa_plicp_cycles), z, sizeof z));
+    return LSA_OK;
+}
+#endif
+
+#ifdef LSA_PLICP_TRACE
+int lsa_debug_plicp_trace(double* out, int* n)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(lsa::lsa_plicp_trace), sizeof(double) * 8 * 128));
+    HIP_TRY(hipMemcpyFromSymbol(n, HIP_SYMBOL(lsa::lsa_plicp_trace_n), sizeof(int)));
+    int z = 0;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lsa::lsa_plicp_trace_n), &z, sizeof z));
     return LSA_OK;
 }
 #endif
@@ -268,6 +281,7 @@ void lsa_ctx_destroy(lsa_ctx* c)
     hipStreamSynchronize(c->stream);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     hipFree(c->d_tab);
+    if (c->d_trig) hipFree(c->d_trig);
     if (c->d_r) { hipFree(c->d_r); hipFree(c->d_bad); hipFree(c->d_seg); hipFree(c->d_idx); hipFree(c->d_small); hipFree(c->d_ismall); }
     delete c;
 }
@@ -1179,10 +1193,19 @@ int lsa_plicp_batch(lsa_ctx* c, int B, const float* d_r, const int32_t* d_ref_id
     P.restart_threshold_mean_error = o.restart_threshold_mean_error; P.restart_dt = o.restart_dt; P.restart_dtheta = o.restart_dtheta;
     P.outliers_maxPerc = o.outliers_maxPerc; P.outliers_adaptive_order = o.outliers_adaptive_order;
     P.outliers_adaptive_mult = o.outliers_adaptive_mult; P.outliers_remove_doubles = o.outliers_remove_doubles;
+    if (!c->d_trig) {
+        // The bearings' cosines and sines come from the host's libm once per context: CSM computes the scans' Cartesian
+        // points on the CPU, and range-quantised scans hold many exactly symmetric neighbour pairs whose nearer-of-two
+        // choice is decided by the last bit of these products.
+        std::vector<double> t(2 * (size_t)P.n);
+        for (int i = 0; i < P.n; ++i) { const double th = (double)(P.fi_min + P.dfi * i); t[i] = cos(th); t[P.n + i] = sin(th); }
+        HIP_TRY(hipMalloc((void**)&c->d_trig, sizeof(double) * t.size()));
+        HIP_TRY(hipMemcpy(c->d_trig, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+    }
     static bool once = false;
     if (!once) { once = true; HIP_TRY(hipFuncSetAttribute((const void*)lsa::plicp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
     hipLaunchKernelGGL(lsa::plicp_kernel, dim3(B), dim3(lsa::PLICP_THREADS), lsa::plicp_lds_bytes(P.n), c->stream, P, B, d_r,
-                       d_ref_idx, d_act_idx, d_out8);
+                       d_ref_idx, d_act_idx, c->d_trig, d_out8);
     HIP_TRY(hipGetLastError());
     return LSA_OK;
 }

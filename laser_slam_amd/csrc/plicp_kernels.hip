@@ -33,6 +33,10 @@ __device__ unsigned long long lsa_plicp_cycles[8];
 #else
 #define PSTAMP(slot) do {} while (0)
 #endif
+#ifdef LSA_PLICP_TRACE       // diagnostic build only: per iteration record of workgroup 0 (x_new, error, kept, matched, limit, hash)
+__device__ double lsa_plicp_trace[8 * 128];
+__device__ int lsa_plicp_trace_n;
+#endif
 __host__ __device__ inline int plicp_lds_bytes(int n) { int Np = (n + 63) & ~63; return Np * (6 * 8 + 4 + 4 + 4) + 1024 + 2 * 1088; }
 
 struct PlicpLds {
@@ -225,6 +229,9 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
                     const float tq = sqrtf((float)bound) * 1.0001f / rho_f;
                     const int M = tq < 1.0f ? (int)((tq + 0.5708f * tq * tq * tq) / P.dfi) + 5 : n;      // asin t <= t + (pi/2 - 1) t^3
                     fast = M + 8 <= range_min;
+#ifdef LSA_PLICP_DIAG_FULLSCAN          // diagnostic build only: the reference's whole window, no pruning
+                    fast = false;
+#endif
                     lo0 = c0f - M > 0 ? c0f - M : 0; hi0 = c0f + M < n - 1 ? c0f + M : n - 1;
                     // (Scanning in rings outwards from the bearing with a half width that shrinks as closer points
                     //  turn up was measured slower than this one ascending scan from the seeds' bound.)
@@ -250,7 +257,11 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
                     if (prev >= from && prev <= to && L.rvalid[prev]) { const double d = plicp_dist2(wx, wy, L.rx[prev], L.ry[prev]); bound = d < bound ? d : bound; }
                     const double sb = sqrt(bound) * (1.0 + 1e-9) + 1e-12;
                     lo0 = from; hi0 = to;
+#ifdef LSA_PLICP_DIAG_FULLSCAN
+                    if (false) {
+#else
                     if (sb < rho) {
+#endif
                         const double tq = sb / rho;                                      // asin t <= t + (pi/2 - 1) t^3 on [0, 1]
                         const int M = (int)((tq + 0.5708 * tq * tq * tq) / (double)P.dfi) + 3;   // bearings are float(fi_min + dfi j): margin
                         const int T = (int)rint(2 * PI / (double)P.dfi);
@@ -338,6 +349,9 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
             plicp_select2(L.dist, n, order, order2, L.hist, limit1, limit2);
             limit2 *= P.outliers_adaptive_mult;
             const double limit = limit1 < limit2 ? limit1 : limit2;
+#ifdef LSA_PLICP_TRACE
+            if (tid == 0 && blockIdx.x == 0 && lsa_plicp_trace_n < 128) { lsa_plicp_trace[8 * lsa_plicp_trace_n + 6] = limit; lsa_plicp_trace[8 * lsa_plicp_trace_n + 5] = num + 1000.0 * k; }
+#endif
             double err = 0;
             mine = 0;
             for (int i = tid; i < n; i += PLICP_THREADS) {
@@ -426,6 +440,12 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
             for (int a = 0; a < it && a < 64; ++a) if (hashes[a] == hash) loop = 1;
             if (it < 64) hashes[it] = hash;
             ((int*)L.red)[20] = loop;
+#ifdef LSA_PLICP_TRACE
+            if (blockIdx.x == 0 && lsa_plicp_trace_n < 128) {
+                double* t = lsa_plicp_trace + 8 * lsa_plicp_trace_n++;
+                t[0] = x_new[0]; t[1] = x_new[1]; t[2] = x_new[2]; t[3] = total_error; t[4] = nvalid; t[7] = hash;
+            }
+#endif
         }
         __syncthreads();
         const bool loop = ((int*)L.red)[20] != 0;
@@ -442,7 +462,7 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
 // scans: [S][n] ranges in cm (PMScan::r); out8[b] = {x, y, theta (m, m, rad), valid, error, iterations, kept, 0}
 __global__ __launch_bounds__(PLICP_THREADS, 2) void plicp_kernel(PlicpParam P, int B, const float* __restrict__ g_r,
                                                               const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
-                                                              double* __restrict__ out8)
+                                                              const double* __restrict__ trig, double* __restrict__ out8)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = P.n, Np = (n + 63) & ~63, tid = threadIdx.x;
@@ -458,13 +478,13 @@ __global__ __launch_bounds__(PLICP_THREADS, 2) void plicp_kernel(PlicpParam P, i
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
         for (int i = tid; i < n; i += PLICP_THREADS) {                   // fromPMScan2LDP (:191-227) + ld_compute_cartesian
-            const double theta = (double)(P.fi_min + P.dfi * i);
+            const double cth = trig[i], sth = trig[n + i];             // cos | sin of float(fi_min + dfi i), from the host's libm
             for (int w = 0; w < 2; ++w) {
                 const double r = (double)g_r[(size_t)(w ? act_idx[b] : ref_idx[b]) * n + i];
                 bool valid = !(r <= P.min_range_cm || r >= P.max_range_cm);
                 const double rm = valid ? r / 100.0 : -1.0;
                 if (valid && !(rm > min_reading && rm < max_reading)) valid = false;
-                const double x = cos(theta) * rm, y = sin(theta) * rm;
+                const double x = cth * rm, y = sth * rm;
                 if (w) { L.sx[i] = x; L.sy[i] = y; L.svalid[i] = valid; }
                 else { L.rx[i] = valid ? x : 1e150; L.ry[i] = valid ? y : 1e150; L.rvalid[i] = valid; }     // (never read when invalid, except by the window scan)
             }

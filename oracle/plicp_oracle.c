@@ -33,6 +33,12 @@ typedef struct {
 
 typedef struct { int valid, j1, j2; double d2; } corr_t;
 
+/* optional per-iteration trace for debugging sessions (x_new, error, kept, matched + 1000 k, limit, hash) */
+static double* g_trace; static int g_trace_cap, g_trace_n; static double g_trace_limit; static int g_trace_k;
+void orc_plicp_set_trace(double* buf, int cap) { g_trace = buf; g_trace_cap = cap; g_trace_n = 0; }
+int orc_plicp_trace_count(void) { return g_trace_n; }
+
+
 static void scan_init(scan_t* s, const float* r_cm, int n, float fi_min, float dfi, int min_range_cm, int max_range_cm)
 {
     s->n = n;
@@ -144,6 +150,7 @@ static void kill_outliers_trim(const orc_plicp_params* P, const scan_t* ref, con
     const int order2 = minmax(0, k - 1, (int)floor(k * P->outliers_adaptive_order));
     const double limit1 = sorted[order], limit2 = P->outliers_adaptive_mult * sorted[order2];
     const double limit = limit1 < limit2 ? limit1 : limit2;
+    g_trace_limit = limit; g_trace_k = k;
     for (int i = 0; i < sens->n; ++i) {
         if (!c[i].valid) continue;
         if (dist[i] > limit) { c[i].valid = 0; c[i].j1 = c[i].j2 = -1; }
@@ -269,6 +276,10 @@ static int icp_loop(const orc_plicp_params* P, const scan_t* ref, scan_t* sens, 
         /* loop detection on the correspondence set */
         unsigned hash = 0;
         for (int i = 0; i < sens->n; ++i) hash = hash * 31u + (unsigned)(c[i].valid ? c[i].j1 + 1000 * c[i].j2 : -1);
+        if (g_trace && g_trace_n < g_trace_cap) {
+            double* t = g_trace + 8 * g_trace_n++;
+            t[0] = x_new[0]; t[1] = x_new[1]; t[2] = x_new[2]; t[3] = error; t[4] = nv; t[5] = num + 1000.0 * g_trace_k; t[6] = g_trace_limit; t[7] = hash;
+        }
         int loop = 0;
         for (int a = 0; a < it && a < 64; ++a) if (hashes[a] == hash) loop = 1;
         if (it < 64) hashes[it] = hash;

@@ -75,3 +75,43 @@ def test_plicp_restart_path():
         restarted += want[5] > 10
     assert restarted >= B // 2
     ctx.close()
+
+
+@pytest.mark.parametrize("name", ["mit", "fr079", "intel", "indoor"])
+def test_plicp_log_pairs_vs_oracle(name):
+    """Every pair of the shipped logs' heads up to 6 scans apart.  Range-quantised scans hold many exactly symmetric
+    neighbour pairs (equal readings on the rays either side of the match) whose nearer-of-two choice hangs on the
+    last bit of the Cartesian points: the device takes the bearings' cos / sin from the host's libm for that reason,
+    and the whole record then follows the oracle (same iteration counts, poses within the summation-order noise)."""
+    import torch
+    torch.zeros(1, device="cuda")
+    from laser_slam_amd import capi
+    from helpers import SETS, golden_param, load
+    from oracle_lib import plicp
+    laser, _, _ = SETS[name]
+    g = load(name); gp = golden_param(g)
+    p = capi.param_preset(laser)
+    p.fi_min = float(np.float32(gp["fi_min"])); p.fi_max = float(np.float32(gp["fi_max"])); p.max_range = int(gp["max_range"])
+    raw = np.ascontiguousarray(g["raw_r"], np.float32)
+    S = raw.shape[0]
+    pairs = [(i, j) for i in range(S) for j in range(max(0, i - 6), min(S, i + 7))]
+    ri = np.array([a for a, _ in pairs], np.int32); ai = np.array([b for _, b in pairs], np.int32)
+    B = len(pairs)
+    ctx = capi.Context(p)
+    d_out = torch.zeros(B, 8, dtype=torch.float64, device="cuda")
+    d_r = torch.from_numpy(raw).cuda()
+    torch.cuda.synchronize()
+    capi.plicp_batch(ctx, B, d_r, torch.from_numpy(ri).cuda(), torch.from_numpy(ai).cuda(), d_out)
+    ctx.sync()
+    got = d_out.cpu().numpy()
+    restarted = 0
+    for k in range(B):
+        want = plicp(raw[ri[k]], raw[ai[k]], p.fi_min, p.dfi, p.min_range, p.max_range)
+        assert got[k, 3] == want[3], (k, got[k], want)
+        assert got[k, 5] == want[5], (k, got[k], want)
+        if want[3] == 1.0:
+            assert np.abs(got[k, :3] - want[:3]).max() <= 5e-6, (k, got[k], want)
+            assert got[k, 6] == want[6] and abs(got[k, 4] - want[4]) <= 1e-6 * want[4] + 1e-9, (k, got[k], want)
+            restarted += want[5] > 10
+    assert restarted > 0
+    ctx.close()
