@@ -228,6 +228,14 @@ int lsa_pf_weights(lsa_ctx* c, const float* d_score, int n, float max_score, flo
  * first..first+M-1 out of n_total, grid offset u0 in [0,1) */
 int lsa_pf_resample(lsa_ctx* c, const float* d_w, int n, double u0, int n_total, int first, int M,
                     int32_t* d_parent);
+/* Standard_resampler (src/sensorFusion/SIRFlt.cpp:39-115; SIR_scheme::update_resample()'s default,
+ * SIRFlt.hpp:191-193, the one CParticles uses at particles.cpp:353): d_u = n_u uniforms in [0,1) (the
+ * reference draws them from its unseeded mt19937; here the caller supplies them, in any order). A particle is
+ * drawn once per uniform u with cum[i-1] <= u * sum(w) < cum[i]; the parents in ascending order are the order
+ * copy_resamples (:323-356) leaves the particles in; d_parent[M] = offspring first .. first + M - 1 of that list
+ * (a shard's block; first = 0, M = n_u for all of it). */
+int lsa_pf_resample_standard(lsa_ctx* c, const float* d_w, int n, const double* d_u, int n_u, int first, int M,
+                             int32_t* d_parent);
 int lsa_gather_poses(lsa_ctx* c, const float* d_src, const int32_t* d_parent, int M, float* d_dst);
 /* threadLocalization::topK (localization.cpp:126-149): the k largest scores in descending order,
  * equal scores in index order; h_score may be NULL */

@@ -99,6 +99,7 @@ def lib():
     L.lsa_pose_argmax.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     L.lsa_pf_weights.argtypes = [vp, vp, C.c_int, C.c_float, vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.lsa_pf_resample.argtypes = [vp, vp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, vp]
+    L.lsa_pf_resample_standard.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]
     L.lsa_pose_topk.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     L.lsa_pf_estimate.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
     L.lsa_pf_predict.argtypes = [vp, C.c_int, vp, vp, vp, vp]
@@ -462,6 +463,13 @@ def icp_goodness_scores(field, d_prob, d_poses, P, d_obs_x, d_obs_y, n_beams, d_
 
 def pf_resample(ctx, d_w, P, u0, n_total, first, M, d_parent):
     check(lib().lsa_pf_resample(ctx.h, _dp(d_w), P, u0, n_total, first, M, _dp(d_parent)), "lsa_pf_resample")
+
+
+def pf_resample_standard(ctx, d_w, P, d_u, n_u, d_parent, first=0, M=None):
+    """Standard_resampler (SIRFlt.cpp:39-115): d_u = n_u uniforms (float64, device); d_parent = offspring
+    first .. first + M - 1 of the parent-ascending list (all of it by default)."""
+    check(lib().lsa_pf_resample_standard(ctx.h, _dp(d_w), P, _dp(d_u), n_u, first, n_u if M is None else M, _dp(d_parent)),
+          "lsa_pf_resample_standard")
 
 
 def gather_poses(ctx, d_src, d_parent, M, d_dst):

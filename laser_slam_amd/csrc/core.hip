@@ -1153,6 +1153,45 @@ int lsa_pf_resample(lsa_ctx* c, const float* d_w, int P, double u0, int n_total,
     return LSA_OK;
 }
 
+// Standard_resampler (SIRFlt.cpp:39-115), the resampler SIR_scheme::update_resample() uses by default
+int lsa_pf_resample_standard(lsa_ctx* c, const float* d_w, int P, const double* d_u, int n_u, int first, int M, int32_t* d_parent)
+{
+    if (!c || !d_w || !d_u || !d_parent || P <= 0 || n_u < 0 || first < 0 || M < 0 || first + M > n_u) return fail(LSA_E_ARG, "bad argument");
+    if (P >= (1 << 24) || n_u >= (1 << 24)) return fail(LSA_E_ARG, "at most 2^24 - 1 particles");
+    if (n_u == 0 || M == 0) return LSA_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const int per = lsa::SCAN_BLOCK * lsa::SCAN_ITEMS, nb = (P + per - 1) / per;
+    double *d_cum = nullptr, *d_bs = nullptr;
+    float* d_cnt = nullptr;
+    hipError_t e = hipMalloc((void**)&d_cum, sizeof(double) * (size_t)P);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_bs, sizeof(double) * (size_t)(nb + 1));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_cnt, sizeof(float) * (size_t)P);
+    double total = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(lsa::scan_block_kernel, dim3(nb), dim3(lsa::SCAN_BLOCK), 0, c->stream, d_w, P, d_cum, d_bs);
+        hipLaunchKernelGGL(lsa::scan_sums_kernel, dim3(1), dim3(64), 0, c->stream, d_bs, nb);
+        hipLaunchKernelGGL(lsa::scan_apply_kernel, dim3(nb), dim3(lsa::SCAN_BLOCK), 0, c->stream, d_cum, P, d_bs);
+        e = hipMemcpyAsync(&total, d_cum + (P - 1), sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, sizeof(float) * (size_t)P, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess && total > 0) {
+        hipLaunchKernelGGL(lsa::resample_count_kernel, dim3(blocks_for((size_t)n_u, 256)), dim3(256), 0, c->stream,
+                           d_cum, P, total, d_u, n_u, d_cnt);
+        // cumulative counts (exact integers in double) -> offspring m belongs to the first particle whose cumulative count exceeds m
+        hipLaunchKernelGGL(lsa::scan_block_kernel, dim3(nb), dim3(lsa::SCAN_BLOCK), 0, c->stream, d_cnt, P, d_cum, d_bs);
+        hipLaunchKernelGGL(lsa::scan_sums_kernel, dim3(1), dim3(64), 0, c->stream, d_bs, nb);
+        hipLaunchKernelGGL(lsa::scan_apply_kernel, dim3(nb), dim3(lsa::SCAN_BLOCK), 0, c->stream, d_cum, P, d_bs);
+        hipLaunchKernelGGL(lsa::resample_kernel, dim3(blocks_for((size_t)M, 256)), dim3(256), 0, c->stream,
+                           d_cum, P, (double)n_u, 0.5, n_u, first, M, d_parent);
+        e = hipStreamSynchronize(c->stream);
+    }
+    hipFree(d_cum); hipFree(d_bs); hipFree(d_cnt);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? LSA_E_NOMEM : LSA_E_HIP, "lsa_pf_resample_standard", e);
+    if (!(total > 0)) return fail(LSA_E_ARG, "zero cumulative weight sum");       // SIRFlt.cpp:72-73
+    return LSA_OK;
+}
+
 int lsa_gather_poses(lsa_ctx* c, const float* d_src, const int32_t* d_parent, int M, float* d_dst)
 {
     if (!c || !d_src || !d_parent || !d_dst) return fail(LSA_E_ARG, "null argument");

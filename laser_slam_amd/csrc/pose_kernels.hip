@@ -215,6 +215,25 @@ __global__ __launch_bounds__(256) void resample_kernel(const double* __restrict_
     }
 }
 
+// Standard resampling (SIRFlt.cpp:39-115): one uniform per offspring; a particle is drawn once for every
+// uniform u with cum[i-1] <= u * total < cum[i].  The reference sorts the uniforms and walks both lists; the
+// counts do not depend on the order, so every uniform finds its particle by bisection and bumps that
+// particle's count (float adds of 1 are exact below 2^24); the parents in ascending order - what
+// copy_resamples (:323-356) leaves behind - then come from the cumulative counts through resample_kernel.
+__global__ __launch_bounds__(256) void resample_count_kernel(const double* __restrict__ cum, int P, double total,
+                                                             const double* __restrict__ u, int n_u, float* __restrict__ count)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_u; k += gridDim.x * blockDim.x) {
+        const double s = u[k] * total;                      // ur *= wcum, :88
+        int lo = 0, hi = P - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s < cum[mid]) hi = mid; else lo = mid + 1;
+        }
+        atomicAdd(&count[lo], 1.0f);
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_poses_kernel(const float* __restrict__ src, const int* __restrict__ parent, int M,
                                                            float* __restrict__ dst)
 {

@@ -6,7 +6,10 @@ Exchange steps (torch.distributed; RCCL over xGMI on GPUs, gloo in the CPU tests
   * weights:   all-reduce(SUM) of {sum w, sum w^2} (w = exp(score - global max)) -> N_eff
   * resample:  all-gather of the weights and poses; every rank draws its own contiguous
     block of the systematic grid (src/sensorFusion/SIRFlt.cpp:118-191) from the same
-    cumulative weights, so the result equals single-process systematic resampling.
+    cumulative weights, so the result equals single-process systematic resampling.  The reference's
+    default Standard_resampler (SIRFlt.cpp:39-115, one uniform per offspring) shards the same way:
+    pass the shared uniforms as `u0` and a `local_resample` built on lsa_pf_resample_standard, whose
+    (first, M) block of the parent-ascending list is this rank's share.
 
 The collectives carry a few bytes (records) or 16 B per particle (resampling); the
 scoring itself never leaves the GPU.  Compute = HIP kernels behind the C ABI

@@ -125,6 +125,7 @@ void orc_score_poses(const float* lik, int sx, int sy, int cx0, int cy0, float o
                      float max_corr, const float* scan_x, const float* scan_y, int n_points, int decim,
                      const float* poses, int P, float* score);
 void orc_systematic_resample(const float* w, int P, double u0, int n_out, int* parent);
+int orc_standard_resample(const float* w, int P, const double* u, int n_u, int* parent);
 double orc_neff(const float* w, int P);
 
 /* ray-cast scan simulator, beam model, top-k / estimate / predict / roughening (sim_oracle.c): PARITY UNPINNED */

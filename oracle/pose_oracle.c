@@ -7,6 +7,7 @@
  *   CParticles::neff              src/localization/particles.cpp:155-171
  *   threadLocalization::topK      src/localization/localization.cpp:126-149
  *   Systematic_resampler          src/sensorFusion/SIRFlt.cpp:118-191
+ *   Standard_resampler            src/sensorFusion/SIRFlt.cpp:39-115 (+ copy_resamples :323-356)
  *
  * PARITY UNPINNED: no fixture of the reference covers these functions and the reference
  * cannot be built here, so this file is checked only against itself and first principles.
@@ -96,6 +97,38 @@ void orc_systematic_resample(const float* w, int P, double u0, int n_out, int* p
         parent[m] = i;
     }
     free(cum);
+}
+
+static int cmp_dbl(const void* a, const void* b)
+{
+    const double x = *(const double*)a, y = *(const double*)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* Standard resampler (SIRFlt.cpp:39-115) followed by copy_resamples (:323-356): Kahan cumulative sum, the n_u
+ * uniforms sorted and scaled by the sum, a particle drawn once per uniform below its cumulative weight;
+ * parent[] lists the parents in ascending order.  Returns the number of uniforms left over (the reference
+ * raises "weights are not numeric" when that is not 0); those are given to the last particle. */
+int orc_standard_resample(const float* w, int P, const double* u, int n_u, int* parent)
+{
+    double* cum = (double*)malloc(sizeof(double) * P);
+    double* ur = (double*)malloc(sizeof(double) * (n_u > 0 ? n_u : 1));
+    double wcum = 0, c = 0;
+    for (int i = 0; i < P; ++i) {
+        const double y = (double)w[i] - c, t = wcum + y;
+        c = t - wcum - y;
+        wcum = cum[i] = t;
+    }
+    for (int k = 0; k < n_u; ++k) ur[k] = u[k];
+    qsort(ur, n_u, sizeof(double), cmp_dbl);
+    for (int k = 0; k < n_u; ++k) ur[k] *= wcum;
+    int k = 0;
+    for (int i = 0; i < P; ++i)
+        while (k < n_u && ur[k] < cum[i]) parent[k++] = i;
+    const int left = n_u - k;
+    while (k < n_u) parent[k++] = P - 1;
+    free(cum); free(ur);
+    return left;
 }
 
 /* neff as written (sic: cum starts at 1), particles.cpp:155-171 */

@@ -281,6 +281,17 @@ def systematic_resample(w, u0, n_out):
     return parent
 
 
+def standard_resample(w, u):
+    """Standard_resampler + copy_resamples: parents in ascending order, and the uniforms left over (0 if fine)."""
+    if Oracle._L is None:
+        Oracle._L = _load_oracle()
+    w = np.ascontiguousarray(w, f32); u = np.ascontiguousarray(u, np.float64)
+    parent = np.zeros(len(u), i32)
+    Oracle._L.orc_standard_resample.restype = C.c_int
+    left = Oracle._L.orc_standard_resample(_p(w), len(w), _p(u), len(u), _p(parent))
+    return parent, left
+
+
 def p2p_icp(rx, ry, cx, cy, init, max_iter=100, thr_d=0.75, thr_a=np.deg2rad(10.0), alfa=0.5, smallest=0.05):
     if Oracle._L is None:
         Oracle._L = _load_oracle()

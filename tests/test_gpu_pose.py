@@ -96,6 +96,43 @@ def test_scores_argmax_weights_resample(world):
     assert np.array_equal(d_new.cpu().numpy(), poses[par_g])
 
 
+def test_standard_resampler(world):
+    """Standard_resampler (SIRFlt.cpp:39-115, what SIR_scheme::update_resample() uses): one uniform per offspring,
+    parents ascending as copy_resamples leaves them; device against oracle (the device sums the weights pairwise,
+    the oracle with Kahan's recurrence: an offspring on a slice boundary may land on the neighbour)."""
+    import torch
+    from laser_slam_amd import capi
+    from oracle_lib import standard_resample
+    ctx = world["ctx"]
+    rng = np.random.default_rng(9)
+    for P, n_u in ((60, 60), (5000, 5000), (200000, 200000), (1000, 4000)):
+        w = (rng.uniform(0, 1, P) ** 6).astype(np.float32)
+        w[P // 3: P // 3 + 7] = 0.0
+        u = rng.uniform(0, 1, n_u)
+        d_w = torch.from_numpy(w).cuda(); d_u = torch.from_numpy(u).cuda()
+        d_par = torch.full((n_u,), -1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        capi.pf_resample_standard(ctx, d_w, P, d_u, n_u, d_par)
+        got = d_par.cpu().numpy()
+        want, left = standard_resample(w, u)
+        assert left == 0
+        assert np.all(np.diff(got) >= 0) and got.min() >= 0 and got.max() < P
+        assert (got != want).mean() < 1e-3 and np.abs(got - want).max() <= 1
+        assert not np.isin(got, np.arange(P // 3, P // 3 + 7)).any()
+        # a shard's block of the same list
+        first, M = n_u // 3, min(777, n_u - n_u // 3)
+        d_blk = torch.full((M,), -1, dtype=torch.int32, device="cuda")
+        capi.pf_resample_standard(ctx, d_w, P, d_u, n_u, d_blk, first, M)
+        assert np.array_equal(d_blk.cpu().numpy(), got[first:first + M])
+    # all the weight on one particle; zero weights are an error like the reference's "zero cumulative weight sum"
+    w = np.zeros(100, np.float32); w[42] = 3.0
+    d_par = torch.zeros(50, dtype=torch.int32, device="cuda")
+    capi.pf_resample_standard(ctx, torch.from_numpy(w).cuda(), 100, torch.from_numpy(rng.uniform(0, 1, 50)).cuda(), 50, d_par)
+    assert (d_par.cpu().numpy() == 42).all()
+    with pytest.raises(Exception):
+        capi.pf_resample_standard(ctx, torch.zeros(100, device="cuda"), 100, torch.from_numpy(rng.uniform(0, 1, 50)).cuda(), 50, d_par)
+
+
 def test_sharded_filter_single_gpu(world):
     """ShardedParticleFilter wired to the HIP entry points (world size 1)."""
     torch, capi, ctx, fld = world["torch"], world["capi"], world["ctx"], world["fld"]

@@ -67,3 +67,27 @@ def test_topk_estimate_predict_roughen():
     rr = ol.pf_roughen(poses, 0.2, nrm)
     rootq = (poses.max(0).astype(np.float64) - poses.min(0)) * 0.2 * 500 ** (-1 / 3)
     assert np.allclose(rr, poses + nrm * rootq, atol=1e-6)
+
+
+def test_standard_resampler_counts():
+    """Standard_resampler (SIRFlt.cpp:39-115) + copy_resamples: a particle is drawn once per uniform inside its slice
+    of the cumulative weights, whatever order the uniforms come in; the offspring are listed parent-ascending."""
+    import oracle_lib as ol
+    rng = np.random.default_rng(4)
+    P = 500
+    w = rng.uniform(0, 1, P).astype(np.float32) ** 4
+    w[17:40] = 0.0                                       # dead particles are never drawn
+    u = rng.uniform(0, 1, 800)
+    parent, left = ol.standard_resample(w, u)
+    assert left == 0 and np.all(np.diff(parent) >= 0)
+    cum = np.cumsum(w.astype(np.float64))
+    want = np.searchsorted(cum, np.sort(u) * cum[-1], side="right")
+    assert (parent != want).sum() <= 1                   # (Kahan vs pairwise summation: a boundary case at most)
+    assert not np.isin(parent, np.arange(17, 40)).any()
+    # the order of the draws does not matter
+    parent2, _ = ol.standard_resample(w, u[::-1].copy())
+    assert np.array_equal(parent, parent2)
+    # one heavy particle takes nearly everything
+    w2 = np.full(P, 1e-6, np.float32); w2[123] = 1.0
+    p3, _ = ol.standard_resample(w2, u)
+    assert (p3 == 123).mean() > 0.99
