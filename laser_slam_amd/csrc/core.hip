@@ -100,6 +100,17 @@ int lsa_debug_phase_cycles(unsigned long long* out16)
 }
 #endif
 
+#ifdef LSA_GRID_STAMPS
+int lsa_debug_grid_cycles(unsigned long long* out16)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(lsa::lsa_grid_cycles), sizeof(unsigned long long) * 16));
+    unsigned long long z[16] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lsa::lsa_grid_cycles), z, sizeof z));
+    return LSA_OK;
+}
+#endif
+
 #ifdef LSA_NN_STATS
 int lsa_debug_nn_stats(unsigned long long* out8 /* 24 entries */)
 {
@@ -624,6 +635,10 @@ struct lsa_grid {
     int* d_bbox = nullptr;
     size_t ends_cap = 0, info_cap = 0;
     size_t cells = 0;
+    // binned batch update: per-tile counts / list offsets / item offsets (3 x (tiles + 1) ints) + 2 totals; the lists
+    int* d_tile = nullptr;
+    uint32_t* d_list = nullptr;
+    size_t list_cap = 0;
 };
 
 int lsa_grid_create(lsa_grid** out, lsa_ctx* c, int sx, int sy, int cx, int cy, float offx, float offy, double res)
@@ -654,7 +669,7 @@ void lsa_grid_destroy(lsa_grid* g)
     if (!g) return;
     hipSetDevice(g->c->device);
     hipStreamSynchronize(g->c->stream);
-    hipFree(g->d_hit); hipFree(g->d_sum); hipFree(g->d_prob); hipFree(g->d_tmp); hipFree(g->d_rows); hipFree(g->d_pts); hipFree(g->d_ends); hipFree(g->d_info); hipFree(g->d_blk); hipFree(g->d_bbox);
+    hipFree(g->d_hit); hipFree(g->d_sum); hipFree(g->d_prob); hipFree(g->d_tmp); hipFree(g->d_rows); hipFree(g->d_pts); hipFree(g->d_ends); hipFree(g->d_info); hipFree(g->d_blk); hipFree(g->d_bbox); hipFree(g->d_tile); hipFree(g->d_list);
     delete g;
 }
 
@@ -708,6 +723,37 @@ int lsa_grid_update_batch(lsa_grid* g, int S, int n_beams, const float* d_gx, co
         if (!g->d_bbox) HIP_TRY(hipMalloc((void**)&g->d_bbox, 8 * sizeof(int)));
         static const int bbox0[8] = {INT_MAX, INT_MAX, INT_MIN, INT_MIN, 0, 0, 0, 0};      // box, work-item counter
         HIP_TRY(hipMemcpyAsync(g->d_bbox, bbox0, sizeof bbox0, hipMemcpyHostToDevice, g->c->stream));
+        if (!(path_env && !strcmp(path_env, "owned")) && S < (1 << 24)) {
+            // binned: prep (+ tile counts, robot-cell totals) -> offsets -> lists -> one workgroup per (tile, chunk of its list)
+            const int ntx = (g->G.size_x + lsa::BIN_T - 1) / lsa::BIN_T, nty = (g->G.size_y + lsa::BIN_T - 1) / lsa::BIN_T, nt = ntx * nty;
+            if (!g->d_tile) HIP_TRY(hipMalloc((void**)&g->d_tile, sizeof(int) * (3 * ((size_t)nt + 1) + 2)));
+            int* tile_cnt = g->d_tile; int* tile_off = tile_cnt + (nt + 1); int* item_off = tile_off + (nt + 1); int* totals = item_off + (nt + 1);
+            const char* chunk_env = getenv("LSA_GRID_CHUNK");
+            int chunk = chunk_env ? atoi(chunk_env) : 64;
+            if (chunk < 4) chunk = 4;
+            if (chunk > lsa::BIN_CHUNK_MAX) chunk = lsa::BIN_CHUNK_MAX;
+            HIP_TRY(hipMemsetAsync(tile_cnt, 0, sizeof(int) * ((size_t)nt + 1), g->c->stream));
+            hipLaunchKernelGGL(lsa::grid_prep_kernel, dim3(S < 8192 ? S : 8192), dim3(256), 0, g->c->stream, g->G, S, n_beams,
+                               d_gx, d_gy, d_robot_xy, d_n_valid, g->d_ends, g->d_info, g->d_blk, g->d_bbox, tile_cnt, nty, g->d_hit, g->d_sum);
+            hipLaunchKernelGGL(lsa::grid_bin_scan_kernel, dim3(1), dim3(256), 0, g->c->stream, tile_cnt, nt, chunk, tile_off, item_off, totals);
+            int tot[2] = {0, 0};                        // list entries, work items: sizes the list and the launch
+            HIP_TRY(hipMemcpyAsync(tot, totals, sizeof tot, hipMemcpyDeviceToHost, g->c->stream));
+            HIP_TRY(hipStreamSynchronize(g->c->stream));
+            if (tot[0] <= 0) return LSA_OK;             // every ray outside the map
+            if (g->list_cap < (size_t)tot[0]) {
+                if (g->d_list) HIP_TRY(hipFree(g->d_list));
+                g->d_list = nullptr; g->list_cap = 0;
+                const size_t cap = (size_t)tot[0] + (size_t)tot[0] / 4;
+                HIP_TRY(hipMalloc((void**)&g->d_list, cap * sizeof(uint32_t)));
+                g->list_cap = cap;
+            }
+            hipLaunchKernelGGL(lsa::grid_bin_fill_kernel, dim3(S < 8192 ? S : 8192), dim3(256), 0, g->c->stream, g->G, S, n_beams,
+                               g->d_info, g->d_blk, nty, tile_off, tile_cnt, g->d_list);
+            hipLaunchKernelGGL(lsa::grid_binned_kernel, dim3(tot[1]), dim3(256), 0, g->c->stream, g->G, n_beams, g->d_ends, g->d_info,
+                               nt, nty, chunk, tile_off, item_off, g->d_list, g->d_hit, g->d_sum);
+            HIP_TRY(hipGetLastError());
+            return LSA_OK;
+        }
         hipLaunchKernelGGL(lsa::grid_prep_kernel, dim3(S < 8192 ? S : 8192), dim3(256), 0, g->c->stream, g->G, S, n_beams,
                            d_gx, d_gy, d_robot_xy, d_n_valid, g->d_ends, g->d_info, g->d_blk, g->d_bbox);
         // scans per tile are divided among several workgroups when the batch covers few tiles (decided on the

@@ -186,18 +186,90 @@ constexpr int OWN_T = 64;               // cells per owned tile side (2 x 16 KiB
 constexpr int OWN_CHUNK = 256;          // scans looked at per culling round (fewer when a scan has many blocks)
 constexpr int OWN_LIST = 256 * 17;      // candidate blocks per round
 
+// Binned path, shared by the counting pass (grid_prep_kernel) and the fill pass (grid_bin_fill_kernel): which
+// 64x64 tiles do the 64-beam blocks of one scan concern?  A workgroup owns the scan.  When the scan's tile
+// rectangle is small enough, the blocks' boxes are first merged in LDS into one 64-bit block mask per tile, so
+// that the layers' global counters see one atomic per (scan, tile) instead of one per (block, tile) - the hot
+// tiles around the robot are otherwise hit by every block of every scan.
+constexpr int BIN_T = 64;                // cells per tile side
+constexpr int BIN_RECT_MAX = 1024;       // tiles of a scan's rectangle held as LDS masks
+
+__device__ __forceinline__ bool bin_tile_rect(const GridParam& G, int4 bb, int& tx0, int& tx1, int& ty0, int& ty1)
+{
+    if (bb.y < 0 || bb.w < 0 || bb.x >= G.size_x || bb.z >= G.size_y) return false;
+    tx0 = (bb.x > 0 ? bb.x : 0) / BIN_T; tx1 = (bb.y < G.size_x - 1 ? bb.y : G.size_x - 1) / BIN_T;
+    ty0 = (bb.z > 0 ? bb.z : 0) / BIN_T; ty1 = (bb.w < G.size_y - 1 ? bb.w : G.size_y - 1) / BIN_T;
+    return true;
+}
+
+// boxes[bk] = (xmin, xmax, ymin, ymax) of block bk (LDS), scan_box likewise for the whole scan; all threads call.
+// FILL = false: tile_ctr[t] += blocks of this scan that meet tile t.
+// FILL = true : those blocks are appended to tile t's list (tile_ctr = fill cursors).
+template <bool FILL>
+__device__ __forceinline__ void bin_scan_tiles(const GridParam& G, int s, int nb, int nblk, const int4* boxes, int4 scan_box,
+                                               int nty_all, int* __restrict__ tile_ctr, const int* __restrict__ tile_off,
+                                               uint32_t* __restrict__ list, unsigned long long* mask /* LDS, BIN_RECT_MAX */)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nvb = (nb + 63) >> 6 < nblk ? (nb + 63) >> 6 : nblk;            // blocks that hold rays
+    int sx0, sx1, sy0, sy1;
+    if (nvb <= 0 || !bin_tile_rect(G, scan_box, sx0, sx1, sy0, sy1)) return;
+    const int swy = sy1 - sy0 + 1, area = (sx1 - sx0 + 1) * swy;
+    if (area <= BIN_RECT_MAX && nblk <= 64) {
+        for (int k = tid; k < area; k += blockDim.x) mask[k] = 0ull;
+        __syncthreads();
+        for (int bk = wave; bk < nvb; bk += (blockDim.x >> 6)) {
+            int tx0, tx1, ty0, ty1;
+            if (!bin_tile_rect(G, boxes[bk], tx0, tx1, ty0, ty1)) continue;
+            const int wy = ty1 - ty0 + 1, nrect = (tx1 - tx0 + 1) * wy;
+            for (int k = lane; k < nrect; k += 64)
+                atomicOr(&mask[(tx0 + k / wy - sx0) * swy + (ty0 + k % wy - sy0)], 1ull << bk);
+        }
+        __syncthreads();
+        for (int k = tid; k < area; k += blockDim.x) {
+            unsigned long long m = mask[k];
+            if (!m) continue;
+            const int t = (sx0 + k / swy) * nty_all + sy0 + k % swy;
+            const int c = __popcll(m);
+            if (!FILL) atomicAdd(&tile_ctr[t], c);
+            else {
+                int pos = tile_off[t] + atomicAdd(&tile_ctr[t], c);
+                while (m) { const int bk = __ffsll((long long)m) - 1; m &= m - 1; list[pos++] = ((uint32_t)s << 8) | (uint32_t)bk; }
+            }
+        }
+        __syncthreads();
+    } else {
+        for (int bk = wave; bk < nvb; bk += (blockDim.x >> 6)) {
+            int tx0, tx1, ty0, ty1;
+            if (!bin_tile_rect(G, boxes[bk], tx0, tx1, ty0, ty1)) continue;
+            const int wy = ty1 - ty0 + 1, nrect = (tx1 - tx0 + 1) * wy;
+            for (int k = lane; k < nrect; k += 64) {
+                const int t = (tx0 + k / wy) * nty_all + ty0 + k % wy;
+                if (!FILL) atomicAdd(&tile_ctr[t], 1);
+                else list[tile_off[t] + atomicAdd(&tile_ctr[t], 1)] = ((uint32_t)s << 8) | (uint32_t)bk;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void grid_prep_kernel(
     GridParam G, int S, int n_beams, const float* __restrict__ gx, const float* __restrict__ gy,
     const float* __restrict__ robot_xy, const int* __restrict__ n_valid,
     int2* __restrict__ ends, ScanInfo* __restrict__ info, int4* __restrict__ blk /* [S][n_beams/64]: xmin,xmax,ymin,ymax */,
-    int* __restrict__ bbox /* xmin, ymin, xmax, ymax */)
+    int* __restrict__ bbox /* xmin, ymin, xmax, ymax */,
+    int* __restrict__ tile_cnt = nullptr /* binned path: blocks per 64x64 tile */, int nty_all = 0,
+    uint32_t* __restrict__ hit = nullptr, uint32_t* __restrict__ sum = nullptr /* binned path: robot-cell totals */)
 {
     __shared__ int red[4][5];
+    __shared__ int4 boxes[64];
+    __shared__ int4 scan_box;
+    __shared__ unsigned long long mask[BIN_RECT_MAX];
     const int nblk = (n_beams + 63) >> 6;
     for (int s = blockIdx.x; s < S; s += gridDim.x) {
+        __syncthreads();                                    // (the previous scan's boxes are still being read)
         const int sx = grid_cell1(robot_xy[2 * s], G.off_x, G.center_x, G.res);
         const int sy = grid_cell1(robot_xy[2 * s + 1], G.off_y, G.center_y, G.res);
-        const int nb = n_valid ? n_valid[s] : n_beams;
+        const int nb = n_valid ? (n_valid[s] < n_beams ? n_valid[s] : n_beams) : n_beams;
         int x0 = sx, x1 = sx, y0 = sy, y1 = sy, nh = 0;
         for (int i = threadIdx.x; i < nblk * 64; i += blockDim.x) {
             const size_t t = (size_t)s * n_beams + i;
@@ -214,6 +286,7 @@ __global__ __launch_bounds__(256) void grid_prep_kernel(
                     a0 = p0 < a0 ? p0 : a0; a1 = p1 > a1 ? p1 : a1; c0 = q0 < c0 ? q0 : c0; c1 = q1 > c1 ? q1 : c1;
                 }
                 if ((threadIdx.x & 63) == 0) blk[(size_t)s * nblk + (i >> 6)] = make_int4(a0, a1, c0, c1);
+                if ((threadIdx.x & 63) == 0 && (i >> 6) < 64) boxes[i >> 6] = make_int4(a0, a1, c0, c1);
             }
             if (i >= nb) continue;
             x0 = ex < x0 ? ex : x0; x1 = ex > x1 ? ex : x1;
@@ -241,7 +314,17 @@ __global__ __launch_bounds__(256) void grid_prep_kernel(
             ScanInfo si; si.sx = sx; si.sy = sy; si.xmin = x0; si.xmax = x1; si.ymin = y0; si.ymax = y1;
             si.nb = nb > 0 ? nb : 0; si.nh = nh; si.s = s; si.pad = 0;
             info[s] = si;
+            if (sum && inb(G, sx, sy)) {                    // every ray of the scan starts in the robot cell; the walks leave it out
+                const size_t c = (size_t)sx * G.size_y + sy;
+                if (si.nb) atomicAdd(&sum[c], (uint32_t)si.nb);
+                if (nh) atomicAdd(&hit[c], (uint32_t)nh);
+            }
             atomicMin(&bbox[0], x0); atomicMin(&bbox[1], y0); atomicMax(&bbox[2], x1); atomicMax(&bbox[3], y1);
+            scan_box = make_int4(x0, x1, y0, y1);
+        }
+        if (tile_cnt) {                                     // binned path: blocks per tile
+            __syncthreads();
+            bin_scan_tiles<false>(G, s, nb > 0 ? nb : 0, nblk, boxes, scan_box, nty_all, tile_cnt, nullptr, nullptr, mask);
         }
     }
 }
@@ -295,6 +378,13 @@ __device__ __forceinline__ void own_walk(const GridParam& G, uint32_t* lh, uint3
     }
 }
 
+#ifdef LSA_GRID_STAMPS       // diagnostic build only: workgroup cycles per phase (thread 0), items, longest item, cells walked
+__device__ unsigned long long lsa_grid_cycles[16];
+#define GSTAMP(slot) do { if (threadIdx.x == 0) { unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&lsa_grid_cycles[slot], t_ - gt_); gt_ = t_; } } while (0)
+#else
+#define GSTAMP(slot) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(256) void grid_owned_kernel(
     GridParam G, int S, int n_beams, const int2* __restrict__ ends, const ScanInfo* __restrict__ info,
     const int4* __restrict__ blk, int* __restrict__ bbox /* [0..3] box, [4] item counter */, int splits_req,
@@ -322,12 +412,22 @@ __global__ __launch_bounds__(256) void grid_owned_kernel(
     // items are claimed from a counter (bbox[4], zeroed with the box) so that a workgroup that drew a
     // light tile moves on: the work per item differs by orders of magnitude
     __shared__ int next_item;
+#ifdef LSA_GRID_STAMPS
+    unsigned long long gt_ = __builtin_readcyclecounter(), gstart_ = gt_, gitem_ = gt_;
+#endif
     for (;;) {
     __syncthreads();
+#ifdef LSA_GRID_STAMPS
+    if (tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicMax(&lsa_grid_cycles[6], t_ - gitem_); gitem_ = t_; }
+#endif
     if (tid == 0) next_item = atomicAdd((int*)&bbox[4], 1);
     __syncthreads();
     const int item = next_item;
     if (item >= nt * splits) break;
+    GSTAMP(4);
+#ifdef LSA_GRID_STAMPS
+    if (tid == 0) atomicAdd(&lsa_grid_cycles[5], 1ull);
+#endif
     const int tile = item % nt, part = item / nt;
     const int X0 = (bx0 + tile / nty) * OWN_T, Y0 = (by0 + tile % nty) * OWN_T;
     const int X1 = X0 + OWN_T - 1, Y1 = Y0 + OWN_T - 1;
@@ -368,8 +468,12 @@ __global__ __launch_bounds__(256) void grid_owned_kernel(
             if (ov) list[base + prefix_popc(m)] = (uint16_t)(((pr / nblk) << 8) | (pr % nblk));
         }
         __syncthreads();
+        GSTAMP(1);
         const int nl = nlist;
         if (nl) touched = true;
+#ifdef LSA_GRID_STAMPS
+        if (tid == 0) atomicAdd(&lsa_grid_cycles[8], (unsigned long long)nl);
+#endif
         // every wave walks listed blocks, 64 rays at a time; the next block's end cells are in flight meanwhile
         int q = wave;
         int2 e = make_int2(0, 0);
@@ -389,8 +493,11 @@ __global__ __launch_bounds__(256) void grid_owned_kernel(
             if (64 * bk + lane < cand[j].nb) own_walk(G, lh, ls, X0, Y0, inside, sx, sy, rin, e.x, e.y);
             e = en;
         }
+        __syncthreads();
+        GSTAMP(2);
     }
     __syncthreads();
+    GSTAMP(0);
     if (!touched) continue;
     // flush: consecutive lanes -> consecutive y of one x row (contiguous in the [x][y] layers)
     for (int k = tid; k < OWN_T * OWN_T; k += blockDim.x) {
@@ -401,6 +508,172 @@ __global__ __launch_bounds__(256) void grid_owned_kernel(
         if (splits == 1) { if (vh) hit[c] += vh; if (vs) sum[c] += vs; }
         else { if (vh) atomicAdd(&hit[c], vh); if (vs) atomicAdd(&sum[c], vs); }
     }
+    __syncthreads();
+    GSTAMP(3);
+    }
+#ifdef LSA_GRID_STAMPS
+    if (tid == 0) { atomicAdd(&lsa_grid_cycles[7], __builtin_readcyclecounter() - gstart_); atomicAdd(&lsa_grid_cycles[9], 1ull); }
+#endif
+}
+
+// Batched update, binned (the throughput path).  The owned-tile kernel above spends most of its time finding out
+// which rays concern a tile; here that question is answered once, rasteriser style:
+//   grid_prep_kernel      (above) end cells, per-scan header, the bounding box of every 64-beam block; with
+//                         `tile_cnt` it also counts, per 64x64 tile of the grid, the blocks whose box meets it,
+//                         and adds the robot cell's totals (every ray of a scan starts there) to the layers.
+//   grid_bin_scan_kernel  one workgroup: tile counts -> list offsets and work-item offsets (an item = up to
+//                         `chunk` list entries of one tile), totals for the host (list capacity, launch size).
+//   grid_bin_fill_kernel  every (scan, block) appends itself to the lists of the tiles its box meets.
+//   grid_binned_kernel    one workgroup per item: the tile's two count layers, packed hit << 16 | sum, live in
+//                         16 KiB of LDS; every wave walks list entries, 64 rays at a time, through exactly the
+//                         part of the reference's Bresenham line inside the tile (closed-form restart as above;
+//                         one LDS add per cell, the last generated cell adds hit and sum at once); the tile is
+//                         then added to the layers (plain read-modify-write when the tile has a single item).
+// The work per item is bounded by `chunk`, the number of items follows the work, and a tile nobody's box meets
+// costs nothing.  Counts are additive integers: the order of the list entries does not matter.
+constexpr int BIN_CHUNK_MAX = 256;       // packed 16-bit counters: sum <= 64 chunk, hit <= 128 chunk per cell and item
+
+__global__ __launch_bounds__(256) void grid_bin_scan_kernel(int* __restrict__ tile_cnt, int ntiles, int chunk,
+                                                            int* __restrict__ tile_off, int* __restrict__ item_off,
+                                                            int* __restrict__ totals /* entries, items */)
+{
+    __shared__ int sh[2][256];
+    const int tid = threadIdx.x, per = (ntiles + 255) / 256, a = tid * per, b = a + per < ntiles ? a + per : ntiles;
+    int e = 0, it = 0;
+    for (int t = a; t < b; ++t) { const int c = tile_cnt[t]; e += c; it += (c + chunk - 1) / chunk; }
+    sh[0][tid] = e; sh[1][tid] = it;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int x = tid >= off ? sh[0][tid - off] : 0, y = tid >= off ? sh[1][tid - off] : 0;
+        __syncthreads();
+        sh[0][tid] += x; sh[1][tid] += y;
+        __syncthreads();
+    }
+    int eo = sh[0][tid] - e, io = sh[1][tid] - it;
+    for (int t = a; t < b; ++t) {
+        const int c = tile_cnt[t];
+        tile_off[t] = eo; item_off[t] = io;
+        eo += c; io += (c + chunk - 1) / chunk;
+        tile_cnt[t] = 0;                                    // becomes the fill cursor
+    }
+    if (tid == 255) { tile_off[ntiles] = sh[0][255]; item_off[ntiles] = sh[1][255]; totals[0] = sh[0][255]; totals[1] = sh[1][255]; }
+}
+
+__global__ __launch_bounds__(256) void grid_bin_fill_kernel(GridParam G, int S, int n_beams, const ScanInfo* __restrict__ info,
+                                                            const int4* __restrict__ blk, int nty_all, const int* __restrict__ tile_off,
+                                                            int* __restrict__ tile_cur, uint32_t* __restrict__ list)
+{
+    __shared__ int4 boxes[64];
+    __shared__ unsigned long long mask[BIN_RECT_MAX];
+    const int nblk = (n_beams + 63) >> 6;
+    for (int s = blockIdx.x; s < S; s += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x < nblk && threadIdx.x < 64) boxes[threadIdx.x] = blk[(size_t)s * nblk + threadIdx.x];
+        const ScanInfo si = info[s];
+        __syncthreads();
+        bin_scan_tiles<true>(G, s, si.nb, nblk, boxes, make_int4(si.xmin, si.xmax, si.ymin, si.ymax), nty_all, tile_cur, tile_off, list, mask);
+    }
+}
+
+// The part of one ray inside the tile at (X0, Y0); robot_cc = the robot cell's index in the tile or -1 (that cell
+// has its totals already).  lt: packed counters, hit << 16 | sum.
+template <bool INSIDE>
+__device__ __forceinline__ void bin_walk(const GridParam& G, uint32_t* lt, int X0, int Y0, int sx, int sy, int robot_cc, int ex, int ey)
+{
+    const int X1 = X0 + BIN_T - 1, Y1 = Y0 + BIN_T - 1;
+    if (ex >= X0 && ex <= X1 && ey >= Y0 && ey <= Y1 && (INSIDE || inb(G, ex, ey)))       // :72-75
+        atomicAdd(&lt[(ex - X0) * BIN_T + (ey - Y0)], 0x10000u);
+    const int dx = abs(ex - sx), dy = abs(ey - sy);
+    const bool x_major = dy <= dx;
+    const bool from_end = x_major ? sx > ex : sy > ey;
+    const int len = x_major ? dx : dy, dmin = x_major ? dy : dx;
+    const int m0 = x_major ? (from_end ? ex : sx) : (from_end ? ey : sy);                  // major / minor of the first cell
+    const int n0 = x_major ? (from_end ? ey : sy) : (from_end ? ex : sx);
+    const int mstep = ((x_major ? ey - sy : ex - sx) * (from_end ? -1 : 1)) > 0 ? 1 : -1;
+    const int M0 = x_major ? X0 : Y0, N0 = x_major ? Y0 : X0;
+    const int t_lo = M0 - m0 > 0 ? M0 - m0 : 0;
+    const int t_hi = M0 + BIN_T - 1 - m0 < len ? M0 + BIN_T - 1 - m0 : len;
+    if (t_lo > t_hi) return;
+    const int c_major = x_major ? BIN_T : 1, c_minor = x_major ? mstep : mstep * BIN_T;   // cell index steps
+    const int inc_keep = 2 * dmin, inc_step = 2 * (dmin - len);
+    int t = t_lo;
+    int steps = 0;                                                                       // minor steps taken before cell t
+    if (len > 0) {
+        if (len < 32768) steps = (int)((2u * (unsigned)dmin * (unsigned)t + (unsigned)len) / (2u * (unsigned)len));   // t <= len
+        else steps = (int)((2ll * dmin * t + len) / (2ll * len));
+    }
+    int minor = n0 + mstep * steps;
+    int d = (int)(2ll * dmin * (t + 1) - len - 2ll * len * steps);                      // |d| <= 2 len
+    int cc = x_major ? (m0 + t - X0) * BIN_T + (minor - Y0) : (minor - X0) * BIN_T + (m0 + t - Y0);
+    for (; t <= t_hi; ++t) {
+        bool ok = (unsigned)(minor - N0) < (unsigned)BIN_T && cc != robot_cc;
+        if (!INSIDE) ok = ok && inb(G, x_major ? m0 + t : minor, x_major ? minor : m0 + t);
+        if (ok) atomicAdd(&lt[cc], t == len ? 0x10001u : 1u);                            // :87, and the last generated cell :84-86
+        const bool keep = d < 0;
+        cc += c_major + (keep ? 0 : c_minor);
+        minor += keep ? 0 : mstep;
+        d += keep ? inc_keep : inc_step;
+    }
+}
+
+__global__ __launch_bounds__(256) void grid_binned_kernel(
+    GridParam G, int n_beams, const int2* __restrict__ ends, const ScanInfo* __restrict__ info, int ntiles, int nty_all, int chunk,
+    const int* __restrict__ tile_off, const int* __restrict__ item_off, const uint32_t* __restrict__ list,
+    uint32_t* __restrict__ hit, uint32_t* __restrict__ sum)
+{
+    __shared__ uint32_t lt[BIN_T * BIN_T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int item = blockIdx.x;
+    // the item's tile: the last tile whose first item is <= item (uniform; the offsets sit in L2)
+    int lo = 0, hi = ntiles - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (item_off[mid] <= item) lo = mid; else hi = mid - 1;
+    }
+    const int tile = lo, part = item - item_off[tile], items_here = item_off[tile + 1] - item_off[tile];
+    const int e0 = tile_off[tile] + part * chunk;
+    const int e1 = e0 + chunk < tile_off[tile + 1] ? e0 + chunk : tile_off[tile + 1];
+    const int X0 = (tile / nty_all) * BIN_T, Y0 = (tile % nty_all) * BIN_T;
+    const bool inside = X0 + BIN_T <= G.size_x && Y0 + BIN_T <= G.size_y;
+    for (int k = tid; k < BIN_T * BIN_T; k += 256) lt[k] = 0;
+    __syncthreads();
+    // every wave walks list entries, 64 rays at a time; the next entry's end cells are in flight meanwhile
+    int q = e0 + wave;
+    int2 e = make_int2(0, 0);
+    int hs = 0, hx = 0, hy = 0, hn = 0;
+    if (q < e1) {
+        const uint32_t en = list[q];
+        hs = (int)(en >> 8); const int bk = (int)(en & 255u);
+        hx = info[hs].sx; hy = info[hs].sy; hn = info[hs].nb - 64 * bk;
+        if (lane < hn) e = ends[(size_t)hs * n_beams + 64 * bk + lane];
+    }
+    for (; q < e1; q += 4) {
+        const int sx = hx, sy = hy, nv = hn;
+        const int2 ec = e;
+        if (q + 4 < e1) {
+            const uint32_t en = list[q + 4];
+            hs = (int)(en >> 8); const int bk = (int)(en & 255u);
+            hx = info[hs].sx; hy = info[hs].sy; hn = info[hs].nb - 64 * bk;
+            if (lane < hn) e = ends[(size_t)hs * n_beams + 64 * bk + lane];
+        }
+        if (lane < nv) {
+            const bool rin = sx >= X0 && sx < X0 + BIN_T && sy >= Y0 && sy < Y0 + BIN_T;
+            const int robot_cc = rin ? (sx - X0) * BIN_T + (sy - Y0) : -1;
+            if (inside) bin_walk<true>(G, lt, X0, Y0, sx, sy, robot_cc, ec.x, ec.y);
+            else bin_walk<false>(G, lt, X0, Y0, sx, sy, robot_cc, ec.x, ec.y);
+        }
+    }
+    __syncthreads();
+    // flush: consecutive lanes -> consecutive y of one x row (contiguous in the [x][y] layers)
+    for (int k = tid; k < BIN_T * BIN_T; k += 256) {
+        const uint32_t v = lt[k];
+        if (!v) continue;
+        const int x = X0 + k / BIN_T, y = Y0 + k % BIN_T;
+        if (!(inside || inb(G, x, y))) continue;
+        const uint32_t vh = v >> 16, vs = v & 0xffffu;
+        const size_t c = (size_t)x * G.size_y + y;
+        if (items_here == 1) { if (vh) hit[c] += vh; if (vs) sum[c] += vs; }
+        else { if (vh) atomicAdd(&hit[c], vh); if (vs) atomicAdd(&sum[c], vs); }
     }
 }
 

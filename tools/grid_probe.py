@@ -24,3 +24,19 @@ t0 = time.perf_counter()
 for _ in range(3): g.update_batch(nb, 1081, dgx, dgy, drob)
 ctx.sync(); dt = (time.perf_counter() - t0) / 3
 print("%s splits=%s: %.0f scans/s (%.2f ms per 2048 scans)" % (os.path.basename(sys.argv[1]), os.environ.get("LSA_GRID_SPLITS", "auto"), nb / dt, dt * 1e3))
+
+if hasattr(capi.lib(), "lsa_debug_grid_cycles") or True:
+    import ctypes as C
+    try:
+        f = capi.lib().lsa_debug_grid_cycles
+    except AttributeError:
+        f = None
+    if f is not None:
+        buf = (C.c_ulonglong * 16)()
+        f(buf)                                              # reset
+        g.update_batch(nb, 1081, dgx, dgy, drob); ctx.sync()
+        f(buf)
+        v = list(buf)
+        tot = float(v[7])
+        print("workgroups %d items %d blocks walked %d | share of workgroup time: cull %.1f%% walk %.1f%% zero+tail %.1f%% flush %.1f%% claim/idle %.1f%% | longest item %.0f cycles, mean workgroup life %.0f cycles"
+              % (v[9], v[5], v[8], 100 * v[1] / tot, 100 * v[2] / tot, 100 * v[0] / tot, 100 * v[3] / tot, 100 * v[4] / tot, v[6], tot / max(v[9], 1)))
