@@ -526,9 +526,9 @@ __global__ __launch_bounds__(256) void grid_owned_kernel(
 //   grid_bin_fill_kernel  every (scan, block) appends itself to the lists of the tiles its box meets.
 //   grid_binned_kernel    one workgroup per item: the tile's two count layers, packed hit << 16 | sum, live in
 //                         16 KiB of LDS; every wave walks list entries, 64 rays at a time, through exactly the
-//                         part of the reference's Bresenham line inside the tile (closed-form restart as above;
-//                         one LDS add per cell, the last generated cell adds hit and sum at once); the tile is
-//                         then added to the layers (plain read-modify-write when the tile has a single item).
+//                         part of the reference's Bresenham line inside the tile (closed-form restart as above,
+//                         inverted to clip the walk in both coordinates: one LDS add per cell and no test); the
+//                         tile is then added to the layers (plain read-modify-write when it has a single item).
 // The work per item is bounded by `chunk`, the number of items follows the work, and a tile nobody's box meets
 // costs nothing.  Counts are additive integers: the order of the list entries does not matter.
 constexpr int BIN_CHUNK_MAX = 256;       // packed 16-bit counters: sum <= 64 chunk, hit <= 128 chunk per cell and item
@@ -575,45 +575,93 @@ __global__ __launch_bounds__(256) void grid_bin_fill_kernel(GridParam G, int S, 
     }
 }
 
-// The part of one ray inside the tile at (X0, Y0); robot_cc = the robot cell's index in the tile or -1 (that cell
-// has its totals already).  lt: packed counters, hit << 16 | sum.
-template <bool INSIDE>
-__device__ __forceinline__ void bin_walk(const GridParam& G, uint32_t* lt, int X0, int Y0, int sx, int sy, int robot_cc, int ex, int ey)
+// The part of one ray inside the tile [X0, X1] x [Y0, Y1] (inclusive, already clipped to the grid).  lt: packed
+// counters, hit << 16 | sum.  The reference's line is generated from the end with the smaller major coordinate
+// (cell t = 0 .. len along the major axis); a standard integer DDA has taken floor((2 dmin t + len) / (2 len))
+// minor steps before cell t.  That closed form is inverted here to clip the walk to the cells that lie in the
+// tile in BOTH coordinates, so the loop adds without testing anything:
+//   minor steps >= a  <=>  t >= ceil(len (2a - 1) / (2 dmin)),   minor steps <= b  <=>  t <= floor((len (2b + 1) - 1) / (2 dmin)).
+// The robot cell (t = 0, or t = len when the line comes from the beam's end) is left out: grid_prep_kernel added
+// its totals.  The beam's end cell receives its end hit (:72-75) and, when it is also the last generated cell
+// (:84-86), a second one.
+__device__ __forceinline__ void bin_walk(uint32_t* lt, int X0, int Y0, int X1, int Y1, int sx, int sy, int ex, int ey)
 {
-    const int X1 = X0 + BIN_T - 1, Y1 = Y0 + BIN_T - 1;
-    if (ex >= X0 && ex <= X1 && ey >= Y0 && ey <= Y1 && (INSIDE || inb(G, ex, ey)))       // :72-75
-        atomicAdd(&lt[(ex - X0) * BIN_T + (ey - Y0)], 0x10000u);
     const int dx = abs(ex - sx), dy = abs(ey - sy);
     const bool x_major = dy <= dx;
     const bool from_end = x_major ? sx > ex : sy > ey;
     const int len = x_major ? dx : dy, dmin = x_major ? dy : dx;
+    if (ex >= X0 && ex <= X1 && ey >= Y0 && ey <= Y1)
+        atomicAdd(&lt[(ex - X0) * BIN_T + (ey - Y0)], !from_end && len > 0 ? 0x20000u : 0x10000u);
     const int m0 = x_major ? (from_end ? ex : sx) : (from_end ? ey : sy);                  // major / minor of the first cell
     const int n0 = x_major ? (from_end ? ey : sy) : (from_end ? ex : sx);
     const int mstep = ((x_major ? ey - sy : ex - sx) * (from_end ? -1 : 1)) > 0 ? 1 : -1;
-    const int M0 = x_major ? X0 : Y0, N0 = x_major ? Y0 : X0;
-    const int t_lo = M0 - m0 > 0 ? M0 - m0 : 0;
-    const int t_hi = M0 + BIN_T - 1 - m0 < len ? M0 + BIN_T - 1 - m0 : len;
-    if (t_lo > t_hi) return;
+    const int M0 = x_major ? X0 : Y0, M1 = x_major ? X1 : Y1, N0 = x_major ? Y0 : X0, N1 = x_major ? Y1 : X1;
+    int t_lo = M0 - m0 > 0 ? M0 - m0 : 0;
+    int t_hi = M1 - m0 < len ? M1 - m0 : len;
+    if (from_end) t_hi = t_hi < len - 1 ? t_hi : len - 1; else t_lo = t_lo > 1 ? t_lo : 1;
+    const int a_lo = mstep > 0 ? N0 - n0 : n0 - N1;         // minor steps needed to enter the tile's minor range
+    const int b_hi = mstep > 0 ? N1 - n0 : n0 - N0;         // minor steps after which it is left
+    if (b_hi < 0 || a_lo > dmin || t_lo > t_hi) return;
+    const bool small = len < 32768;                         // every product below fits 32 bits
+    if (dmin > 0) {
+        if (a_lo > 0) {
+            const long long num = (long long)len * (2 * a_lo - 1) + 2 * dmin - 1;
+            const int q = small ? (int)((unsigned)num / (unsigned)(2 * dmin)) : (int)(num / (2ll * dmin));
+            t_lo = q > t_lo ? q : t_lo;
+        }
+        if (b_hi < dmin) {
+            const long long num = (long long)len * (2 * b_hi + 1) - 1;
+            const int q = small ? (int)((unsigned)num / (unsigned)(2 * dmin)) : (int)(num / (2ll * dmin));
+            t_hi = q < t_hi ? q : t_hi;
+        }
+        if (t_lo > t_hi) return;
+    }
     const int c_major = x_major ? BIN_T : 1, c_minor = x_major ? mstep : mstep * BIN_T;   // cell index steps
     const int inc_keep = 2 * dmin, inc_step = 2 * (dmin - len);
-    int t = t_lo;
-    int steps = 0;                                                                       // minor steps taken before cell t
-    if (len > 0) {
-        if (len < 32768) steps = (int)((2u * (unsigned)dmin * (unsigned)t + (unsigned)len) / (2u * (unsigned)len));   // t <= len
-        else steps = (int)((2ll * dmin * t + len) / (2ll * len));
+    int steps;                                                                           // minor steps taken before cell t_lo (len > 0 here)
+    if (small) steps = (int)((2u * (unsigned)dmin * (unsigned)t_lo + (unsigned)len) / (2u * (unsigned)len));
+    else steps = (int)((2ll * dmin * t_lo + len) / (2ll * len));
+    const int minor = n0 + mstep * steps;
+    int d = (int)(2ll * dmin * (t_lo + 1) - len - 2ll * len * steps);                   // |d| <= 2 len
+    int cc = x_major ? (m0 + t_lo - X0) * BIN_T + (minor - Y0) : (minor - X0) * BIN_T + (m0 + t_lo - Y0);
+    int n = t_hi - t_lo + 1;
+#if defined(LSA_GRID_STAMPS) && defined(LSA_GRID_STATS)
+    {
+        int mx = n;
+        for (int o = 32; o; o >>= 1) { const int v = __shfl_xor(mx, o); mx = v > mx ? v : mx; }      // (inactive lanes: stale values, close enough for a diagnostic)
+        atomicAdd(&lsa_grid_cycles[10], (unsigned long long)n);
+        if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) { atomicAdd(&lsa_grid_cycles[11], (unsigned long long)mx); atomicAdd(&lsa_grid_cycles[13], 1ull); }
     }
-    int minor = n0 + mstep * steps;
-    int d = (int)(2ll * dmin * (t + 1) - len - 2ll * len * steps);                      // |d| <= 2 len
-    int cc = x_major ? (m0 + t - X0) * BIN_T + (minor - Y0) : (minor - X0) * BIN_T + (m0 + t - Y0);
-    for (; t <= t_hi; ++t) {
-        bool ok = (unsigned)(minor - N0) < (unsigned)BIN_T && cc != robot_cc;
-        if (!INSIDE) ok = ok && inb(G, x_major ? m0 + t : minor, x_major ? minor : m0 + t);
-        if (ok) atomicAdd(&lt[cc], t == len ? 0x10001u : 1u);                            // :87, and the last generated cell :84-86
+#endif
+    // Neighbouring beams run through the same cells while they are close to the robot, and 64 adds of one wave
+    // instruction to one LDS address are executed one after the other (measured: half of this kernel's time).
+    // The lanes are in bearing order, so equal cells sit in runs of adjacent lanes: the first lane of a run adds
+    // the run's length, the others nothing.  When no two adjacent lanes agree the plain add is taken.
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned long long sentinel = 1ull << (63 - lane);
+    do {
+#if defined(LSA_GRID_DIAG_STORE)            // diagnostics (wrong counts): what the LDS adds cost
+        lt[cc] = 1u;
+#elif defined(LSA_GRID_DIAG_SPREAD)
+        atomicAdd(&lt[(cc + (int)(threadIdx.x & 63) * 67) & (BIN_T * BIN_T - 1)], 1u);
+#elif defined(LSA_GRID_DIAG_NOADD)
+        asm volatile("" :: "v"(cc));
+#elif defined(LSA_GRID_DIAG_PLAIN)
+        atomicAdd(&lt[cc], 1u);
+#else
+        const int prev = __builtin_amdgcn_update_dpp(-2, cc, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // lane 0 / idle neighbour: -2
+        const unsigned long long act = __ballot(1);
+        const unsigned long long heads = __ballot(cc != prev);
+        if (heads == act) atomicAdd(&lt[cc], 1u);                                        // :87
+        else if (cc != prev) {
+            const unsigned long long ends_ = ((heads | ~act) >> 1 >> lane) | sentinel;  // next run start or idle lane above this one
+            atomicAdd(&lt[cc], (uint32_t)__ffsll((long long)ends_));
+        }
+#endif
         const bool keep = d < 0;
-        cc += c_major + (keep ? 0 : c_minor);
-        minor += keep ? 0 : mstep;
+        cc += keep ? c_major : c_major + c_minor;
         d += keep ? inc_keep : inc_step;
-    }
+    } while (--n);
 }
 
 __global__ __launch_bounds__(256) void grid_binned_kernel(
@@ -624,6 +672,9 @@ __global__ __launch_bounds__(256) void grid_binned_kernel(
     __shared__ uint32_t lt[BIN_T * BIN_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int item = blockIdx.x;
+#ifdef LSA_GRID_STAMPS
+    unsigned long long gt_ = __builtin_readcyclecounter();
+#endif
     // the item's tile: the last tile whose first item is <= item (uniform; the offsets sit in L2)
     int lo = 0, hi = ntiles - 1;
     while (lo < hi) {
@@ -634,9 +685,12 @@ __global__ __launch_bounds__(256) void grid_binned_kernel(
     const int e0 = tile_off[tile] + part * chunk;
     const int e1 = e0 + chunk < tile_off[tile + 1] ? e0 + chunk : tile_off[tile + 1];
     const int X0 = (tile / nty_all) * BIN_T, Y0 = (tile % nty_all) * BIN_T;
-    const bool inside = X0 + BIN_T <= G.size_x && Y0 + BIN_T <= G.size_y;
+    const int X1 = X0 + BIN_T - 1 < G.size_x - 1 ? X0 + BIN_T - 1 : G.size_x - 1;      // the tile clipped to the grid
+    const int Y1 = Y0 + BIN_T - 1 < G.size_y - 1 ? Y0 + BIN_T - 1 : G.size_y - 1;
+    GSTAMP(4);                                              // item -> tile search
     for (int k = tid; k < BIN_T * BIN_T; k += 256) lt[k] = 0;
     __syncthreads();
+    GSTAMP(0);
     // every wave walks list entries, 64 rays at a time; the next entry's end cells are in flight meanwhile
     int q = e0 + wave;
     int2 e = make_int2(0, 0);
@@ -656,25 +710,25 @@ __global__ __launch_bounds__(256) void grid_binned_kernel(
             hx = info[hs].sx; hy = info[hs].sy; hn = info[hs].nb - 64 * bk;
             if (lane < hn) e = ends[(size_t)hs * n_beams + 64 * bk + lane];
         }
-        if (lane < nv) {
-            const bool rin = sx >= X0 && sx < X0 + BIN_T && sy >= Y0 && sy < Y0 + BIN_T;
-            const int robot_cc = rin ? (sx - X0) * BIN_T + (sy - Y0) : -1;
-            if (inside) bin_walk<true>(G, lt, X0, Y0, sx, sy, robot_cc, ec.x, ec.y);
-            else bin_walk<false>(G, lt, X0, Y0, sx, sy, robot_cc, ec.x, ec.y);
-        }
+        if (lane < nv) bin_walk(lt, X0, Y0, X1, Y1, sx, sy, ec.x, ec.y);
     }
     __syncthreads();
+    GSTAMP(2);
     // flush: consecutive lanes -> consecutive y of one x row (contiguous in the [x][y] layers)
     for (int k = tid; k < BIN_T * BIN_T; k += 256) {
         const uint32_t v = lt[k];
         if (!v) continue;
-        const int x = X0 + k / BIN_T, y = Y0 + k % BIN_T;
-        if (!(inside || inb(G, x, y))) continue;
+        const int x = X0 + k / BIN_T, y = Y0 + k % BIN_T;            // (cells outside the grid were never added to)
         const uint32_t vh = v >> 16, vs = v & 0xffffu;
         const size_t c = (size_t)x * G.size_y + y;
         if (items_here == 1) { if (vh) hit[c] += vh; if (vs) sum[c] += vs; }
         else { if (vh) atomicAdd(&hit[c], vh); if (vs) atomicAdd(&sum[c], vs); }
     }
+#ifdef LSA_GRID_STAMPS
+    __syncthreads();
+    GSTAMP(3);
+    if (tid == 0) { atomicAdd(&lsa_grid_cycles[9], 1ull); atomicAdd(&lsa_grid_cycles[5], 1ull); }
+#endif
 }
 
 // computeProbsOfMap: prob = hit / (double) sum clipped to 1, unseen cells 0.3.

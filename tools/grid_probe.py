@@ -37,6 +37,9 @@ if hasattr(capi.lib(), "lsa_debug_grid_cycles") or True:
         g.update_batch(nb, 1081, dgx, dgy, drob); ctx.sync()
         f(buf)
         v = list(buf)
-        tot = float(v[7])
+        tot = float(v[7]) or float(v[0] + v[1] + v[2] + v[3] + v[4]) or 1.0
+        if v[13]:
+            print("binned walk: entries-with-crossing %d, lane spans %d (%.1f per crossing lane-slot of 64), wave trip counts %d (mean %.1f), cells added %d -> lane utilisation %.1f%% of wave-iterations x 64"
+                  % (v[13], v[10], v[10] / (64.0 * v[13]), v[11], v[11] / float(v[13]), v[12], 100.0 * v[12] / (64.0 * v[11])))
         print("workgroups %d items %d blocks walked %d | share of workgroup time: cull %.1f%% walk %.1f%% zero+tail %.1f%% flush %.1f%% claim/idle %.1f%% | longest item %.0f cycles, mean workgroup life %.0f cycles"
               % (v[9], v[5], v[8], 100 * v[1] / tot, 100 * v[2] / tot, 100 * v[0] / tot, 100 * v[3] / tot, 100 * v[4] / tot, v[6], tot / max(v[9], 1)))
