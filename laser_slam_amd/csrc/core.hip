@@ -720,23 +720,23 @@ int lsa_grid_update_batch(lsa_grid* g, int S, int n_beams, const float* d_gx, co
             HIP_TRY(hipMalloc((void**)&g->d_blk, (size_t)S * nblk * sizeof(int4)));
             g->blk_cap = (size_t)S * nblk;
         }
-        if (!g->d_bbox) HIP_TRY(hipMalloc((void**)&g->d_bbox, 8 * sizeof(int)));
-        static const int bbox0[8] = {INT_MAX, INT_MAX, INT_MIN, INT_MIN, 0, 0, 0, 0};      // box, work-item counter
-        HIP_TRY(hipMemcpyAsync(g->d_bbox, bbox0, sizeof bbox0, hipMemcpyHostToDevice, g->c->stream));
         if (!(path_env && !strcmp(path_env, "owned")) && S < (1 << 24)) {
             // binned: prep (+ tile counts, robot-cell totals) -> offsets -> lists -> one workgroup per (tile, chunk of its list)
             const int ntx = (g->G.size_x + lsa::BIN_T - 1) / lsa::BIN_T, nty = (g->G.size_y + lsa::BIN_T - 1) / lsa::BIN_T, nt = ntx * nty;
-            if (!g->d_tile) HIP_TRY(hipMalloc((void**)&g->d_tile, sizeof(int) * (3 * ((size_t)nt + 1) + 2)));
+            if (!g->d_tile) HIP_TRY(hipMalloc((void**)&g->d_tile, sizeof(int) * (3 * ((size_t)nt + 1) + 4)));
             int* tile_cnt = g->d_tile; int* tile_off = tile_cnt + (nt + 1); int* item_off = tile_off + (nt + 1); int* totals = item_off + (nt + 1);
             const char* chunk_env = getenv("LSA_GRID_CHUNK");
-            int chunk = chunk_env ? atoi(chunk_env) : 64;
-            if (chunk < 4) chunk = 4;
+            int chunk = chunk_env ? atoi(chunk_env) : 0;      // 0: chosen on the device from the number of list entries
+            if (chunk != 0 && chunk < 4) chunk = 4;
             if (chunk > lsa::BIN_CHUNK_MAX) chunk = lsa::BIN_CHUNK_MAX;
             HIP_TRY(hipMemsetAsync(tile_cnt, 0, sizeof(int) * ((size_t)nt + 1), g->c->stream));
+            const int ngroups = (S + lsa::BIN_GROUP - 1) / lsa::BIN_GROUP;
             hipLaunchKernelGGL(lsa::grid_prep_kernel, dim3(S < 8192 ? S : 8192), dim3(256), 0, g->c->stream, g->G, S, n_beams,
-                               d_gx, d_gy, d_robot_xy, d_n_valid, g->d_ends, g->d_info, g->d_blk, g->d_bbox, tile_cnt, nty, g->d_hit, g->d_sum);
+                               d_gx, d_gy, d_robot_xy, d_n_valid, g->d_ends, g->d_info, g->d_blk, (int*)nullptr, g->d_hit, g->d_sum);
+            hipLaunchKernelGGL(lsa::grid_bin_tiles_kernel<false>, dim3(ngroups < 4096 ? ngroups : 4096), dim3(256), 0, g->c->stream, g->G, S, n_beams,
+                               g->d_info, g->d_blk, nty, tile_cnt, (const int*)nullptr, (uint32_t*)nullptr);
             hipLaunchKernelGGL(lsa::grid_bin_scan_kernel, dim3(1), dim3(256), 0, g->c->stream, tile_cnt, nt, chunk, tile_off, item_off, totals);
-            int tot[2] = {0, 0};                        // list entries, work items: sizes the list and the launch
+            int tot[3] = {0, 0, 0};                     // list entries, work items, chunk: size the list and the launch
             HIP_TRY(hipMemcpyAsync(tot, totals, sizeof tot, hipMemcpyDeviceToHost, g->c->stream));
             HIP_TRY(hipStreamSynchronize(g->c->stream));
             if (tot[0] <= 0) return LSA_OK;             // every ray outside the map
@@ -747,13 +747,16 @@ int lsa_grid_update_batch(lsa_grid* g, int S, int n_beams, const float* d_gx, co
                 HIP_TRY(hipMalloc((void**)&g->d_list, cap * sizeof(uint32_t)));
                 g->list_cap = cap;
             }
-            hipLaunchKernelGGL(lsa::grid_bin_fill_kernel, dim3(S < 8192 ? S : 8192), dim3(256), 0, g->c->stream, g->G, S, n_beams,
-                               g->d_info, g->d_blk, nty, tile_off, tile_cnt, g->d_list);
+            hipLaunchKernelGGL(lsa::grid_bin_tiles_kernel<true>, dim3(ngroups < 4096 ? ngroups : 4096), dim3(256), 0, g->c->stream, g->G, S, n_beams,
+                               g->d_info, g->d_blk, nty, tile_cnt, tile_off, g->d_list);
             hipLaunchKernelGGL(lsa::grid_binned_kernel, dim3(tot[1]), dim3(256), 0, g->c->stream, g->G, n_beams, g->d_ends, g->d_info,
-                               nt, nty, chunk, tile_off, item_off, g->d_list, g->d_hit, g->d_sum);
+                               nt, nty, tot[2], tile_off, item_off, g->d_list, g->d_hit, g->d_sum);
             HIP_TRY(hipGetLastError());
             return LSA_OK;
         }
+        if (!g->d_bbox) HIP_TRY(hipMalloc((void**)&g->d_bbox, 8 * sizeof(int)));
+        static const int bbox0[8] = {INT_MAX, INT_MAX, INT_MIN, INT_MIN, 0, 0, 0, 0};      // box, work-item counter
+        HIP_TRY(hipMemcpyAsync(g->d_bbox, bbox0, sizeof bbox0, hipMemcpyHostToDevice, g->c->stream));
         hipLaunchKernelGGL(lsa::grid_prep_kernel, dim3(S < 8192 ? S : 8192), dim3(256), 0, g->c->stream, g->G, S, n_beams,
                            d_gx, d_gy, d_robot_xy, d_n_valid, g->d_ends, g->d_info, g->d_blk, g->d_bbox);
         // scans per tile are divided among several workgroups when the batch covers few tiles (decided on the

@@ -202,52 +202,91 @@ __device__ __forceinline__ bool bin_tile_rect(const GridParam& G, int4 bb, int& 
     return true;
 }
 
-// boxes[bk] = (xmin, xmax, ymin, ymax) of block bk (LDS), scan_box likewise for the whole scan; all threads call.
-// FILL = false: tile_ctr[t] += blocks of this scan that meet tile t.
-// FILL = true : those blocks are appended to tile t's list (tile_ctr = fill cursors).
+constexpr int BIN_GROUP = 8;             // scans binned by one workgroup
+
+// One workgroup bins BIN_GROUP consecutive scans.  FILL = false: tile_ctr[t] += the blocks of these scans whose
+// box meets tile t.  FILL = true: the same blocks are appended to the tiles' lists (tile_ctr = fill cursors).
+// The blocks' boxes are merged in LDS - per scan into a 64-bit block mask per tile, then into a per-tile count of
+// the whole group - so that a tile's global counter sees one atomic per group and tile, not one per block.
 template <bool FILL>
-__device__ __forceinline__ void bin_scan_tiles(const GridParam& G, int s, int nb, int nblk, const int4* boxes, int4 scan_box,
-                                               int nty_all, int* __restrict__ tile_ctr, const int* __restrict__ tile_off,
-                                               uint32_t* __restrict__ list, unsigned long long* mask /* LDS, BIN_RECT_MAX */)
+__global__ __launch_bounds__(256) void grid_bin_tiles_kernel(GridParam G, int S, int n_beams, const ScanInfo* __restrict__ info,
+                                                             const int4* __restrict__ blk, int nty_all, int* __restrict__ tile_ctr,
+                                                             const int* __restrict__ tile_off, uint32_t* __restrict__ list)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nvb = (nb + 63) >> 6 < nblk ? (nb + 63) >> 6 : nblk;            // blocks that hold rays
-    int sx0, sx1, sy0, sy1;
-    if (nvb <= 0 || !bin_tile_rect(G, scan_box, sx0, sx1, sy0, sy1)) return;
-    const int swy = sy1 - sy0 + 1, area = (sx1 - sx0 + 1) * swy;
-    if (area <= BIN_RECT_MAX && nblk <= 64) {
-        for (int k = tid; k < area; k += blockDim.x) mask[k] = 0ull;
+    __shared__ int4 boxes[BIN_GROUP][64];
+    __shared__ int4 sbox[BIN_GROUP];
+    __shared__ int snb[BIN_GROUP];
+    __shared__ unsigned long long mask[BIN_RECT_MAX];
+    __shared__ int cnt[BIN_RECT_MAX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nblk = (n_beams + 63) >> 6;
+    for (int g0 = blockIdx.x * BIN_GROUP; g0 < S; g0 += gridDim.x * BIN_GROUP) {
+        const int ng = S - g0 < BIN_GROUP ? S - g0 : BIN_GROUP;
         __syncthreads();
-        for (int bk = wave; bk < nvb; bk += (blockDim.x >> 6)) {
-            int tx0, tx1, ty0, ty1;
-            if (!bin_tile_rect(G, boxes[bk], tx0, tx1, ty0, ty1)) continue;
-            const int wy = ty1 - ty0 + 1, nrect = (tx1 - tx0 + 1) * wy;
-            for (int k = lane; k < nrect; k += 64)
-                atomicOr(&mask[(tx0 + k / wy - sx0) * swy + (ty0 + k % wy - sy0)], 1ull << bk);
+        if (nblk <= 64) for (int k = tid; k < ng * nblk; k += 256) boxes[k / nblk][k % nblk] = blk[(size_t)g0 * nblk + k];
+        if (tid < ng) {
+            const ScanInfo si = info[g0 + tid];
+            sbox[tid] = make_int4(si.xmin, si.xmax, si.ymin, si.ymax);
+            snb[tid] = (si.nb + 63) >> 6 < nblk ? (si.nb + 63) >> 6 : nblk;      // blocks that hold rays
         }
         __syncthreads();
-        for (int k = tid; k < area; k += blockDim.x) {
-            unsigned long long m = mask[k];
-            if (!m) continue;
-            const int t = (sx0 + k / swy) * nty_all + sy0 + k % swy;
-            const int c = __popcll(m);
-            if (!FILL) atomicAdd(&tile_ctr[t], c);
-            else {
-                int pos = tile_off[t] + atomicAdd(&tile_ctr[t], c);
-                while (m) { const int bk = __ffsll((long long)m) - 1; m &= m - 1; list[pos++] = ((uint32_t)s << 8) | (uint32_t)bk; }
-            }
+        // the group's tile rectangle
+        int4 ub = make_int4(INT_MAX, INT_MIN, INT_MAX, INT_MIN);
+        for (int g = 0; g < ng; ++g) if (snb[g] > 0) {
+            ub.x = sbox[g].x < ub.x ? sbox[g].x : ub.x; ub.y = sbox[g].y > ub.y ? sbox[g].y : ub.y;
+            ub.z = sbox[g].z < ub.z ? sbox[g].z : ub.z; ub.w = sbox[g].w > ub.w ? sbox[g].w : ub.w;
         }
-        __syncthreads();
-    } else {
-        for (int bk = wave; bk < nvb; bk += (blockDim.x >> 6)) {
-            int tx0, tx1, ty0, ty1;
-            if (!bin_tile_rect(G, boxes[bk], tx0, tx1, ty0, ty1)) continue;
-            const int wy = ty1 - ty0 + 1, nrect = (tx1 - tx0 + 1) * wy;
-            for (int k = lane; k < nrect; k += 64) {
-                const int t = (tx0 + k / wy) * nty_all + ty0 + k % wy;
-                if (!FILL) atomicAdd(&tile_ctr[t], 1);
-                else list[tile_off[t] + atomicAdd(&tile_ctr[t], 1)] = ((uint32_t)s << 8) | (uint32_t)bk;
+        int sx0, sx1, sy0, sy1;
+        if (ub.x > ub.y || !bin_tile_rect(G, ub, sx0, sx1, sy0, sy1)) continue;
+        const int swy = sy1 - sy0 + 1, area = (sx1 - sx0 + 1) * swy;
+        if (area <= BIN_RECT_MAX && nblk <= 64) {
+            for (int k = tid; k < area; k += 256) cnt[k] = 0;
+            for (int pass = 0; pass < (FILL ? 2 : 1); ++pass) {
+                for (int g = 0; g < ng; ++g) {
+                    __syncthreads();
+                    for (int k = tid; k < area; k += 256) mask[k] = 0ull;
+                    __syncthreads();
+                    for (int bk = wave; bk < snb[g]; bk += 4) {
+                        int tx0, tx1, ty0, ty1;
+                        if (!bin_tile_rect(G, boxes[g][bk], tx0, tx1, ty0, ty1)) continue;
+                        const int wy = ty1 - ty0 + 1, nrect = (tx1 - tx0 + 1) * wy;
+                        for (int k = lane; k < nrect; k += 64)
+                            atomicOr(&mask[(tx0 + k / wy - sx0) * swy + (ty0 + k % wy - sy0)], 1ull << bk);
+                    }
+                    __syncthreads();
+                    for (int k = tid; k < area; k += 256) {              // (tile k belongs to one thread throughout)
+                        unsigned long long m = mask[k];
+                        if (!m) continue;
+                        if (pass == 0) cnt[k] += __popcll(m);
+                        else {
+                            int pos = cnt[k];
+                            cnt[k] = pos + __popcll(m);
+                            while (m) { const int bk = __ffsll((long long)m) - 1; m &= m - 1; list[pos++] = ((uint32_t)(g0 + g) << 8) | (uint32_t)bk; }
+                        }
+                    }
+                }
+                if (pass == 0) {
+                    for (int k = tid; k < area; k += 256) {
+                        const int c = cnt[k];
+                        if (!c) continue;
+                        const int t = (sx0 + k / swy) * nty_all + sy0 + k % swy;
+                        if (!FILL) atomicAdd(&tile_ctr[t], c);
+                        else cnt[k] = tile_off[t] + atomicAdd(&tile_ctr[t], c);  // the group's slots in tile t's list
+                    }
+                }
             }
+        } else {                                    // a huge rectangle (or more than 64 blocks per scan): block by block
+            for (int g = 0; g < ng; ++g)
+                for (int bk = wave; bk < snb[g]; bk += 4) {
+                    int tx0, tx1, ty0, ty1;
+                    const int4 bb = nblk <= 64 ? boxes[g][bk] : blk[(size_t)(g0 + g) * nblk + bk];
+                    if (!bin_tile_rect(G, bb, tx0, tx1, ty0, ty1)) continue;
+                    const int wy = ty1 - ty0 + 1, nrect = (tx1 - tx0 + 1) * wy;
+                    for (int k = lane; k < nrect; k += 64) {
+                        const int t = (tx0 + k / wy) * nty_all + ty0 + k % wy;
+                        if (!FILL) atomicAdd(&tile_ctr[t], 1);
+                        else list[tile_off[t] + atomicAdd(&tile_ctr[t], 1)] = ((uint32_t)(g0 + g) << 8) | (uint32_t)bk;
+                    }
+                }
         }
     }
 }
@@ -256,17 +295,12 @@ __global__ __launch_bounds__(256) void grid_prep_kernel(
     GridParam G, int S, int n_beams, const float* __restrict__ gx, const float* __restrict__ gy,
     const float* __restrict__ robot_xy, const int* __restrict__ n_valid,
     int2* __restrict__ ends, ScanInfo* __restrict__ info, int4* __restrict__ blk /* [S][n_beams/64]: xmin,xmax,ymin,ymax */,
-    int* __restrict__ bbox /* xmin, ymin, xmax, ymax */,
-    int* __restrict__ tile_cnt = nullptr /* binned path: blocks per 64x64 tile */, int nty_all = 0,
+    int* __restrict__ bbox /* xmin, ymin, xmax, ymax (owned-tile path; may be null) */,
     uint32_t* __restrict__ hit = nullptr, uint32_t* __restrict__ sum = nullptr /* binned path: robot-cell totals */)
 {
     __shared__ int red[4][5];
-    __shared__ int4 boxes[64];
-    __shared__ int4 scan_box;
-    __shared__ unsigned long long mask[BIN_RECT_MAX];
     const int nblk = (n_beams + 63) >> 6;
     for (int s = blockIdx.x; s < S; s += gridDim.x) {
-        __syncthreads();                                    // (the previous scan's boxes are still being read)
         const int sx = grid_cell1(robot_xy[2 * s], G.off_x, G.center_x, G.res);
         const int sy = grid_cell1(robot_xy[2 * s + 1], G.off_y, G.center_y, G.res);
         const int nb = n_valid ? (n_valid[s] < n_beams ? n_valid[s] : n_beams) : n_beams;
@@ -286,7 +320,6 @@ __global__ __launch_bounds__(256) void grid_prep_kernel(
                     a0 = p0 < a0 ? p0 : a0; a1 = p1 > a1 ? p1 : a1; c0 = q0 < c0 ? q0 : c0; c1 = q1 > c1 ? q1 : c1;
                 }
                 if ((threadIdx.x & 63) == 0) blk[(size_t)s * nblk + (i >> 6)] = make_int4(a0, a1, c0, c1);
-                if ((threadIdx.x & 63) == 0 && (i >> 6) < 64) boxes[i >> 6] = make_int4(a0, a1, c0, c1);
             }
             if (i >= nb) continue;
             x0 = ex < x0 ? ex : x0; x1 = ex > x1 ? ex : x1;
@@ -319,12 +352,7 @@ __global__ __launch_bounds__(256) void grid_prep_kernel(
                 if (si.nb) atomicAdd(&sum[c], (uint32_t)si.nb);
                 if (nh) atomicAdd(&hit[c], (uint32_t)nh);
             }
-            atomicMin(&bbox[0], x0); atomicMin(&bbox[1], y0); atomicMax(&bbox[2], x1); atomicMax(&bbox[3], y1);
-            scan_box = make_int4(x0, x1, y0, y1);
-        }
-        if (tile_cnt) {                                     // binned path: blocks per tile
-            __syncthreads();
-            bin_scan_tiles<false>(G, s, nb > 0 ? nb : 0, nblk, boxes, scan_box, nty_all, tile_cnt, nullptr, nullptr, mask);
+            if (bbox) { atomicMin(&bbox[0], x0); atomicMin(&bbox[1], y0); atomicMax(&bbox[2], x1); atomicMax(&bbox[3], y1); }
         }
     }
 }
@@ -518,12 +546,12 @@ __global__ __launch_bounds__(256) void grid_owned_kernel(
 
 // Batched update, binned (the throughput path).  The owned-tile kernel above spends most of its time finding out
 // which rays concern a tile; here that question is answered once, rasteriser style:
-//   grid_prep_kernel      (above) end cells, per-scan header, the bounding box of every 64-beam block; with
-//                         `tile_cnt` it also counts, per 64x64 tile of the grid, the blocks whose box meets it,
-//                         and adds the robot cell's totals (every ray of a scan starts there) to the layers.
+//   grid_prep_kernel      (above) end cells, per-scan header, the bounding box of every 64-beam block; adds the
+//                         robot cell's totals (every ray of a scan starts there) to the layers.
+//   grid_bin_tiles_kernel<false>  per 64x64 tile of the grid, the number of blocks whose box meets it.
 //   grid_bin_scan_kernel  one workgroup: tile counts -> list offsets and work-item offsets (an item = up to
 //                         `chunk` list entries of one tile), totals for the host (list capacity, launch size).
-//   grid_bin_fill_kernel  every (scan, block) appends itself to the lists of the tiles its box meets.
+//   grid_bin_tiles_kernel<true>   every (scan, block) is appended to the lists of the tiles its box meets.
 //   grid_binned_kernel    one workgroup per item: the tile's two count layers, packed hit << 16 | sum, live in
 //                         16 KiB of LDS; every wave walks list entries, 64 rays at a time, through exactly the
 //                         part of the reference's Bresenham line inside the tile (closed-form restart as above,
@@ -533,46 +561,51 @@ __global__ __launch_bounds__(256) void grid_owned_kernel(
 // costs nothing.  Counts are additive integers: the order of the list entries does not matter.
 constexpr int BIN_CHUNK_MAX = 256;       // packed 16-bit counters: sum <= 64 chunk, hit <= 128 chunk per cell and item
 
-__global__ __launch_bounds__(256) void grid_bin_scan_kernel(int* __restrict__ tile_cnt, int ntiles, int chunk,
+__global__ __launch_bounds__(256) void grid_bin_scan_kernel(int* __restrict__ tile_cnt, int ntiles, int chunk_req,
                                                             int* __restrict__ tile_off, int* __restrict__ item_off,
-                                                            int* __restrict__ totals /* entries, items */)
+                                                            int* __restrict__ totals /* entries, items, chunk */)
 {
-    __shared__ int sh[2][256];
+    __shared__ int sh[256];
     const int tid = threadIdx.x, per = (ntiles + 255) / 256, a = tid * per, b = a + per < ntiles ? a + per : ntiles;
-    int e = 0, it = 0;
-    for (int t = a; t < b; ++t) { const int c = tile_cnt[t]; e += c; it += (c + chunk - 1) / chunk; }
-    sh[0][tid] = e; sh[1][tid] = it;
+    // list offsets
+    int e = 0;
+    for (int t = a; t < b; ++t) e += tile_cnt[t];
+    sh[tid] = e;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
-        const int x = tid >= off ? sh[0][tid - off] : 0, y = tid >= off ? sh[1][tid - off] : 0;
+        const int x = tid >= off ? sh[tid - off] : 0;
         __syncthreads();
-        sh[0][tid] += x; sh[1][tid] += y;
+        sh[tid] += x;
         __syncthreads();
     }
-    int eo = sh[0][tid] - e, io = sh[1][tid] - it;
+    const int entries = sh[255];
+    int eo = sh[tid] - e;
+    // entries per work item: about 4096 items (two rounds of resident workgroups) unless the caller fixed it;
+    // small chunks pay the tile's zeroing and flush more often, large ones leave compute units idle at the end
+    int chunk = chunk_req;
+    if (chunk <= 0) {
+        chunk = (entries / 4096 + 15) & ~15;
+        chunk = chunk < 32 ? 32 : (chunk > BIN_CHUNK_MAX ? BIN_CHUNK_MAX : chunk);
+    }
+    int it = 0;
+    for (int t = a; t < b; ++t) it += (tile_cnt[t] + chunk - 1) / chunk;
+    __syncthreads();
+    sh[tid] = it;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int x = tid >= off ? sh[tid - off] : 0;
+        __syncthreads();
+        sh[tid] += x;
+        __syncthreads();
+    }
+    int io = sh[tid] - it;
     for (int t = a; t < b; ++t) {
         const int c = tile_cnt[t];
         tile_off[t] = eo; item_off[t] = io;
         eo += c; io += (c + chunk - 1) / chunk;
         tile_cnt[t] = 0;                                    // becomes the fill cursor
     }
-    if (tid == 255) { tile_off[ntiles] = sh[0][255]; item_off[ntiles] = sh[1][255]; totals[0] = sh[0][255]; totals[1] = sh[1][255]; }
-}
-
-__global__ __launch_bounds__(256) void grid_bin_fill_kernel(GridParam G, int S, int n_beams, const ScanInfo* __restrict__ info,
-                                                            const int4* __restrict__ blk, int nty_all, const int* __restrict__ tile_off,
-                                                            int* __restrict__ tile_cur, uint32_t* __restrict__ list)
-{
-    __shared__ int4 boxes[64];
-    __shared__ unsigned long long mask[BIN_RECT_MAX];
-    const int nblk = (n_beams + 63) >> 6;
-    for (int s = blockIdx.x; s < S; s += gridDim.x) {
-        __syncthreads();
-        if (threadIdx.x < nblk && threadIdx.x < 64) boxes[threadIdx.x] = blk[(size_t)s * nblk + threadIdx.x];
-        const ScanInfo si = info[s];
-        __syncthreads();
-        bin_scan_tiles<true>(G, s, si.nb, nblk, boxes, make_int4(si.xmin, si.xmax, si.ymin, si.ymax), nty_all, tile_cur, tile_off, list, mask);
-    }
+    if (tid == 255) { tile_off[ntiles] = entries; item_off[ntiles] = sh[255]; totals[0] = entries; totals[1] = sh[255]; totals[2] = chunk; }
 }
 
 // The part of one ray inside the tile [X0, X1] x [Y0, Y1] (inclusive, already clipped to the grid).  lt: packed
