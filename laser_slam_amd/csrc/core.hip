@@ -639,6 +639,7 @@ struct lsa_grid {
     int* d_tile = nullptr;
     uint32_t* d_list = nullptr;
     size_t list_cap = 0;
+    int* h_tot = nullptr;        // pinned: list entries, work items, chunk of the current batch
 };
 
 int lsa_grid_create(lsa_grid** out, lsa_ctx* c, int sx, int sy, int cx, int cy, float offx, float offy, double res)
@@ -670,6 +671,7 @@ void lsa_grid_destroy(lsa_grid* g)
     hipSetDevice(g->c->device);
     hipStreamSynchronize(g->c->stream);
     hipFree(g->d_hit); hipFree(g->d_sum); hipFree(g->d_prob); hipFree(g->d_tmp); hipFree(g->d_rows); hipFree(g->d_pts); hipFree(g->d_ends); hipFree(g->d_info); hipFree(g->d_blk); hipFree(g->d_bbox); hipFree(g->d_tile); hipFree(g->d_list);
+    if (g->h_tot) hipHostFree(g->h_tot);
     delete g;
 }
 
@@ -736,8 +738,9 @@ int lsa_grid_update_batch(lsa_grid* g, int S, int n_beams, const float* d_gx, co
             hipLaunchKernelGGL(lsa::grid_bin_tiles_kernel<false>, dim3(ngroups < 4096 ? ngroups : 4096), dim3(256), 0, g->c->stream, g->G, S, n_beams,
                                g->d_info, g->d_blk, nty, tile_cnt, (const int*)nullptr, (uint32_t*)nullptr);
             hipLaunchKernelGGL(lsa::grid_bin_scan_kernel, dim3(1), dim3(256), 0, g->c->stream, tile_cnt, nt, chunk, tile_off, item_off, totals);
-            int tot[3] = {0, 0, 0};                     // list entries, work items, chunk: size the list and the launch
-            HIP_TRY(hipMemcpyAsync(tot, totals, sizeof tot, hipMemcpyDeviceToHost, g->c->stream));
+            if (!g->h_tot) HIP_TRY(hipHostMalloc((void**)&g->h_tot, 4 * sizeof(int)));
+            int* tot = g->h_tot;                        // list entries, work items, chunk: size the list and the launch
+            HIP_TRY(hipMemcpyAsync(tot, totals, 3 * sizeof(int), hipMemcpyDeviceToHost, g->c->stream));
             HIP_TRY(hipStreamSynchronize(g->c->stream));
             if (tot[0] <= 0) return LSA_OK;             // every ray outside the map
             if (g->list_cap < (size_t)tot[0]) {

@@ -617,6 +617,17 @@ __global__ __launch_bounds__(256) void grid_bin_scan_kernel(int* __restrict__ ti
 // The robot cell (t = 0, or t = len when the line comes from the beam's end) is left out: grid_prep_kernel added
 // its totals.  The beam's end cell receives its end hit (:72-75) and, when it is also the last generated cell
 // (:84-86), a second one.
+// floor(n / d) for n < 2^31, 1 <= d < 2^16: exact while the quotient is below 2^16; larger quotients come out as
+// large (within 2^-20 of the truth) - the callers clamp those away.  A third of the compiler's 32-bit division.
+__device__ __forceinline__ int bin_udiv(unsigned n, unsigned d)
+{
+    unsigned q = (unsigned)((float)n * __frcp_rn((float)d));
+    const int r = (int)(n - q * d);
+    q = r < 0 ? q - 1 : q;
+    q = r >= (int)d ? q + 1 : q;
+    return (int)q;
+}
+
 __device__ __forceinline__ void bin_walk(uint32_t* lt, int X0, int Y0, int X1, int Y1, int sx, int sy, int ex, int ey)
 {
     const int dx = abs(ex - sx), dy = abs(ey - sy);
@@ -639,12 +650,12 @@ __device__ __forceinline__ void bin_walk(uint32_t* lt, int X0, int Y0, int X1, i
     if (dmin > 0) {
         if (a_lo > 0) {
             const long long num = (long long)len * (2 * a_lo - 1) + 2 * dmin - 1;
-            const int q = small ? (int)((unsigned)num / (unsigned)(2 * dmin)) : (int)(num / (2ll * dmin));
+            const int q = small ? bin_udiv((unsigned)num, (unsigned)(2 * dmin)) : (int)(num / (2ll * dmin));
             t_lo = q > t_lo ? q : t_lo;
         }
         if (b_hi < dmin) {
             const long long num = (long long)len * (2 * b_hi + 1) - 1;
-            const int q = small ? (int)((unsigned)num / (unsigned)(2 * dmin)) : (int)(num / (2ll * dmin));
+            const int q = small ? bin_udiv((unsigned)num, (unsigned)(2 * dmin)) : (int)(num / (2ll * dmin));
             t_hi = q < t_hi ? q : t_hi;
         }
         if (t_lo > t_hi) return;
@@ -652,7 +663,7 @@ __device__ __forceinline__ void bin_walk(uint32_t* lt, int X0, int Y0, int X1, i
     const int c_major = x_major ? BIN_T : 1, c_minor = x_major ? mstep : mstep * BIN_T;   // cell index steps
     const int inc_keep = 2 * dmin, inc_step = 2 * (dmin - len);
     int steps;                                                                           // minor steps taken before cell t_lo (len > 0 here)
-    if (small) steps = (int)((2u * (unsigned)dmin * (unsigned)t_lo + (unsigned)len) / (2u * (unsigned)len));
+    if (small) steps = bin_udiv(2u * (unsigned)dmin * (unsigned)t_lo + (unsigned)len, 2u * (unsigned)len);
     else steps = (int)((2ll * dmin * t_lo + len) / (2ll * len));
     const int minor = n0 + mstep * steps;
     int d = (int)(2ll * dmin * (t_lo + 1) - len - 2ll * len * steps);                   // |d| <= 2 len
@@ -669,9 +680,11 @@ __device__ __forceinline__ void bin_walk(uint32_t* lt, int X0, int Y0, int X1, i
     // Neighbouring beams run through the same cells while they are close to the robot, and 64 adds of one wave
     // instruction to one LDS address are executed one after the other (measured: half of this kernel's time).
     // The lanes are in bearing order, so equal cells sit in runs of adjacent lanes: the first lane of a run adds
-    // the run's length, the others nothing.  When no two adjacent lanes agree the plain add is taken.
+    // the run's length, the others nothing (runs are cut at lane 32 so that 32-bit masks do).  Starting lane l
+    // l mod k iterations late instead - rays of one scan that are a different number of steps from the robot
+    // are in different cells - was measured slower for every k (the extra iterations cost more).
     const int lane = (int)(threadIdx.x & 63);
-    const unsigned long long sentinel = 1ull << (63 - lane);
+    const uint32_t sentinel = 0x80000000u >> (lane & 31);
     do {
 #if defined(LSA_GRID_DIAG_STORE)            // diagnostics (wrong counts): what the LDS adds cost
         lt[cc] = 1u;
@@ -684,11 +697,10 @@ __device__ __forceinline__ void bin_walk(uint32_t* lt, int X0, int Y0, int X1, i
 #else
         const int prev = __builtin_amdgcn_update_dpp(-2, cc, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // lane 0 / idle neighbour: -2
         const unsigned long long act = __ballot(1);
-        const unsigned long long heads = __ballot(cc != prev);
-        if (heads == act) atomicAdd(&lt[cc], 1u);                                        // :87
-        else if (cc != prev) {
-            const unsigned long long ends_ = ((heads | ~act) >> 1 >> lane) | sentinel;  // next run start or idle lane above this one
-            atomicAdd(&lt[cc], (uint32_t)__ffsll((long long)ends_));
+        const unsigned long long heads = __ballot(cc != prev) | ~act | 0x100000001ull;   // run starts, idle lanes, lanes 0 and 32
+        if (cc != prev || (lane & 31) == 0) {                                            // :87
+            const uint32_t h = lane < 32 ? (uint32_t)heads : (uint32_t)(heads >> 32);
+            atomicAdd(&lt[cc], (uint32_t)__ffs((int)((h >> 1 >> (lane & 31)) | sentinel)));   // distance to the next run start above
         }
 #endif
         const bool keep = d < 0;
