@@ -701,7 +701,7 @@ int lsa_grid_update_batch(lsa_grid* g, int S, int n_beams, const float* d_gx, co
     // Batches: tile ownership (no global atomics).  LSA_GRID_PATH=scan forces the per-scan kernels.
     const char* path_env = getenv("LSA_GRID_PATH");
     const char* splits_env = getenv("LSA_GRID_SPLITS");
-    if (S >= 8 && n_beams <= 4096 && !(path_env && !strcmp(path_env, "scan"))) {      // (one lane per 64-beam block)
+    if (S >= 16 && n_beams <= 4096 && !(path_env && !strcmp(path_env, "scan"))) {      // (one lane per 64-beam block)
         const size_t need = (size_t)S * n_beams;
         if (g->ends_cap < need) {
             if (g->d_ends) HIP_TRY(hipFree(g->d_ends));
