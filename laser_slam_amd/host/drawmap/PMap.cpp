@@ -14,7 +14,11 @@ void must(int rc, const char* what)
 
 CPMap::CPMap(float prob_thre)
     : m_size_x(0), m_size_y(0), m_center_x(0), m_center_y(0), m_offset_x(0), m_offset_y(0), m_resolution(0),
-      m_max_line_lens(0), m_prob_thre(prob_thre), m_ctx(0), m_grid(0) {}
+      m_max_line_lens(0), m_prob_thre(prob_thre), m_qstride(0), m_flush_scans(256), m_dx(0), m_dy(0), m_drob(0), m_dn(0),
+      m_dcap_pts(0), m_dcap_scans(0), m_ctx(0), m_grid(0)
+{
+    if (const char* e = getenv("LSA_PMAP_BATCH")) m_flush_scans = atoi(e) > 1 ? atoi(e) : 1;
+}
 
 CPMap::~CPMap() { uninitMap(); }
 
@@ -39,6 +43,9 @@ void CPMap::initializeMap(int size_x, int size_y, int start_x, int start_y, floa
 
 void CPMap::uninitMap()
 {
+    m_qx.clear(); m_qy.clear(); m_qrob.clear(); m_qn.clear(); m_qstride = 0;          // (nobody can read the queued scans any more)
+    if (m_dx) { lsa_free(m_dx); lsa_free(m_dy); m_dx = m_dy = 0; m_dcap_pts = 0; }
+    if (m_drob) { lsa_free(m_drob); lsa_free(m_dn); m_drob = m_dn = 0; m_dcap_scans = 0; }
     if (m_grid) { lsa_grid_destroy(m_grid); m_grid = 0; }
     if (m_ctx) { lsa_ctx_destroy(m_ctx); m_ctx = 0; }
 }
@@ -52,13 +59,44 @@ void CPMap::updateMap(float* gx, float* gy, int n, float rx, float ry, float)
         computeProbsOfMap();
         return;
     }
-    must(lsa_grid_update_host(m_grid, gx, gy, n, rx, ry), "lsa_grid_update_host");
+    if (n == 0) return;
+    if (m_flush_scans <= 1) { must(lsa_grid_update_host(m_grid, gx, gy, n, rx, ry), "lsa_grid_update_host"); return; }
+    if (!m_qn.empty() && n > m_qstride) flushPending();      // rows are as wide as the queue's first scan
+    if (m_qn.empty()) m_qstride = n;
+    m_qx.insert(m_qx.end(), gx, gx + n); m_qx.resize(m_qx.size() + (m_qstride - n), 0.0f);
+    m_qy.insert(m_qy.end(), gy, gy + n); m_qy.resize(m_qy.size() + (m_qstride - n), 0.0f);
+    m_qrob.push_back(rx); m_qrob.push_back(ry);
+    m_qn.push_back(n);
+    if ((int)m_qn.size() >= m_flush_scans) flushPending();
+}
+
+void CPMap::flushPending()
+{
+    const size_t S = m_qn.size();
+    if (!S) return;
+    const size_t pts = S * (size_t)m_qstride;
+    if (m_dcap_pts < pts) {
+        if (m_dx) { lsa_free(m_dx); lsa_free(m_dy); m_dx = m_dy = 0; m_dcap_pts = 0; }
+        must(lsa_malloc(&m_dx, pts * 4), "lsa_malloc"); must(lsa_malloc(&m_dy, pts * 4), "lsa_malloc");
+        m_dcap_pts = pts;
+    }
+    if (m_dcap_scans < S) {
+        if (m_drob) { lsa_free(m_drob); lsa_free(m_dn); m_drob = m_dn = 0; m_dcap_scans = 0; }
+        must(lsa_malloc(&m_drob, S * 8), "lsa_malloc"); must(lsa_malloc(&m_dn, S * 4), "lsa_malloc");
+        m_dcap_scans = S;
+    }
+    must(lsa_memcpy_h2d(m_ctx, m_dx, m_qx.data(), pts * 4), "h2d"); must(lsa_memcpy_h2d(m_ctx, m_dy, m_qy.data(), pts * 4), "h2d");
+    must(lsa_memcpy_h2d(m_ctx, m_drob, m_qrob.data(), S * 8), "h2d"); must(lsa_memcpy_h2d(m_ctx, m_dn, m_qn.data(), S * 4), "h2d");
+    must(lsa_grid_update_batch(m_grid, (int)S, m_qstride, (float*)m_dx, (float*)m_dy, (float*)m_drob, (int32_t*)m_dn), "lsa_grid_update_batch");
+    must(lsa_ctx_sync(m_ctx), "sync");
+    m_qx.clear(); m_qy.clear(); m_qrob.clear(); m_qn.clear();
 }
 
 void CPMap::updateMapBatch(const float* gx, const float* gy, int n_scans, int n_beams, const float* robot_xy,
                            const int* n_valid)
 {
     if (!m_grid) throw std::runtime_error("CPMap: initializeMap has not been called");
+    flushPending();
     const size_t pts = (size_t)n_scans * n_beams;
     void *dx = 0, *dy = 0, *dr = 0, *dn = 0;
     must(lsa_malloc(&dx, pts * 4), "lsa_malloc"); must(lsa_malloc(&dy, pts * 4), "lsa_malloc");
@@ -91,6 +129,7 @@ void CPMap::mirror(int layer, vector<vector<float> >& dst)
 
 void CPMap::syncFromDevice()
 {
+    flushPending();
     mirror(0, m_maphit);
     mirror(1, m_mapsum);
 }
@@ -99,6 +138,7 @@ void CPMap::syncFromDevice()
 // (drawmap.cpp:144-149), so they are mirrored here.
 void CPMap::computeProbsOfMap()
 {
+    flushPending();
     must(lsa_grid_compute_prob(m_grid), "lsa_grid_compute_prob");
     syncFromDevice();
     mirror(2, m_mapprob);

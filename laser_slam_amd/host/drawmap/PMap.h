@@ -3,6 +3,9 @@
 // Bresenham ray casting runs in a HIP kernel, and the public float layers are mirrored
 // back whenever the reference would have had them up to date for a reader
 // (computeProbsOfMap, updateMap(n < 0), getPointCloud) or on demand (syncFromDevice).
+// updateMap() queues the scan on the host and hands the queue to the device in batches (256 scans, or when a
+// reader needs the counts): counts are additive, so the result is the sequential one bit for bit, and the
+// per-scan signature runs at the batched kernels' rate.  LSA_PMAP_BATCH=1 in the environment disables the queue.
 #ifndef PMAP_H
 #define PMAP_H
 
@@ -62,9 +65,17 @@ public:
     vector<vector<float> > m_mapsum;
     vector<vector<float> > m_mapprob;
 
+    void flushPending();       // queued scans -> device (every reader calls it)
+
 private:
     void default_init();
     void mirror(int layer, vector<vector<float> >& dst);
+    vector<float> m_qx, m_qy, m_qrob;      // queued scans: rows of m_qstride end points, robot (x, y)
+    vector<int> m_qn;                      // end points per queued scan
+    int m_qstride;
+    int m_flush_scans;
+    void *m_dx, *m_dy, *m_drob, *m_dn;     // device staging of a flush
+    size_t m_dcap_pts, m_dcap_scans;
     CPMap(const CPMap&);
     CPMap& operator=(const CPMap&);
     lsa_ctx* m_ctx;

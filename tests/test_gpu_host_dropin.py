@@ -129,6 +129,31 @@ def test_cpmap_dropin(name, exe, tmp_path):
     assert same_bits(cx, z["cloud_x"]) and same_bits(cy, z["cloud_y"])
 
 
+def test_cpmap_dropin_queue(exe, tmp_path):
+    """updateMap() queues scans and flushes them in batches of 256 (or when a row wider than the queue's arrives, or
+    when a reader needs the counts): 20 passes over the golden scans - 600 per-scan calls with ragged lengths - must
+    give exactly 20 x the golden counts and, the ratio being the same, the golden probabilities."""
+    z = np.load(os.path.join(GOLDEN, "pmap_mit.npz"))
+    G = z["geom"]
+    reps = 20
+    gx = np.tile(z["gx"].astype(np.float32), (reps, 1)); gy = np.tile(z["gy"].astype(np.float32), (reps, 1))
+    rob = np.tile(z["robot"].astype(np.float32), (reps, 1))
+    assert len(set(rob[:, 2].tolist())) > 1                       # ragged: the queue's row width has to grow on the way
+    S, nb = gx.shape
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<4i2fd2i", int(G[0]), int(G[1]), int(G[2]), int(G[3]), float(G[4]), float(G[5]), float(G[6]), S, nb))
+        f.write(gx.tobytes()); f.write(gy.tobytes()); f.write(rob.tobytes())
+    res = subprocess.run([exe, "pmap", fin, fout], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    raw = open(fout, "rb").read()
+    cells = int(G[0]) * int(G[1])
+    lay = np.frombuffer(raw, np.float32, 3 * cells).reshape(3, int(G[0]), int(G[1]))
+    assert np.array_equal(lay[0], reps * z["hit"].astype(np.float32))
+    assert np.array_equal(lay[1], reps * z["sum"].astype(np.float32))
+    assert same_bits(lay[2], z["prob"])
+
+
 def test_offline_driver_runlog_improved(exe, tmp_path):
     """CPolarMatch::runOurFile -> runlogImproved (ZHPolar_Match.cpp:353-360, 736-852) on the in-house
     LMS151 log: the trajectory file against the same driver logic replayed with the CPU oracle."""

@@ -42,5 +42,5 @@ json.dump(sqo, open("profiles/r01_pmc_sq_counters.json", "w"), indent=1)
 shutil.copy(glob.glob(stats + "/*/*kernel_stats.csv")[0], "profiles/r01_kernel_stats.csv")
 shutil.copy(bprof, "profiles/r01_bench_profiled.json")
 shutil.copy(bdef, "profiles/r01_bench_default.json")
-for k in ("lsa::icp_kernel", "lsa::psm_kernel", "lsa::grid_owned_kernel"):
+for k in ("lsa::icp_kernel", "lsa::psm_kernel", "lsa::grid_binned_kernel"):
     print(k, out.get(k), {c: "%.4g" % v for c, v in sqo.get(k, {}).items()})
