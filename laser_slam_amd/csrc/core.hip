@@ -879,6 +879,7 @@ struct lsa_field {
     float* d_loglik = nullptr;
     uint16_t* d_col = nullptr;
     size_t cells = 0;
+    uint32_t* d_cls = nullptr;   // scan simulator: two-bit cell classes in 16 x 16 tiles (sim_class_kernel), rebuilt per call
 };
 
 int lsa_field_create(lsa_field** out, lsa_ctx* c, int sx, int sy, int cx, int cy, float offx, float offy, double res)
@@ -909,7 +910,7 @@ void lsa_field_destroy(lsa_field* f)
     if (!f) return;
     hipSetDevice(f->c->device);
     hipStreamSynchronize(f->c->stream);
-    hipFree(f->d_lik); hipFree(f->d_loglik); hipFree(f->d_col);
+    hipFree(f->d_lik); hipFree(f->d_loglik); hipFree(f->d_col); hipFree(f->d_cls);
     delete f;
 }
 
@@ -1085,6 +1086,16 @@ static lsa::SimParam sim_param(const lsa_field* f, int n_beams, float fov, float
     return S;
 }
 
+// the simulator's view of the map: d_prob -> two-bit classes in cache-line tiles (sim_kernels.hip)
+static int sim_classes(lsa_field* f, const lsa::SimParam& S, const float* d_prob, int* nty_out)
+{
+    const int ntx = (S.size_x + 15) / 16, nty = (S.size_y + 15) / 16;
+    if (!f->d_cls) HIP_TRY(hipMalloc((void**)&f->d_cls, (size_t)ntx * nty * 64));
+    hipLaunchKernelGGL(lsa::sim_class_kernel, dim3(blocks_for((size_t)ntx * nty * 16, 256)), dim3(256), 0, f->c->stream, S, d_prob, ntx, nty, f->d_cls);
+    *nty_out = nty;
+    return LSA_OK;
+}
+
 int lsa_simulate_scans(lsa_field* f, const float* d_prob, const float* d_poses, int n_poses, int n_beams,
                        float fov, float min_angle, float max_range, float* d_ranges, uint8_t* d_bad)
 {
@@ -1093,7 +1104,8 @@ int lsa_simulate_scans(lsa_field* f, const float* d_prob, const float* d_poses, 
     if (n_beams < 2 || !(max_range > 0)) return fail(LSA_E_ARG, "bad scan geometry");
     HIP_TRY(hipSetDevice(f->c->device));
     const lsa::SimParam S = sim_param(f, n_beams, fov, min_angle, max_range);
-    hipLaunchKernelGGL(lsa::sim_scans_kernel, dim3(n_poses < 65535 ? n_poses : 65535), dim3(256), 0, f->c->stream, S, d_prob, d_poses,
+    int nty = 0, rc = sim_classes(f, S, d_prob, &nty); if (rc) return rc;
+    hipLaunchKernelGGL(lsa::sim_scans_kernel, dim3(n_poses < 65535 ? n_poses : 65535), dim3(256), 0, f->c->stream, S, f->d_cls, nty, d_poses,
                        n_poses, d_ranges, d_bad, (float*)nullptr, (float*)nullptr);
     HIP_TRY(hipGetLastError());
     return LSA_OK;
@@ -1107,8 +1119,9 @@ int lsa_beam_model_scores(lsa_field* f, const float* d_prob, const float* d_pose
     if (n_beams < 2 || n_beams > 4096 || !(max_range > 0)) return fail(LSA_E_ARG, "bad scan geometry");
     HIP_TRY(hipSetDevice(f->c->device));
     const lsa::SimParam S = sim_param(f, n_beams, fov, min_angle, max_range);
+    int nty = 0, rc = sim_classes(f, S, d_prob, &nty); if (rc) return rc;
     hipLaunchKernelGGL(lsa::beam_model_kernel, dim3(n_poses < 65535 ? n_poses : 65535), dim3(256), sizeof(double) * n_beams, f->c->stream,
-                       S, d_prob, d_poses, n_poses, d_obs_r, d_obs_bad, d_score);
+                       S, f->d_cls, nty, d_poses, n_poses, d_obs_r, d_obs_bad, d_score);
     HIP_TRY(hipGetLastError());
     return LSA_OK;
 }
@@ -1139,8 +1152,10 @@ int lsa_icp_goodness_scores(lsa_field* f, const float* d_prob, const float* d_po
     int* d_match = (int*)(d_sy + pts); int* d_off = d_match + pts;
     const lsa::SimParam S = sim_param(f, n_beams, fov, min_angle, max_range);
     hipError_t e = hipMemsetAsync(d_init, 0, sizeof(double) * 3 * (size_t)n_poses, c->stream);
+    int nty = 0;
+    if (e == hipSuccess && sim_classes(f, S, d_prob, &nty) != LSA_OK) e = hipErrorOutOfMemory;
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(lsa::sim_scans_kernel, dim3(n_poses < 65535 ? n_poses : 65535), dim3(256), 0, c->stream, S, d_prob, d_poses,
+        hipLaunchKernelGGL(lsa::sim_scans_kernel, dim3(n_poses < 65535 ? n_poses : 65535), dim3(256), 0, c->stream, S, f->d_cls, nty, d_poses,
                            n_poses, (float*)nullptr, (uint8_t*)nullptr, d_sx, d_sy);
         hipLaunchKernelGGL(lsa::iota_scaled_kernel, dim3((n_poses + 256) / 256), dim3(256), 0, c->stream, n_poses + 1, n_beams, d_off);
         lsa::P2PParam P = {o.max_iterations, o.threshold_dist, o.threshold_ang, o.alfa, o.smallest_threshold_dist};
