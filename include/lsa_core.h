@@ -256,6 +256,13 @@ int lsa_pf_roughen(lsa_ctx* c, int n, double K, const float* d_normals, float* d
  * fov 4.712388981, min_angle 3 * -0.7853981635, max_range 30 (VPmap.h:12-31) */
 int lsa_simulate_scans(lsa_field* f, const float* d_prob, const float* d_poses, int n_poses, int n_beams,
                        float fov, float min_angle, float max_range, float* d_ranges, uint8_t* d_bad);
+/* CVPmap::isValidPose (src/localization/VPmap.cpp:61-81) for n poses [n][3]: d_valid[i] = 1 iff the pose's cell
+ * (CPMap::mapPosfromPoint) lies in the map, is free (prob <= free_thr; g_free_threshold 0.3, globaldef.cpp) and known
+ * (|prob - unknown_value| >= 0.01).  The filter of threadLocalization::randomPose / globalization
+ * (localization.cpp:88-103, 483-540).  Deviation: the reference tests the index with `>` against the size and reads
+ * outside the map for such poses; here they are invalid. */
+int lsa_valid_poses(lsa_field* f, const float* d_prob, const float* d_poses, int n_poses, float free_thr, float unknown_value,
+                    uint8_t* d_valid);
 /* CVPmap::obsLikelyhood2 (VPmap.cpp:454-483): beam-model score of every pose against one observed scan */
 int lsa_beam_model_scores(lsa_field* f, const float* d_prob, const float* d_poses, int n_poses, const float* d_obs_r,
                           const uint8_t* d_obs_bad, int n_beams, float fov, float min_angle, float max_range,

@@ -105,6 +105,7 @@ def lib():
     L.lsa_pf_predict.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.lsa_pf_roughen.argtypes = [vp, C.c_int, C.c_double, vp, vp]
     L.lsa_simulate_scans.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp]
+    L.lsa_valid_poses.argtypes = [vp, vp, vp, C.c_int, C.c_float, C.c_float, vp]
     L.lsa_beam_model_scores.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, vp]
     L.lsa_plicp_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.lsa_plicp_host.argtypes = [vp, vp, vp, vp, vp]
@@ -445,6 +446,11 @@ def simulate_scans(field, d_prob, d_poses, P, n_beams, d_ranges, d_bad, fov=SIM_
                    max_range=SIM_MAX_RANGE):
     check(lib().lsa_simulate_scans(field.h, _dp(d_prob), _dp(d_poses), P, n_beams, fov, min_angle, max_range,
                                    _dp(d_ranges), _dp(d_bad)), "lsa_simulate_scans")
+
+
+def valid_poses(field, d_prob, d_poses, P, d_valid, free_thr=0.3, unknown=0.5):
+    """CVPmap::isValidPose for P poses: d_valid (uint8) = 1 where the pose's cell is inside the map, free and known."""
+    check(lib().lsa_valid_poses(field.h, _dp(d_prob), _dp(d_poses), P, free_thr, unknown, _dp(d_valid)), "lsa_valid_poses")
 
 
 def beam_model_scores(field, d_prob, d_poses, P, d_obs_r, d_obs_bad, n_beams, d_score, fov=SIM_FOV,

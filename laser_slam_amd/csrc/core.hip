@@ -1111,6 +1111,21 @@ int lsa_simulate_scans(lsa_field* f, const float* d_prob, const float* d_poses, 
     return LSA_OK;
 }
 
+// CVPmap::isValidPose (VPmap.cpp:61-81) for a list of poses: the filter of randomPose / globalization
+int lsa_valid_poses(lsa_field* f, const float* d_prob, const float* d_poses, int n_poses, float free_thr, float unknown_value,
+                    uint8_t* d_valid)
+{
+    if (!f || !d_prob || !d_poses || !d_valid) return fail(LSA_E_ARG, "null argument");
+    if (n_poses <= 0) return LSA_OK;
+    HIP_TRY(hipSetDevice(f->c->device));
+    lsa::SimParam S = sim_param(f, 2, 1.0f, 0.0f, 1.0f);
+    S.unknown = unknown_value;
+    hipLaunchKernelGGL(lsa::valid_poses_kernel, dim3(blocks_for((size_t)n_poses, 256)), dim3(256), 0, f->c->stream, S, d_prob, d_poses,
+                       n_poses, free_thr, d_valid);
+    HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+
 int lsa_beam_model_scores(lsa_field* f, const float* d_prob, const float* d_poses, int n_poses, const float* d_obs_r,
                           const uint8_t* d_obs_bad, int n_beams, float fov, float min_angle, float max_range, float* d_score)
 {

@@ -117,6 +117,24 @@ __device__ __forceinline__ void sim_ray(const SimParam& S, const uint32_t* __res
     }
 }
 
+// CVPmap::isValidPose (VPmap.cpp:61-81): the pose's cell (CPMap::mapPosfromPoint) must be free (prob <= free_thr) and
+// known (|prob - unknown| >= 0.01).  The reference tests the cell index with `>` against the size and not at all against
+// 0, i.e. it reads outside the map for such poses; here every pose outside the map is invalid.
+__global__ __launch_bounds__(256) void valid_poses_kernel(SimParam S, const float* __restrict__ prob, const float* __restrict__ poses,
+                                                          int P, float free_thr, uint8_t* __restrict__ valid)
+{
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const float px = poses[3 * (size_t)p], py = poses[3 * (size_t)p + 1];
+        const int x = grid_cell1(px, S.off_x, S.center_x, S.res), y = grid_cell1(py, S.off_y, S.center_y, S.res);   // mapPosfromPoint, PMap.cpp:100-117
+        bool ok = x >= 0 && y >= 0 && x < S.size_x && y < S.size_y;
+        if (ok) {
+            const float v = prob[(size_t)x * S.size_y + y];
+            ok = !(v > free_thr) && !(fabs((double)(v - S.unknown)) < (double)0.01f);
+        }
+        valid[p] = ok ? 1 : 0;
+    }
+}
+
 // bearing of beam i at pose angle th (:184-219): A_0 = -(float)(min_angle) - normAngle(th, -pi'), A_i = A_0 - i AA
 __device__ __forceinline__ double sim_beam_angle(const SimParam& S, float th, int i)
 {

@@ -138,6 +138,8 @@ void orc_beam_model(const float* prob, int sx, int sy, int cx, int cy, float off
 void orc_icp_goodness(const float* prob, int sx, int sy, int cx, int cy, float offx, float offy, double res,
                       const float* poses, int P, const float* obs_x, const float* obs_y, int n_beams,
                       float fov, float min_angle, float max_range, float* weight, float* rel);
+int orc_valid_pose(const float* prob, int size_x, int size_y, int center_x, int center_y, float off_x, float off_y, double res,
+                   float px, float py, float free_thr, float unknown_value);
 void orc_topk(const float* score, int n, int k, int* index);
 void orc_pf_estimate(const float* poses, const float* score, const int* index, int k,
                      double mean[3], double* mean_weight, double* mean_dis);

@@ -105,6 +105,22 @@ void orc_beam_model(const float* prob, int sx, int sy, int cx, int cy, float off
 }
 
 /* topK, localization.cpp:126-149: the k largest, equal scores in index order */
+/* CVPmap::isValidPose, VPmap.cpp:61-81 (cell by CPMap::mapPosfromPoint, PMap.cpp:100-117); poses outside the map are
+ * invalid (the reference reads out of bounds there) */
+int orc_valid_pose(const float* prob, int size_x, int size_y, int center_x, int center_y, float off_x, float off_y, double res,
+                   float px, float py, float free_thr, float unknown_value)
+{
+    const float tail = 0.0005f;
+    const double dx = px, dy = py;
+    const int x = dx < off_x ? (int)(center_x + ((dx - off_x + tail) / res) - 1) : (int)(center_x + ((dx - off_x + tail) / res));
+    const int y = dy < off_y ? (int)(center_y + ((dy - off_y + tail) / res) - 1) : (int)(center_y + ((dy - off_y + tail) / res));
+    if (x < 0 || y < 0 || x >= size_x || y >= size_y) return 0;
+    const float v = prob[(size_t)x * size_y + y];
+    if (v > free_thr) return 0;
+    if (fabs(v - unknown_value) < 0.01) return 0;
+    return 1;
+}
+
 void orc_topk(const float* score, int n, int k, int* index)
 {
     char* used = (char*)calloc(n, 1);

@@ -281,6 +281,14 @@ def systematic_resample(w, u0, n_out):
     return parent
 
 
+def valid_pose(prob, geom, px, py, free_thr=0.3, unknown=0.5):
+    """CVPmap::isValidPose; geom = (size_x, size_y, center_x, center_y, off_x, off_y, res)."""
+    prob = np.ascontiguousarray(prob, f32)
+    sx, sy, cx, cy, ox, oy, res = geom
+    return _orc().orc_valid_pose(_p(prob), int(sx), int(sy), int(cx), int(cy), C.c_float(ox), C.c_float(oy), C.c_double(res),
+                                 C.c_float(px), C.c_float(py), C.c_float(free_thr), C.c_float(unknown))
+
+
 def standard_resample(w, u):
     """Standard_resampler + copy_resamples: parents in ascending order, and the uniforms left over (0 if fine)."""
     if Oracle._L is None:

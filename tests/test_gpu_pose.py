@@ -271,3 +271,33 @@ def test_icp_goodness_scorer(world):
     assert ok.sum() >= P // 2 and np.allclose(rel_g[ok], rel_o[ok], atol=2e-3)
     assert w_g[0] > 0.95 and np.abs(rel_g[0]).max() < 5e-3          # the true pose: everything pairs, no correction
     assert w_g[-1] < w_g[0]
+
+
+def test_valid_poses_and_global_search(world):
+    """CVPmap::isValidPose for a pose list against the oracle, and the reference's global localisation pipeline
+    (valid candidates -> scorer -> topK -> best pose, localization.cpp:483-540) recovering a known pose."""
+    import torch
+    from laser_slam_amd import capi, localization
+    import oracle_lib as ol
+    ctx, fld, prob, res = world["ctx"], world["fld"], world["prob"], world["res"]
+    sx, sy = prob.shape
+    geom = (sx, sy, 0, 0, 0.0, 0.0, res)
+    rng = np.random.default_rng(21)
+    P = 4000
+    poses = localization.random_poses(P, sx * res * 1.1, sy * res * 1.1, rng)        # some fall outside the map
+    poses[:50, :2] -= 1.0                                                            # and some at negative coordinates
+    d_prob = torch.from_numpy(prob).cuda(); d_poses = torch.from_numpy(poses).cuda()
+    d_valid = torch.zeros(P, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    capi.valid_poses(fld, d_prob, d_poses, P, d_valid); ctx.sync()
+    want = np.array([ol.valid_pose(prob, geom, float(p[0]), float(p[1])) for p in poses], np.uint8)
+    assert np.array_equal(d_valid.cpu().numpy(), want)
+    assert 0.2 < want.mean() < 0.95
+    # global search with the beam model: the observation is the virtual scan of one valid candidate
+    n = 181
+    true_i = int(np.nonzero(want)[0][7])
+    r = torch.zeros(1, n, device="cuda"); bad = torch.zeros(1, n, dtype=torch.uint8, device="cuda")
+    capi.simulate_scans(fld, d_prob, d_poses[true_i:true_i + 1].contiguous(), 1, n, r, bad); ctx.sync()
+    best, idx, sc = localization.global_search(fld, d_prob, d_poses, dict(r=r[0].contiguous(), bad=bad[0].contiguous()), scorer="beam", k=10)
+    assert int(idx[0]) == true_i and np.array_equal(best, poses[true_i])
+    assert np.all(np.diff(sc) <= 0) and want[idx].all()
