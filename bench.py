@@ -178,7 +178,7 @@ def main():
         out["roofline"]["valu_busy_frac"] = pmc_valu_busy(args.matcher)
         if args.extras:
             out["extras"] = extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p)
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:                   # (rank 0 at N = 1 only: the other ranks would wait for it)
             out["cpu_baseline"] = cpu_baseline(raw, args.cpu_pairs, 1 if which == capi.MATCH_ICP else 0)
     if dist is not None:
         dist.barrier()
