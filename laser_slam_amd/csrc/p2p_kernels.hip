@@ -12,10 +12,12 @@
 //           (1e-6) both thresholds shrink by ALFA until thresholdDist < smallestThresholdDist.
 //   goodness = paired fraction of the second map (what CICPWarpper::ICPMatch returns).
 //
-// One 256-thread workgroup per problem; the first map is streamed through LDS in tiles and
-// every lane scans it for its own points (brute force: the clouds are a few hundred to a
-// few thousand points, src/zhicp/data/*.log).  Sums use a fixed-order tree in double, so the
-// result does not depend on scheduling.
+// One 256-thread workgroup per problem.  A first map of up to 2048 points is sorted by x once (bitonic, in LDS)
+// and every lane searches it for its own points outwards from its x: a point further away in x alone than the
+// best distance so far (at first: the pairing threshold) cannot be the neighbour, so the search sees a slab of
+// the map instead of all of it - exactly the brute-force result, ties to the smaller original index included.
+// Larger first maps are streamed through LDS in tiles and scanned whole.  Sums use a fixed-order tree in double,
+// so the result does not depend on scheduling.
 #include "lsa_device.h"
 
 namespace lsa {
@@ -46,10 +48,33 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
     double* __restrict__ out, int n_cur_shared /* cur_off == nullptr: every problem aligns the same second map */)
 {
     __shared__ float2 tile[P2P_TILE];
+    __shared__ uint16_t sid[P2P_TILE];                       // original index of the sorted first-map points
     __shared__ double sh[8];
     const int tid = threadIdx.x;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const int r0 = ref_off[b], n1 = ref_off[b + 1] - r0;
+        const bool sorted = n1 > 0 && n1 <= P2P_TILE;
+        if (sorted) {                                        // first map by (x, original index), padded with +inf to a power of two
+            int npad = 1;
+            while (npad < n1) npad <<= 1;
+            __syncthreads();
+            for (int k = tid; k < npad; k += P2P_THREADS) {
+                tile[k] = k < n1 ? make_float2(ref_x[r0 + k], ref_y[r0 + k]) : make_float2(__int_as_float(0x7f800000), 0.0f);
+                sid[k] = (uint16_t)k;
+            }
+            __syncthreads();
+            for (int kk = 2; kk <= npad; kk <<= 1)
+                for (int j = kk >> 1; j > 0; j >>= 1) {
+                    for (int t = tid; t < (npad >> 1); t += P2P_THREADS) {
+                        const int i0 = ((t / j) * 2 * j) + (t % j), i1 = i0 + j;
+                        const float2 a = tile[i0], c = tile[i1];
+                        const uint16_t ia = sid[i0], ic = sid[i1];
+                        const bool a_gt = a.x > c.x || (a.x == c.x && ia > ic);
+                        if (a_gt == ((i0 & kk) == 0)) { tile[i0] = c; tile[i1] = a; sid[i0] = ic; sid[i1] = ia; }
+                    }
+                    __syncthreads();
+                }
+        }
         const int c0 = cur_off ? cur_off[b] : 0, n2 = cur_off ? cur_off[b + 1] - c0 : n_cur_shared;
         int* const match_b = match + (cur_off ? (size_t)c0 : (size_t)b * n_cur_shared);       // per-problem scratch
         double qx = init_pose[3 * b], qy = init_pose[3 * b + 1], qphi = init_pose[3 * b + 2];
@@ -71,6 +96,35 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
                     gx = (float)qx + cphi * px - sphi * py;
                     gy = (float)qy + sphi * px + cphi * py;
                 }
+                float lim2 = 0.0f;
+                if (i < n2) {
+                    const float pivot = sqrtf((gx - (float)qx) * (gx - (float)qx) + (gy - (float)qy) * (gy - (float)qy));
+                    const float lim = thr_d + thr_a * pivot;
+                    lim2 = lim * lim;
+                }
+                if (sorted) {
+                    if (i < n2) {
+                        best = lim2;                            // only closer points can be paired
+                        int lo = 0, hi = n1;
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (tile[mid].x < gx) lo = mid + 1; else hi = mid; }
+                        for (int k = lo; k < n1; ++k) {         // x >= gx, ascending
+                            const float ex = gx - tile[k].x, ex2 = ex * ex;
+                            if (ex2 > best) break;
+                            const float ey = gy - tile[k].y;
+                            const float d = ex2 + ey * ey;
+                            const int oj = sid[k];
+                            if (d < best || (d == best && bj >= 0 && oj < bj)) { best = d; bj = oj; }
+                        }
+                        for (int k = lo - 1; k >= 0; --k) {     // x < gx, descending
+                            const float ex = gx - tile[k].x, ex2 = ex * ex;
+                            if (ex2 > best) break;
+                            const float ey = gy - tile[k].y;
+                            const float d = ex2 + ey * ey;
+                            const int oj = sid[k];
+                            if (d < best || (d == best && bj >= 0 && oj < bj)) { best = d; bj = oj; }
+                        }
+                    }
+                } else
                 for (int t0 = 0; t0 < n1; t0 += P2P_TILE) {
                     const int tn = n1 - t0 < P2P_TILE ? n1 - t0 : P2P_TILE;
                     __syncthreads();
@@ -85,9 +139,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
                 }
                 int mj = -1;
                 if (i < n2 && bj >= 0) {
-                    const float pivot = sqrtf((gx - (float)qx) * (gx - (float)qx) + (gy - (float)qy) * (gy - (float)qy));
-                    const float lim = thr_d + thr_a * pivot;
-                    if (best < lim * lim) {
+                    if (best < lim2) {
                         mj = bj;
                         // the first-map point keeps its closest partner (ties: smaller index)
                         atomicMin(&owner[r0 + bj], ((unsigned long long)f2u(best) << 32) | (unsigned)i);
