@@ -10,6 +10,7 @@
 #include <climits>
 #include <cstdlib>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "match_kernels.hip"
@@ -1323,8 +1324,14 @@ int lsa_plicp_batch(lsa_ctx* c, int B, const float* d_r, const int32_t* d_ref_id
         HIP_TRY(hipMalloc((void**)&c->d_trig, sizeof(double) * t.size()));
         HIP_TRY(hipMemcpy(c->d_trig, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
     }
-    static bool once = false;
-    if (!once) { once = true; HIP_TRY(hipFuncSetAttribute((const void*)lsa::plicp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
+    {   // more than 64 KB of dynamic LDS: opt in once per device (contexts of several devices may live in one process)
+        static std::atomic<unsigned long long> done{0};
+        const unsigned long long bit = 1ull << (c->device & 63);
+        if (!(done.load(std::memory_order_acquire) & bit)) {
+            HIP_TRY(hipFuncSetAttribute((const void*)lsa::plicp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            done.fetch_or(bit, std::memory_order_release);
+        }
+    }
     hipLaunchKernelGGL(lsa::plicp_kernel, dim3(B), dim3(lsa::PLICP_THREADS), lsa::plicp_lds_bytes(P.n), c->stream, P, B, d_r,
                        d_ref_idx, d_act_idx, c->d_trig, d_out8);
     HIP_TRY(hipGetLastError());
