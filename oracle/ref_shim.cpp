@@ -20,6 +20,7 @@
 #include "point.h"
 #include <cstring>
 #include <cstdio>
+#include <vector>
 
 namespace {
 
@@ -118,6 +119,27 @@ int ref_read_carmen(void* hv, const char* filename, const char* tag)
     CPolarMatch* pm = ((Handle*)hv)->pm;
     if (!pm->readCarmon(std::string(filename), std::string(tag))) return 0;
     return (int)pm->m_SickScans.size();
+}
+
+// readRawSeed (ZHPolar_Match.cpp:123-170): "timestamp,n,offset,r_1,..,r_n" [m]; number of scans read.
+int ref_read_rawseed(void* hv, const char* filename)
+{
+    CPolarMatch* pm = ((Handle*)hv)->pm;
+    if (!pm->readRawSeed(std::string(filename))) return 0;
+    return (int)pm->m_SickScans.size();
+}
+
+// construct511Data (ZHPolar_Match.cpp:649-667): one "timestamp n r_1 .. r_n" [m] line; 1 = parsed.
+int ref_construct511(void* hv, const char* line, float* r, float* x, float* y, int* bad)
+{
+    CPolarMatch* pm = ((Handle*)hv)->pm;
+    const int n = pm->m_pParam->pm_l_points;
+    PMScan scan(n);
+    std::vector<char> buf(line, line + strlen(line) + 1);
+    if (!pm->construct511Data(buf.data(), scan)) return 0;
+    memcpy(r, scan.r, sizeof(float) * n); memcpy(x, scan.x, sizeof(float) * n); memcpy(y, scan.y, sizeof(float) * n);
+    memcpy(bad, scan.bad, sizeof(int) * n);
+    return 1;
 }
 
 // Copy scan k of the reader's record: r[N], x[N], y[N], bad[N], pose[3].

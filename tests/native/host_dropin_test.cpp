@@ -140,8 +140,52 @@ static int run_pmap(const char* in, const char* out)
     return 0;
 }
 
+// readers rawseed|511 <laser> <file> <out.bin>: out = int32 count, then per record float r[n], x[n], y[n], int32 bad[n]
+// (511: every line gives a record preceded by an int32 "parsed" flag; refused lines carry zeros)
+static int run_readers(const char* kind, const char* laser, const char* file, const char* out)
+{
+    CPolarMatch m(laser);
+    const int n = m.m_pParam->pm_l_points;
+    FILE* g = fopen(out, "wb");
+    if (!g) return 2;
+    if (!strcmp(kind, "rawseed")) {
+        if (!m.readRawSeed(file)) return 3;
+        int S = (int)m.m_SickScans.size();
+        fwrite(&S, 4, 1, g);
+        for (int k = 0; k < S; ++k) {
+            PMScan* s = m.m_SickScans[k];
+            fwrite(s->r, 4, n, g); fwrite(s->x, 4, n, g); fwrite(s->y, 4, n, g); fwrite(s->bad, 4, n, g);
+        }
+    } else {
+        FILE* f = fopen(file, "r");
+        if (!f) return 3;
+        std::vector<char> line(1 << 16);
+        std::vector<std::vector<char> > recs;
+        int S = 0;
+        long pos = ftell(g);
+        fwrite(&S, 4, 1, g);
+        while (fgets(line.data(), (int)line.size(), f)) {
+            size_t L = strlen(line.data());
+            while (L && (line[L - 1] == '\n' || line[L - 1] == '\r')) line[--L] = 0;
+            if (!L) continue;
+            PMScan scan(n);
+            for (int i = 0; i < n; ++i) { scan.r[i] = scan.x[i] = scan.y[i] = 0; scan.bad[i] = 0; }
+            int ok = m.construct511Data(line.data(), scan) ? 1 : 0;
+            if (!ok) for (int i = 0; i < n; ++i) { scan.r[i] = scan.x[i] = scan.y[i] = 0; scan.bad[i] = 0; }
+            fwrite(&ok, 4, 1, g);
+            fwrite(scan.r, 4, n, g); fwrite(scan.x, 4, n, g); fwrite(scan.y, 4, n, g); fwrite(scan.bad, 4, n, g);
+            ++S;
+        }
+        fclose(f);
+        fseek(g, pos, SEEK_SET); fwrite(&S, 4, 1, g);
+    }
+    fclose(g);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc >= 6 && !strcmp(argv[1], "readers")) return run_readers(argv[2], argv[3], argv[4], argv[5]);
     if (argc >= 6 && !strcmp(argv[1], "match")) return run_match(argv[2], argv[3], argv[4], atoi(argv[5]));
     if (argc >= 4 && !strcmp(argv[1], "pmap")) return run_pmap(argv[2], argv[3]);
     if (argc >= 7 && !strcmp(argv[1], "runlog")) {       // runlog <our|flirt> <laser> <log> <out> <n>
