@@ -506,3 +506,60 @@ def test_full_size_grid_checksum(torch_mod):
     assert sum1.sum(dtype=np.float64) > hit1.sum(dtype=np.float64)
     assert cx.min() >= 0 and cx.max() < 4096
     g1.close(); g2.close(); ctx.close()
+
+
+def test_slam_loop_mit_4096(torch_mod):
+    """BASELINE config 5 in small: the head of mit-cscail.log through the whole loop - FMatch's matcher (pm_icp) on
+    consecutive scans, poses chained in double like OrientedPoint2D::oplus, every scan's end points put into a 4096^2
+    counting grid at 5 cm at the chained pose - device against the same loop run with the CPU oracle.  Poses and
+    relative motions must carry the same bits, hence the end points, hence the three grid layers."""
+    torch = torch_mod
+    from laser_slam_amd import capi
+    from oracle_lib import Oracle, OraclePMap
+    name = "mit"
+    g = load(name)
+    ctx, _ = make_ctx(name, g)
+    laser = SETS[name][0]
+    gp = golden_param(g)
+    o = Oracle(laser); o.set_fimin_maxrange(np.float32(gp["fi_min"]), int(gp["max_range"]))
+    r, bad, seg = g["pre_r"], g["pre_bad"], g["pre_seg"]
+    S, n = r.shape
+    ref_idx = np.arange(S - 1); act_idx = ref_idx + 1
+    out = run_match(torch, ctx, 1, r, bad, seg, ref_idx, act_idx, want_err=False)
+    rel_o = np.zeros((S - 1, 3), np.float32); st_o = np.zeros(S - 1, np.int32)
+    for k in range(S - 1):
+        st_o[k], rel_o[k], _, _ = o.match(1, (r[k], bad[k], seg[k]), (r[k + 1], bad[k + 1], seg[k + 1]))
+    assert np.array_equal(out["status"], st_o) and same_bits(out["pose"][st_o == 0], rel_o[st_o == 0])
+
+    def chain(rel, status):                     # global poses (m, m, rad) from relative ones (cm, cm, rad); failed pairs: no motion
+        P = np.zeros((S, 3), np.float64)
+        for k in range(S - 1):
+            dx, dy, dth = (rel[k, 0] * 0.01, rel[k, 1] * 0.01, rel[k, 2]) if status[k] == 0 else (0.0, 0.0, 0.0)
+            c, s_ = np.cos(P[k, 2]), np.sin(P[k, 2])
+            P[k + 1] = [P[k, 0] + c * dx - s_ * dy, P[k, 1] + s_ * dx + c * dy, P[k, 2] + dth]
+        return P
+
+    def endpoints(P):
+        fi = g["tab_fi"].astype(np.float64)
+        ok = (bad == 0)
+        rr = np.where(ok, r, 0.0).astype(np.float64) * 0.01
+        gx = (P[:, 0:1] + rr * np.cos(P[:, 2:3] + fi[None])).astype(np.float32)
+        gy = (P[:, 1:2] + rr * np.sin(P[:, 2:3] + fi[None])).astype(np.float32)
+        return gx, gy, P[:, :2].astype(np.float32)
+
+    gx_d, gy_d, rob_d = endpoints(chain(out["pose"], out["status"]))
+    gx_o, gy_o, rob_o = endpoints(chain(rel_o, st_o))
+    assert same_bits(gx_d, gx_o) and same_bits(gy_d, gy_o)
+    geom = (4096, 4096, 2048, 2048, 0.0, 0.0, 0.05)
+    grid = capi.Grid(ctx, *geom)
+    torch.cuda.synchronize()
+    grid.update_batch(S, n, dev(torch, gx_d, np.float32), dev(torch, gy_d, np.float32), dev(torch, rob_d, np.float32))
+    grid.compute_prob()
+    om = OraclePMap(*geom)
+    for k in range(S):
+        om.update(gx_o[k], gy_o[k], float(rob_o[k, 0]), float(rob_o[k, 1]))
+    om.compute()
+    for a, b in zip(grid.layers(), om.layers()):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert grid.layers()[1].sum() > 20 * S * n          # the rays really are tens of cells long
+    grid.close(); ctx.close()
