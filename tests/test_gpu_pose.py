@@ -301,3 +301,41 @@ def test_valid_poses_and_global_search(world):
     best, idx, sc = localization.global_search(fld, d_prob, d_poses, dict(r=r[0].contiguous(), bad=bad[0].contiguous()), scorer="beam", k=10)
     assert int(idx[0]) == true_i and np.array_equal(best, poses[true_i])
     assert np.all(np.diff(sc) <= 0) and want[idx].all()
+
+
+def test_full_size_filter_step_properties(world):
+    """BASELINE config 4's size: one particle-filter step over 1 000 000 particles (likelihood-field scores, best
+    pose, weights and N_eff, the reference's standard resampler with one uniform per offspring, gather, estimate of
+    the 8 best) checked through properties that do not need a second implementation at that size."""
+    torch, capi, ctx, fld = world["torch"], world["capi"], world["ctx"], world["fld"]
+    rng = np.random.default_rng(44)
+    P, n = 1000000, 361
+    ang = np.linspace(-np.pi / 2, np.pi / 2, n)
+    d_x = torch.from_numpy((3.0 * np.cos(ang)).astype(np.float32)).cuda(); d_y = torch.from_numpy((3.0 * np.sin(ang)).astype(np.float32)).cuda()
+    poses = np.stack([rng.uniform(1, 12, P), rng.uniform(1, 9, P), rng.uniform(-3, 3, P)], 1).astype(np.float32)
+    d_p = torch.from_numpy(poses).cuda()
+    d_s = torch.zeros(P, device="cuda"); torch.cuda.synchronize()
+    fld.score_poses(d_x, d_y, n, 3, d_p, P, d_s); ctx.sync()
+    sc = d_s.cpu().numpy()
+    m, i = capi.pose_argmax(ctx, d_s, P)
+    assert m == sc.max() and i == int(np.argmax(sc))                 # ties: the smaller index, like np.argmax
+    d_w = torch.zeros(P, device="cuda"); torch.cuda.synchronize()
+    s1, s2 = capi.pf_weights(ctx, d_s, P, m, d_w); ctx.sync()
+    w = d_w.cpu().numpy()
+    assert w.max() == 1.0 and abs(s1 - w.astype(np.float64).sum()) < 1e-9 * s1 and abs(s2 - (w.astype(np.float64) ** 2).sum()) < 1e-9 * s2
+    u = rng.uniform(0, 1, P)
+    d_par = torch.zeros(P, dtype=torch.int32, device="cuda"); torch.cuda.synchronize()
+    capi.pf_resample_standard(ctx, d_w, P, torch.from_numpy(u).cuda(), P, d_par); ctx.sync()
+    par = d_par.cpu().numpy()
+    assert np.all(np.diff(par) >= 0) and par.min() >= 0 and par.max() < P
+    cum = np.cumsum(w.astype(np.float64))
+    want = np.searchsorted(cum, np.sort(u) * cum[-1], side="right")
+    assert (par != want).mean() < 1e-3 and np.abs(par - want).max() <= 1
+    assert w[par].min() > 0                                          # dead particles are never drawn
+    d_new = torch.zeros(P, 3, device="cuda"); torch.cuda.synchronize()
+    capi.gather_poses(ctx, d_p, d_par, P, d_new); ctx.sync()
+    assert np.array_equal(d_new.cpu().numpy(), poses[par])
+    mean, mw, md, idx = capi.pf_estimate(ctx, d_p, d_s, P, 8)
+    order = np.lexsort((np.arange(P), -sc))[:8]                      # best first, equal scores in index order
+    assert np.array_equal(idx, order)
+    assert float(sc[par].mean()) > float(sc.mean())                  # the offspring sit on better poses
