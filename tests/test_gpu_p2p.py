@@ -117,3 +117,27 @@ def test_map_node_rasterise_cloud_icp_chain(ctx):
     assert got[5] == want[5] and got[6] == want[6]
     assert np.allclose(got[:5], want[:5], rtol=1e-9, atol=1e-9)
     assert np.abs(got[:2] - true[:2]).max() < 0.05 and abs(got[2] - true[2]) < 0.02 and got[3] > 0.5
+
+
+@pytest.mark.parametrize("name", ["fr079", "intel"])
+def test_consecutive_log_scans(ctx, name):
+    """BASELINE configs 1 / 2: CICPWarpper's ICP on consecutive scans of the shipped logs' heads (the reader's
+    Cartesian points, cm -> m, readings at the maximum range dropped), zero prior - device against the oracle."""
+    from laser_slam_amd import capi
+    from helpers import load
+    from oracle_lib import p2p_icp
+    g = load(name)
+    x, y, bad, r = g["reader_x"] * 0.01, g["reader_y"] * 0.01, g["raw_bad"], g["raw_r"]
+    mx = float(g["param"][list(g["param_keys"]).index("max_range")]) if "max_range" in list(g["param_keys"]) else 5000.0
+    done = 0
+    for k in range(0, 40):
+        a = (bad[k] == 0) & (r[k] < mx); b = (bad[k + 1] == 0) & (r[k + 1] < mx)
+        rx, ry = x[k][a].astype(np.float32), y[k][a].astype(np.float32)
+        cx, cy = x[k + 1][b].astype(np.float32), y[k + 1][b].astype(np.float32)
+        got = capi.p2p_icp_host(ctx, rx, ry, cx, cy, (0, 0, 0))
+        want = p2p_icp(rx, ry, cx, cy, (0, 0, 0))
+        assert got[5] == want[5] and got[6] == want[6], (k, got[:7], want[:7])
+        assert np.allclose(got[:5], want[:5], rtol=1e-9, atol=1e-9)
+        assert np.allclose(got[7:13], want[7:13], rtol=1e-6, atol=1e-12)
+        done += got[3] > 0.5
+    assert done >= 30                                   # consecutive scans pair up
