@@ -164,6 +164,45 @@ __device__ bool plicp_quartic_largest_root(double a3, double a2, double a1, doub
     return isfinite(l) && fabs(p) <= 1e-6 * (1 + m * (1 + fabs(l)) * (1 + l * l));
 }
 
+// The multiplier of the closed-form step is the largest real root of det(S + l I)^2 = |(adj S + l I) h|^2, i.e. the
+// root right of -s_min (s_min: S's smaller eigenvalue) of the secular equation |(S + l I)^-1 h| = 1.  Newton's
+// iteration on the quartic from a bound on all its roots takes about sixty dependent double-precision steps (the
+// distance to the root cluster shrinks by 3/4 per step) - a quarter of this kernel's time; on
+//     psi(l) = A(l) / sqrt(B(l)) - 1,   A = l^2 + trS l + detS,   B = hh l^2 + 2 hah l + aa,
+// which is concave and increasing right of -s_min (Reinsch), it converges from l = 0 in a handful, monotonically
+// from the left after at most one step.  Anything unusual (S not positive definite, a step leaving the domain
+// twice, no convergence) hands over to the quartic iteration; the result is accepted by the same residual test.
+__device__ bool plicp_gpm_multiplier(double trS, double detS, double hh, double hah, double aa, double& root)
+{
+    const double a3 = 2 * trS, a2 = trS * trS + 2 * detS - hh, a1 = 2 * trS * detS - 2 * hah, a0 = detS * detS - aa;
+#ifndef LSA_PLICP_DIAG_QUARTIC
+    const double disc = trS * trS * 0.25 - detS;
+    const double lo = -(trS * 0.5 - sqrt(disc > 0 ? disc : 0));               // -s_min
+    if (lo < 0) {
+        double l = 0;
+        bool done = false;
+        for (int it = 0; it < 40 && !done; ++it) {
+            const double A = (l + trS) * l + detS, Bv = (hh * l + 2 * hah) * l + aa;
+            if (!(A > 0 && Bv > 0)) break;
+            const double sb = sqrt(Bv), psi = A / sb - 1;
+            const double dpsi = ((2 * l + trS) - A * (hh * l + hah) / Bv) / sb;
+            if (!(dpsi > 0)) break;
+            double nl = l - psi / dpsi;
+            if (!(nl > lo)) nl = 0.5 * (l + lo);                              // stay right of -s_min
+            done = fabs(nl - l) <= 1e-15 * fabs(nl) + 4e-16 * trS;      // (psi is known to about 1e-16, i.e. l to 1e-16 trS)
+            l = nl;
+        }
+        if (done) {
+            double m = fabs(a3);
+            m = fabs(a2) > m ? fabs(a2) : m; m = fabs(a1) > m ? fabs(a1) : m; m = fabs(a0) > m ? fabs(a0) : m;
+            const double p = (((l + a3) * l + a2) * l + a1) * l + a0;
+            if (isfinite(l) && fabs(p) <= 1e-6 * (1 + m * (1 + fabs(l)) * (1 + l * l))) { root = l; return true; }
+        }
+    }
+#endif
+    return plicp_quartic_largest_root(a3, a2, a1, a0, root);
+}
+
 // one icp_loop from q0; returns ok, x_new, total error, kept correspondences, iterations (all uniform)
 __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double q0[3], double x_new[3], double& total_error,
                            int& nvalid, int& iterations)
@@ -399,7 +438,11 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
                 const double ah0 = S11 * h0 - S01 * h1, ah1 = -S10 * h0 + S00 * h1;
                 const double hh = h0 * h0 + h1 * h1, hah = h0 * ah0 + h1 * ah1, aa = ah0 * ah0 + ah1 * ah1;
                 double l;
-                solved = plicp_quartic_largest_root(2 * trS, trS * trS + 2 * detS - hh, 2 * trS * detS - 2 * hah, detS * detS - aa, l);
+#ifdef LSA_PLICP_DIAG_L0                 // diagnostics (wrong poses): what the multiplier costs
+                l = 0; solved = hh + hah + aa == hh + hah + aa;
+#else
+                solved = plicp_gpm_multiplier(trS, detS, hh, hah, aa, l);
+#endif
                 if (solved) {
                     const double det = l * l + trS * l + detS;
                     solved = fabs(det) > 1e-300;
