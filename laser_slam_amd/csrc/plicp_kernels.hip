@@ -420,6 +420,7 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
         }
         plicp_block_sums<14>(s, L.red);
         PSTAMP(3);
+        // (every lane works the same step out; letting one wave do it and publish the result was measured: no gain)
         bool solved = nvalid >= 2;
         if (solved) {
             const double M00 = s[0], M01 = s[1], M02 = s[2], M03 = s[3], M11 = s[4], M12 = s[5], M13 = s[6], M22 = s[7], M23 = s[8], M33 = s[9];
