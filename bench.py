@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=32768, help="scan pairs per step per GPU")
+    ap.add_argument("--pairs", type=int, default=1 << 20, help="scan pairs per step per GPU (SURVEY 8(d) batch sizes: 1 .. 2^20)")
     ap.add_argument("--matcher", default="icp", choices=["icp", "psm"])
     ap.add_argument("--cpu-pairs", type=int, default=400)
     ap.add_argument("--no-cpu", action="store_true")
