@@ -10,8 +10,8 @@ def norm(n):
 
 
 stats, fetch, write, sq, bprof, bdef = sys.argv[1:7]
-out = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, `python3 bench.py --steps 1 --warmup 0 "
-                "--no-cpu --extras` (32768 pairs per matcher launch, 2048 scans per grid launch). Values are raw counter KB per "
+out = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, `python3 bench.py --pairs 32768 --steps 1 "
+                "--warmup 0 --no-cpu --extras` (32768 pairs per matcher launch, 2048 scans per grid launch). Values are raw counter KB per "
                 "launch; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide streaming reads by 2x (bench.py doubles it), "
                 "WRITE_SIZE is exact. Calibration on preprocess_kernel (known 6.92 MB read, 12.1 MB written): raw FETCH 4.5 MB "
                 "(x1.5), WRITE 12.2 MB (x1.00). icp_kernel WRITE is scratch (register spill) traffic: the algorithmic output is "
@@ -35,7 +35,7 @@ for r in csv.DictReader(open(f)):
     if k.startswith("lsa::"):
         e = acc[k][r["Counter_Name"]]; e[0] += 1; e[1] += float(r["Counter_Value"])
 sqo = {k: {c: v[1] / v[0] for c, v in d.items()} for k, d in acc.items()}
-sqo["_note"] = ("rocprofv3 --pmc SQ_* GRBM_GUI_ACTIVE, `python3 bench.py --steps 1 --warmup 0 --no-cpu --extras`, averages per launch "
+sqo["_note"] = ("rocprofv3 --pmc SQ_* GRBM_GUI_ACTIVE, `python3 bench.py --pairs 32768 --steps 1 --warmup 0 --no-cpu --extras`, averages per launch "
                 "(32768 pairs per matcher launch). SQ cycle counters are in quad-cycles (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is "
                 "summed over the 8 XCDs.")
 json.dump(sqo, open("profiles/r01_pmc_sq_counters.json", "w"), indent=1)
