@@ -152,6 +152,7 @@ def test_cpmap_dropin_queue(exe, tmp_path):
     assert np.array_equal(lay[0], reps * z["hit"].astype(np.float32))
     assert np.array_equal(lay[1], reps * z["sum"].astype(np.float32))
     assert same_bits(lay[2], z["prob"])
+    print(res.stderr.strip().splitlines()[-1])               # the per-scan signature's rate, host buffers in
 
 
 def test_text_readers_vs_reference_fixtures(exe, tmp_path):
