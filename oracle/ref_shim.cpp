@@ -129,6 +129,14 @@ int ref_read_rawseed(void* hv, const char* filename)
     return (int)pm->m_SickScans.size();
 }
 
+// readSICK (ZHPolar_Match.cpp:291-331): "tag n r_1 .. r_n" [m], n <= points; number of scans read.
+int ref_read_sick(void* hv, const char* filename)
+{
+    CPolarMatch* pm = ((Handle*)hv)->pm;
+    if (!pm->readSICK(std::string(filename))) return 0;
+    return (int)pm->m_SickScans.size();
+}
+
 // construct511Data (ZHPolar_Match.cpp:649-667): one "timestamp n r_1 .. r_n" [m] line; 1 = parsed.
 int ref_construct511(void* hv, const char* line, float* r, float* x, float* y, int* bad)
 {

@@ -53,5 +53,20 @@ for k in range(6):
     ok5.append(ok); r5.append(a); x5.append(b); y5.append(c); b5.append(d)
 open(os.path.join(HERE, "readers_511.txt"), "w").write("\n".join(lines5) + "\n")
 out.update(t511_ok=np.array(ok5, i32), t511_r=np.stack(r5), t511_x=np.stack(x5), t511_y=np.stack(y5), t511_bad=np.stack(b5))
+# SICK text: LMS511 (361 beams), "tag n r_1 .. r_n"; every record is complete (a shorter one would keep the previous
+# record's tail - and, in the first record, uninitialised memory - in the reference)
+refs = Ref("LMS511")
+lines_s = []
+for k in range(5):
+    r = ranges(n5)
+    lines_s.append("SICK %d %s" % (n5, " ".join("%.3f" % v for v in r)))
+open(os.path.join(HERE, "readers_sick.txt"), "w").write("\n".join(lines_s) + "\n")
+Ss = refs.L.ref_read_sick(C.c_void_p(refs.h), os.path.join(HERE, "readers_sick.txt").encode())
+assert Ss == 5
+rs = np.zeros((Ss, n5), f32); xs = np.zeros((Ss, n5), f32); ys = np.zeros((Ss, n5), f32); bs = np.zeros((Ss, n5), i32); ps = np.zeros((Ss, 3), f32)
+for k in range(Ss):
+    refs.L.ref_get_scan(C.c_void_p(refs.h), k, rs[k].ctypes.data_as(C.c_void_p), xs[k].ctypes.data_as(C.c_void_p),
+                        ys[k].ctypes.data_as(C.c_void_p), bs[k].ctypes.data_as(C.c_void_p), ps[k].ctypes.data_as(C.c_void_p))
+out.update(sick_r=rs, sick_x=xs, sick_y=ys, sick_bad=bs)
 np.savez_compressed(os.path.join(HERE, "readers.npz"), **out)
 print("rawseed scans", S, "| 511 lines parsed", ok5)

@@ -145,7 +145,7 @@ static int run_pmap(const char* in, const char* out)
     return 0;
 }
 
-// readers rawseed|511 <laser> <file> <out.bin>: out = int32 count, then per record float r[n], x[n], y[n], int32 bad[n]
+// readers rawseed|sick|511 <laser> <file> <out.bin>: out = int32 count, then per record float r[n], x[n], y[n], int32 bad[n]
 // (511: every line gives a record preceded by an int32 "parsed" flag; refused lines carry zeros)
 static int run_readers(const char* kind, const char* laser, const char* file, const char* out)
 {
@@ -153,8 +153,8 @@ static int run_readers(const char* kind, const char* laser, const char* file, co
     const int n = m.m_pParam->pm_l_points;
     FILE* g = fopen(out, "wb");
     if (!g) return 2;
-    if (!strcmp(kind, "rawseed")) {
-        if (!m.readRawSeed(file)) return 3;
+    if (!strcmp(kind, "rawseed") || !strcmp(kind, "sick")) {
+        if (!(kind[0] == 'r' ? m.readRawSeed(file) : m.readSICK(file))) return 3;
         int S = (int)m.m_SickScans.size();
         fwrite(&S, 4, 1, g);
         for (int k = 0; k < S; ++k) {

@@ -156,7 +156,7 @@ def test_cpmap_dropin_queue(exe, tmp_path):
 
 
 def test_text_readers_vs_reference_fixtures(exe, tmp_path):
-    """CPolarMatch::readRawSeed and construct511Data of the drop-in on synthetic files, against what the reference's
+    """CPolarMatch::readRawSeed, readSICK and construct511Data of the drop-in on synthetic files, against what the reference's
     own readers (compiled in place, tests/golden/make_reader_golden.py) made of the same files."""
     z = np.load(os.path.join(GOLDEN, "readers.npz"))
     out = str(tmp_path / "rs.bin")
@@ -170,6 +170,17 @@ def test_text_readers_vs_reference_fixtures(exe, tmp_path):
     rec = np.frombuffer(raw, np.float32, S * 4 * n, 4).reshape(S, 4, n)
     assert same_bits(rec[:, 0], z["rawseed_r"]) and same_bits(rec[:, 1], z["rawseed_x"]) and same_bits(rec[:, 2], z["rawseed_y"])
     assert np.array_equal(rec[:, 3].view(np.int32), z["rawseed_bad"])
+    out = str(tmp_path / "sk.bin")
+    res = subprocess.run([exe, "readers", "sick", "LMS511", os.path.join(GOLDEN, "readers_sick.txt"), out],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    raw = open(out, "rb").read()
+    S = struct.unpack_from("<i", raw, 0)[0]
+    n = z["sick_r"].shape[1]
+    assert S == z["sick_r"].shape[0]
+    rec = np.frombuffer(raw, np.float32, S * 4 * n, 4).reshape(S, 4, n)
+    assert same_bits(rec[:, 0], z["sick_r"]) and same_bits(rec[:, 1], z["sick_x"]) and same_bits(rec[:, 2], z["sick_y"])
+    assert np.array_equal(rec[:, 3].view(np.int32), z["sick_bad"])
     out = str(tmp_path / "t5.bin")
     res = subprocess.run([exe, "readers", "511", "LMS511", os.path.join(GOLDEN, "readers_511.txt"), out],
                          capture_output=True, text=True, timeout=600)
