@@ -698,7 +698,7 @@ __device__ __forceinline__ void bin_walk(uint32_t* lt, int X0, int Y0, int X1, i
         const int prev = __builtin_amdgcn_update_dpp(-2, cc, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // lane 0 / idle neighbour: -2
         const unsigned long long act = __ballot(1);
         const unsigned long long heads = __ballot(cc != prev) | ~act | 0x100000001ull;   // run starts, idle lanes, lanes 0 and 32
-        if (cc != prev || (lane & 31) == 0) {                                            // :87
+        if (cc != prev || (lane & 31) == 0) {                                            // :87  (a branch for "no two neighbours agree" was measured: slower)
             const uint32_t h = lane < 32 ? (uint32_t)heads : (uint32_t)(heads >> 32);
             atomicAdd(&lt[cc], (uint32_t)__ffs((int)((h >> 1 >> (lane & 31)) | sentinel)));   // distance to the next run start above
         }
