@@ -21,12 +21,17 @@ struct GridParam {
 };
 
 // mapPosfromPoint: the point is widened to double, offset and the 0.0005 tail stay float
+// (Cell numbers are kept within +-2^28: a point that far outside any map - or a NaN - has no defined cell in the
+//  reference either, and the walks' integer arithmetic must not overflow on it.)
 __device__ __host__ __forceinline__ int grid_cell1(float pf, float off, int center, double res)
 {
     const float tail = 0.0005f;
     const double p = (double)pf;
-    if (p < (double)off) return (int)((double)center + ((p - (double)off + (double)tail) / res) - 1.0);
-    return (int)((double)center + ((p - (double)off + (double)tail) / res));
+    double c = (double)center + ((p - (double)off + (double)tail) / res);
+    if (p < (double)off) c -= 1.0;
+    if (!(c > -268435456.0)) c = -268435456.0;
+    if (!(c < 268435456.0)) c = 268435456.0;
+    return (int)c;
 }
 
 __device__ __forceinline__ bool inb(const GridParam& G, int x, int y)

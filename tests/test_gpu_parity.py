@@ -563,3 +563,39 @@ def test_slam_loop_mit_4096(torch_mod):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert grid.layers()[1].sum() > 20 * S * n          # the rays really are tens of cells long
     grid.close(); ctx.close()
+
+
+def test_grid_survives_wild_end_points(torch_mod):
+    """End points that are not finite or astronomically far away have no defined cell in the reference (its cast of
+    the cell number overflows); the device clamps cell numbers to +-2^28 so that the walks' integer arithmetic stays
+    defined: the update must complete, sane scans beside the wild ones keep their counts, and nothing lands outside."""
+    torch = torch_mod
+    from laser_slam_amd import capi
+    from oracle_lib import OraclePMap
+    rng = np.random.default_rng(77)
+    geom = (300, 260, 150, 130, 0.0, 0.0, 0.05)
+    S, nb = 32, 200
+    rob = rng.uniform(-3, 3, (S, 2)).astype(np.float32)
+    ang = rng.uniform(0, 2 * np.pi, (S, nb)); d = rng.uniform(0.1, 6, (S, nb))
+    gx = (rob[:, :1] + d * np.cos(ang)).astype(np.float32); gy = (rob[:, 1:] + d * np.sin(ang)).astype(np.float32)
+    sane = OraclePMap(*geom)
+    for s in range(S):
+        sane.update(gx[s], gy[s], float(rob[s, 0]), float(rob[s, 1]))
+    wx, wy = gx.copy(), gy.copy()
+    wild = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 3e9, -3e9, 1e12], np.float32)
+    wx[::2, :8] = wild; wy[1::2, :8] = wild[::-1]; wx[5, 8:16] = wild; wy[5, 8:16] = wild
+    ctx = capi.Context(capi.param_preset("LMS151"))
+    grid = capi.Grid(ctx, *geom)
+    torch.cuda.synchronize()
+    grid.update_batch(S, nb, dev(torch, wx, np.float32), dev(torch, wy, np.float32), dev(torch, rob, np.float32))
+    ctx.sync()
+    hit, summ = grid.layers()[0], grid.layers()[1]
+    assert np.isfinite(hit).all() and np.isfinite(summ).all()
+    # every cell has at least the counts of the rays that were left alone
+    keep = np.ones((S, nb), bool); keep[::2, :8] = False; keep[1::2, :8] = False; keep[5, 8:16] = False
+    part = OraclePMap(*geom)
+    for s in range(S):
+        part.update(gx[s][keep[s]], gy[s][keep[s]], float(rob[s, 0]), float(rob[s, 1]))
+    assert (summ >= part.layers()[1]).all() and (hit >= part.layers()[0]).all()
+    assert summ.sum() < sane.layers()[1].sum() + S * 16 * (300 + 260)          # a wild ray adds a line across the map at most
+    grid.close(); ctx.close()
