@@ -39,6 +39,42 @@ __device__ __forceinline__ bool inb(const GridParam& G, int x, int y)
     return x >= 0 && x < G.size_x && y >= 0 && y < G.size_y;
 }
 
+// The reference's line from (sx, sy) to (ex, ey) (line.cpp:17-101: generated from the end with the smaller major
+// coordinate), entered at the first cell whose MAJOR coordinate lies inside the map and left after the last such
+// cell - a beam that ends (or a robot that stands) millions of cells outside the map costs no more than one that
+// crosses it.  A standard integer DDA (d0 = 2 dmin - len; a minor step whenever d >= 0) has taken
+// floor((2 dmin t + len) / (2 len)) minor steps before its cell t, which gives the exact state at any t.
+struct LineWalk {
+    bool x_major;
+    int major, minor, mstep, d, inc_keep, inc_step, k, k_hi, len;
+    __device__ __forceinline__ int x() const { return x_major ? major : minor; }
+    __device__ __forceinline__ int y() const { return x_major ? minor : major; }
+    __device__ __forceinline__ void step() { ++k; ++major; if (d < 0) d += inc_keep; else { minor += mstep; d += inc_step; } }
+};
+
+__device__ __forceinline__ LineWalk line_begin(const GridParam& G, int sx, int sy, int ex, int ey)
+{
+    LineWalk w;
+    const int dx = abs(ex - sx), dy = abs(ey - sy);
+    w.x_major = dy <= dx;
+    const bool from_end = w.x_major ? sx > ex : sy > ey;
+    const int len = w.x_major ? dx : dy, dmin = w.x_major ? dy : dx;
+    const int m0 = w.x_major ? (from_end ? ex : sx) : (from_end ? ey : sy);
+    const int n0 = w.x_major ? (from_end ? ey : sy) : (from_end ? ex : sx);
+    w.mstep = ((w.x_major ? ey - sy : ex - sx) * (from_end ? -1 : 1)) > 0 ? 1 : -1;
+    w.len = len; w.inc_keep = 2 * dmin; w.inc_step = 2 * (dmin - len);
+    const int size_major = w.x_major ? G.size_x : G.size_y;
+    const int t_lo = m0 < 0 ? -m0 : 0;
+    w.k_hi = size_major - 1 - m0 < len ? size_major - 1 - m0 : len;
+    w.k = t_lo;
+    int steps = 0;
+    if (t_lo > 0 && len > 0) steps = (int)((2ll * dmin * t_lo + len) / (2ll * len));
+    w.major = m0 + t_lo;
+    w.minor = n0 + w.mstep * steps;
+    w.d = (int)(2ll * dmin * (t_lo + 1) - len - 2ll * len * steps);
+    return w;
+}
+
 // One lane per beam; each lane walks its own Bresenham line.
 __global__ __launch_bounds__(256) void grid_update_kernel(
     GridParam G, int S, int n_beams, const float* __restrict__ gx, const float* __restrict__ gy,
@@ -56,30 +92,11 @@ __global__ __launch_bounds__(256) void grid_update_kernel(
         const int ey = grid_cell1(gy[t], G.off_y, G.center_y, G.res);
         if (inb(G, ex, ey)) atomicAdd(&hit[(size_t)ex * G.size_y + ey], 1u);          // :72-75
 
-        const int dx = abs(ex - sx), dy = abs(ey - sy);
-        int x, y, len, d, inc_keep, inc_step, minor_step;
-        bool x_major = dy <= dx;
-        if (x_major) {                                                                 // line.cpp:17-58
-            d = 2 * dy - dx; inc_keep = 2 * dy; inc_step = 2 * (dy - dx);
-            int flag;
-            if (sx > ex) { x = ex; y = ey; flag = -1; } else { x = sx; y = sy; flag = 1; }
-            minor_step = ((ey - sy) * flag) > 0 ? 1 : -1;
-            len = dx;
-        } else {                                                                       // line.cpp:59-101
-            d = 2 * dx - dy; inc_keep = 2 * dx; inc_step = 2 * (dx - dy);
-            int flag;
-            if (sy > ey) { y = ey; x = ex; flag = -1; } else { y = sy; x = sx; flag = 1; }
-            minor_step = ((ex - sx) * flag) > 0 ? 1 : -1;
-            len = dy;
-        }
-        for (int k = 0; k <= len; ++k) {
-            if (k > 0) {
-                if (x_major) { x++; if (d < 0) d += inc_keep; else { y += minor_step; d += inc_step; } }
-                else         { y++; if (d < 0) d += inc_keep; else { x += minor_step; d += inc_step; } }
-            }
+        for (LineWalk w = line_begin(G, sx, sy, ex, ey); w.k <= w.k_hi; w.step()) {
+            const int x = w.x(), y = w.y();
             if (inb(G, x, y)) {
                 const size_t c = (size_t)x * G.size_y + y;
-                if (k == len) atomicAdd(&hit[c], 1u);                                  // j > cnt-2, :84-86
+                if (w.k == w.len) atomicAdd(&hit[c], 1u);                              // j > cnt-2, :84-86
                 atomicAdd(&sum[c], 1u);                                                // :87
             }
         }
@@ -116,34 +133,15 @@ __global__ __launch_bounds__(256) void grid_update_tile_kernel(
                 if (tx < GRID_TILE && ty < GRID_TILE) atomicAdd(&tile[tx * GRID_TILE + ty], 1u << 16);
                 else atomicAdd(&hit[(size_t)ex * G.size_y + ey], 1u);
             }
-            const int dx = abs(ex - sx), dy = abs(ey - sy);
-            int x, y, len, d, inc_keep, inc_step, minor_step;
-            const bool x_major = dy <= dx;
-            if (x_major) {                                                            // line.cpp:17-58
-                d = 2 * dy - dx; inc_keep = 2 * dy; inc_step = 2 * (dy - dx);
-                int flag;
-                if (sx > ex) { x = ex; y = ey; flag = -1; } else { x = sx; y = sy; flag = 1; }
-                minor_step = ((ey - sy) * flag) > 0 ? 1 : -1;
-                len = dx;
-            } else {                                                                  // line.cpp:59-101
-                d = 2 * dx - dy; inc_keep = 2 * dx; inc_step = 2 * (dx - dy);
-                int flag;
-                if (sy > ey) { y = ey; x = ex; flag = -1; } else { y = sy; x = sx; flag = 1; }
-                minor_step = ((ex - sx) * flag) > 0 ? 1 : -1;
-                len = dy;
-            }
-            for (int k = 0; k <= len; ++k) {
-                if (k > 0) {
-                    if (x_major) { x++; if (d < 0) d += inc_keep; else { y += minor_step; d += inc_step; } }
-                    else         { y++; if (d < 0) d += inc_keep; else { x += minor_step; d += inc_step; } }
-                }
+            for (LineWalk w = line_begin(G, sx, sy, ex, ey); w.k <= w.k_hi; w.step()) {
+                const int x = w.x(), y = w.y();
                 if (inb(G, x, y)) {
                     const unsigned tx = (unsigned)(x - ox), ty = (unsigned)(y - oy);
-                    const uint32_t inc = (k == len ? (1u << 16) : 0u) + 1u;           // last cell: hit too (:84-87)
+                    const uint32_t inc = (w.k == w.len ? (1u << 16) : 0u) + 1u;       // last cell: hit too (:84-87)
                     if (tx < GRID_TILE && ty < GRID_TILE) atomicAdd(&tile[tx * GRID_TILE + ty], inc);
                     else {
                         const size_t c = (size_t)x * G.size_y + y;
-                        if (k == len) atomicAdd(&hit[c], 1u);
+                        if (w.k == w.len) atomicAdd(&hit[c], 1u);
                         atomicAdd(&sum[c], 1u);
                     }
                 }

@@ -598,4 +598,15 @@ def test_grid_survives_wild_end_points(torch_mod):
         part.update(gx[s][keep[s]], gy[s][keep[s]], float(rob[s, 0]), float(rob[s, 1]))
     assert (summ >= part.layers()[1]).all() and (hit >= part.layers()[0]).all()
     assert summ.sum() < sane.layers()[1].sum() + S * 16 * (300 + 260)          # a wild ray adds a line across the map at most
-    grid.close(); ctx.close()
+    # the per-scan kernels (fewer than 16 scans) enter such a line where it reaches the map instead of walking 2^28 cells
+    import time
+    g2 = capi.Grid(ctx, *geom)
+    t0 = time.time()
+    g2.update_batch(4, nb, dev(torch, wx[:4], np.float32), dev(torch, wy[:4], np.float32), dev(torch, rob[:4], np.float32))
+    ctx.sync()
+    assert time.time() - t0 < 5.0
+    part4 = OraclePMap(*geom)
+    for s in range(4):
+        part4.update(gx[s][keep[s]], gy[s][keep[s]], float(rob[s, 0]), float(rob[s, 1]))
+    assert (g2.layers()[1] >= part4.layers()[1]).all() and (g2.layers()[0] >= part4.layers()[0]).all()
+    g2.close(); grid.close(); ctx.close()
