@@ -51,6 +51,11 @@ struct lsa_ctx {
     float* d_small = nullptr;    // init pose[6] | pose[3] | ret | exy[2]
     int* d_ismall = nullptr;     // n_assoc | status | iters
     int staged_n = 0;
+    // the staging above is one device block (r | seg | bad | small | ismall | idx) with a pinned host mirror: the
+    // single-pair entry points the drop-in calls per scan move it with one copy each way
+    char* d_stage = nullptr;
+    char* h_stage = nullptr;
+    size_t stage_bytes = 0, off_seg = 0, off_bad = 0, off_small = 0, off_ismall = 0, off_idx = 0;
     double* d_trig = nullptr;    // point-to-line ICP: cos | sin of the beam bearings in double, 2*N (host libm, as CSM's ld_compute_cartesian on the CPU)
 };
 
@@ -213,16 +218,59 @@ static int ensure_staging(lsa_ctx* c)
 {
     const int n = c->p.points;
     if (c->staged_n == n) return LSA_OK;
-    if (c->d_r) { hipFree(c->d_r); hipFree(c->d_bad); hipFree(c->d_seg); hipFree(c->d_idx); hipFree(c->d_small); hipFree(c->d_ismall); }
-    HIP_TRY(hipMalloc((void**)&c->d_r, sizeof(float) * 2 * n));
-    HIP_TRY(hipMalloc((void**)&c->d_bad, 2 * n));
-    HIP_TRY(hipMalloc((void**)&c->d_seg, sizeof(uint16_t) * 2 * n));
-    HIP_TRY(hipMalloc((void**)&c->d_idx, sizeof(int) * 2));
-    HIP_TRY(hipMalloc((void**)&c->d_small, sizeof(float) * 32));      // [16..21]: min/max slots of lsa_pf_roughen
-    HIP_TRY(hipMalloc((void**)&c->d_ismall, sizeof(int) * 4));
-    const int idx[2] = {0, 1};
-    HIP_TRY(hipMemcpy(c->d_idx, idx, sizeof idx, hipMemcpyHostToDevice));
+    if (c->d_stage) { hipFree(c->d_stage); c->d_stage = nullptr; }
+    if (c->h_stage) { hipHostFree(c->h_stage); c->h_stage = nullptr; }
+    c->d_r = nullptr; c->staged_n = 0;
+    c->off_seg = sizeof(float) * 2 * (size_t)n;
+    c->off_bad = c->off_seg + sizeof(uint16_t) * 2 * (size_t)n;
+    c->off_small = (c->off_bad + 2 * (size_t)n + 15) & ~(size_t)15;
+    c->off_ismall = c->off_small + sizeof(float) * 32;                  // small[16..21]: min/max slots of lsa_pf_roughen
+    c->off_idx = c->off_ismall + sizeof(int) * 4;
+    c->stage_bytes = c->off_idx + sizeof(int) * 2;
+    HIP_TRY(hipMalloc((void**)&c->d_stage, c->stage_bytes));
+    HIP_TRY(hipHostMalloc((void**)&c->h_stage, c->stage_bytes));
+    memset(c->h_stage, 0, c->stage_bytes);
+    ((int*)(c->h_stage + c->off_idx))[1] = 1;                            // ref_idx = 0, act_idx = 1
+    HIP_TRY(hipMemcpy(c->d_stage, c->h_stage, c->stage_bytes, hipMemcpyHostToDevice));
+    c->d_r = (float*)c->d_stage;
+    c->d_seg = (uint16_t*)(c->d_stage + c->off_seg);
+    c->d_bad = (uint8_t*)(c->d_stage + c->off_bad);
+    c->d_small = (float*)(c->d_stage + c->off_small);
+    c->d_ismall = (int*)(c->d_stage + c->off_ismall);
+    c->d_idx = (int*)(c->d_stage + c->off_idx);
     c->staged_n = n;
+    return LSA_OK;
+}
+
+// The same staging through the pinned mirror: pack on the host, one copy down, kernels, one copy up.
+static void pack_scan(lsa_ctx* c, int slot, const float* r, const int32_t* bad, const int32_t* seg)
+{
+    const int n = c->p.points;
+    memcpy(c->h_stage + sizeof(float) * (size_t)slot * n, r, sizeof(float) * n);
+    uint16_t* s16 = (uint16_t*)(c->h_stage + c->off_seg) + (size_t)slot * n;
+    uint8_t* b8 = (uint8_t*)(c->h_stage + c->off_bad) + (size_t)slot * n;
+    for (int i = 0; i < n; ++i) { b8[i] = bad ? (uint8_t)bad[i] : 0; s16[i] = seg ? (uint16_t)seg[i] : 0; }
+}
+
+static void unpack_scan(lsa_ctx* c, int slot, float* r, int32_t* bad, int32_t* seg)
+{
+    const int n = c->p.points;
+    memcpy(r, c->h_stage + sizeof(float) * (size_t)slot * n, sizeof(float) * n);
+    const uint16_t* s16 = (const uint16_t*)(c->h_stage + c->off_seg) + (size_t)slot * n;
+    const uint8_t* b8 = (const uint8_t*)(c->h_stage + c->off_bad) + (size_t)slot * n;
+    for (int i = 0; i < n; ++i) { if (bad) bad[i] = b8[i]; if (seg) seg[i] = s16[i]; }
+}
+
+static int push_stage(lsa_ctx* c)            // scans + init pose (everything below the results' slots)
+{
+    HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, c->off_small + sizeof(float) * 6, hipMemcpyHostToDevice, c->stream));
+    return LSA_OK;
+}
+
+static int pull_stage(lsa_ctx* c)
+{
+    HIP_TRY(hipMemcpyAsync(c->h_stage, c->d_stage, c->off_idx, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return LSA_OK;
 }
 
@@ -294,7 +342,8 @@ void lsa_ctx_destroy(lsa_ctx* c)
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     hipFree(c->d_tab);
     if (c->d_trig) hipFree(c->d_trig);
-    if (c->d_r) { hipFree(c->d_r); hipFree(c->d_bad); hipFree(c->d_seg); hipFree(c->d_idx); hipFree(c->d_small); hipFree(c->d_ismall); }
+    if (c->d_stage) hipFree(c->d_stage);
+    if (c->h_stage) hipHostFree(c->h_stage);
     delete c;
 }
 
@@ -513,23 +562,29 @@ int lsa_translation_estimation_host(lsa_ctx* c, const float* ref_r, const int32_
     return LSA_OK;
 }
 
-static int run_pair(lsa_ctx* c, int which, const float* ref_pose, const float* act_pose, bool want_err,
-                    float pose_out[3], float* ret, float exy[2], int32_t* n_assoc, int32_t* status)
+// One pair through the pinned mirror: the scans are already packed (pack_scan); one copy down, the preprocessing
+// launches asked for, the matcher, one copy up.  Results are read from the mirror.
+static int run_pair_staged(lsa_ctx* c, int which, const float* ref_pose, const float* act_pose, bool want_err,
+                           int preprocess_slots /* bit 0: reference scan, bit 1: current scan */,
+                           float pose_out[3], float* ret, float exy[2], int32_t* n_assoc, int32_t* status)
 {
-    float init[6] = {0, 0, 0, 0, 0, 0};
+    const int n = c->p.points;
+    float* init = (float*)(c->h_stage + c->off_small);
     const bool has_init = ref_pose || act_pose;
+    for (int k = 0; k < 6; ++k) init[k] = 0.0f;
     if (ref_pose) memcpy(init, ref_pose, 12);
     if (act_pose) memcpy(init + 3, act_pose, 12);
-    if (has_init) HIP_TRY(hipMemcpyAsync(c->d_small, init, sizeof init, hipMemcpyHostToDevice, c->stream));
-    int rc = lsa_match_batch(c, which, 1, c->d_r, c->d_bad, c->d_seg, c->d_idx, c->d_idx + 1,
-                             has_init ? c->d_small : nullptr, c->d_small + 6, c->d_small + 9,
-                             want_err ? c->d_small + 10 : nullptr, want_err ? c->d_ismall : nullptr,
-                             c->d_ismall + 1, c->d_ismall + 2);
+    int rc = push_stage(c); if (rc) return rc;
+    if (preprocess_slots & 1) { rc = lsa_preprocess_batch(c, 1, c->d_r, c->d_bad, c->d_seg); if (rc) return rc; }
+    if (preprocess_slots & 2) { rc = lsa_preprocess_batch(c, 1, c->d_r + n, c->d_bad + n, c->d_seg + n); if (rc) return rc; }
+    rc = lsa_match_batch(c, which, 1, c->d_r, c->d_bad, c->d_seg, c->d_idx, c->d_idx + 1,
+                         has_init ? c->d_small : nullptr, c->d_small + 6, c->d_small + 9,
+                         want_err ? c->d_small + 10 : nullptr, want_err ? c->d_ismall : nullptr,
+                         c->d_ismall + 1, c->d_ismall + 2);
     if (rc) return rc;
-    float fs[16]; int is[4];
-    HIP_TRY(hipMemcpyAsync(fs, c->d_small, sizeof fs, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(is, c->d_ismall, sizeof is, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = pull_stage(c); if (rc) return rc;
+    const float* fs = (const float*)(c->h_stage + c->off_small);
+    const int* is = (const int*)(c->h_stage + c->off_ismall);
     memcpy(pose_out, fs + 6, 12);
     if (ret) *ret = fs[9];
     if (exy) { exy[0] = fs[10]; exy[1] = fs[11]; }
@@ -546,9 +601,9 @@ int lsa_match_host(lsa_ctx* c, int which,
     if (!c || !ref_r || !act_r || !pose_out) return fail(LSA_E_ARG, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_staging(c); if (rc) return rc;
-    rc = stage_scan(c, 0, ref_r, ref_bad, nullptr); if (rc) return rc;
-    rc = stage_scan(c, 1, act_r, act_bad, act_seg); if (rc) return rc;
-    return run_pair(c, which, ref_pose, act_pose, false, pose_out, ret, nullptr, nullptr, status);
+    pack_scan(c, 0, ref_r, ref_bad, nullptr);
+    pack_scan(c, 1, act_r, act_bad, act_seg);
+    return run_pair_staged(c, which, ref_pose, act_pose, false, 0, pose_out, ret, nullptr, nullptr, status);
 }
 
 int lsa_error_index2_batch(lsa_ctx* c, int B, const float* d_r, const uint8_t* d_bad, const uint16_t* d_seg,
@@ -599,17 +654,14 @@ int lsa_fmatch_host(lsa_ctx* c, float* ref_r, int32_t* ref_bad, int32_t* ref_seg
         return fail(LSA_E_ARG, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_staging(c); if (rc) return rc;
-    const int n = c->p.points;
-    rc = stage_scan(c, 0, ref_r, ref_bad, ref_seg); if (rc) return rc;
-    rc = stage_scan(c, 1, act_r, act_bad, act_seg); if (rc) return rc;
-    if (first) { rc = lsa_preprocess_batch(c, 1, c->d_r, c->d_bad, c->d_seg); if (rc) return rc; }
-    rc = lsa_preprocess_batch(c, 1, c->d_r + n, c->d_bad + n, c->d_seg + n); if (rc) return rc;
+    pack_scan(c, 0, ref_r, ref_bad, ref_seg);
+    pack_scan(c, 1, act_r, act_bad, act_seg);
     int32_t status = 0, na = 0;
     float ret = 0, exy[2] = {0, 0};
-    rc = run_pair(c, LSA_MATCH_ICP, nullptr, nullptr, true, pose_out, &ret, exy, &na, &status);
+    rc = run_pair_staged(c, LSA_MATCH_ICP, nullptr, nullptr, true, first ? 3 : 2, pose_out, &ret, exy, &na, &status);
     if (rc) return rc;
-    if (first) { rc = unstage_scan(c, 0, ref_r, ref_bad, ref_seg); if (rc) return rc; }
-    rc = unstage_scan(c, 1, act_r, act_bad, act_seg); if (rc) return rc;
+    if (first) unpack_scan(c, 0, ref_r, ref_bad, ref_seg);
+    unpack_scan(c, 1, act_r, act_bad, act_seg);
     if (status == LSA_ST_OK) { ret_pair[0] = exy[0]; ret_pair[1] = exy[1]; }
     else { ret_pair[0] = -1.0f; ret_pair[1] = -1.0f; }   // the retry at :110-118 sees the same inputs
     return LSA_OK;
