@@ -1397,18 +1397,15 @@ int lsa_plicp_host(lsa_ctx* c, const float* ref_r, const float* cur_r, const lsa
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_staging(c); if (rc) return rc;
     const int n = c->p.points;
-    HIP_TRY(hipMemcpyAsync(c->d_r, ref_r, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_r + n, cur_r, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
-    const int32_t idx[2] = {0, 1};
-    HIP_TRY(hipMemcpyAsync(c->d_idx, idx, sizeof idx, hipMemcpyHostToDevice, c->stream));
-    double* d_out = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_out, sizeof(double) * 8));
-    rc = lsa_plicp_batch(c, 1, c->d_r, c->d_idx, c->d_idx + 1, opt, d_out);
-    hipError_t e = hipSuccess;
-    if (rc == LSA_OK) { e = hipMemcpyAsync(out8, d_out, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream); if (e == hipSuccess) e = hipStreamSynchronize(c->stream); }
-    hipFree(d_out);
+    // through the pinned staging block: the two range rows down, the 8-double record (the block's small slots) up
+    memcpy(c->h_stage, ref_r, sizeof(float) * n);
+    memcpy(c->h_stage + sizeof(float) * (size_t)n, cur_r, sizeof(float) * n);
+    HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    rc = lsa_plicp_batch(c, 1, c->d_r, c->d_idx, c->d_idx + 1, opt, (double*)c->d_small);
     if (rc) return rc;
-    if (e != hipSuccess) return fail(LSA_E_HIP, "plicp", e);
+    HIP_TRY(hipMemcpyAsync(c->h_stage + c->off_small, c->d_small, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(out8, c->h_stage + c->off_small, sizeof(double) * 8);
     return LSA_OK;
 }
 
