@@ -317,6 +317,19 @@ def extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p):
     t0 = time.perf_counter()
     capi.pose_topk(ctx, d_sc, P, 60)
     res["topk60_of_1M_ms"] = (time.perf_counter() - t0) * 1e3
+    # the particle filter's resampling step at 1 M particles (weights, the reference's standard resampler, gather)
+    m, _ = capi.pose_argmax(ctx, d_sc, P)
+    d_w = torch.zeros(P, device="cuda"); d_par = torch.zeros(P, dtype=torch.int32, device="cuda"); d_new = torch.zeros(P, 3, device="cuda")
+    d_u = torch.rand(P, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+
+    def resample_step():
+        capi.pf_weights(ctx, d_sc, P, m, d_w)
+        capi.pf_resample_standard(ctx, d_w, P, d_u, P, d_par)
+        capi.gather_poses(ctx, d_p, d_par, P, d_new)
+    resample_step(); ctx.sync()
+    t0 = time.perf_counter(); resample_step(); ctx.sync()
+    res["pf_resample_1M_ms"] = (time.perf_counter() - t0) * 1e3
     fld.close()
     grid.close()
     return res

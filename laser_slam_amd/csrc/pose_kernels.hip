@@ -223,14 +223,29 @@ __global__ __launch_bounds__(256) void resample_kernel(const double* __restrict_
 __global__ __launch_bounds__(256) void resample_count_kernel(const double* __restrict__ cum, int P, double total,
                                                              const double* __restrict__ u, int n_u, float* __restrict__ count)
 {
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_u; k += gridDim.x * blockDim.x) {
-        const double s = u[k] * total;                      // ur *= wcum, :88
-        int lo = 0, hi = P - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (s < cum[mid]) hi = mid; else lo = mid + 1;
+    const int lane = (int)(threadIdx.x & 63);
+    for (int k0 = blockIdx.x * blockDim.x; k0 < n_u; k0 += gridDim.x * blockDim.x) {
+        const int k = k0 + (int)threadIdx.x;
+        const bool active = k < n_u;
+        int lo = 0;
+        if (active) {
+            const double s = u[k] * total;                  // ur *= wcum, :88
+            int hi = P - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s < cum[mid]) hi = mid; else lo = mid + 1;
+            }
         }
-        atomicAdd(&count[lo], 1.0f);
+        // sharp weights send a large share of the uniforms to a few particles, and adds to one address are executed one
+        // after the other by the memory system (some 50 ns each): the lanes of a wave that found the same particle add once
+        unsigned long long todo = __ballot(active);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int t = __shfl(lo, leader);
+            const unsigned long long same = __ballot(active && lo == t);
+            if (lane == leader) atomicAdd(&count[t], (float)__popcll(same));
+            todo &= ~same;
+        }
     }
 }
 
