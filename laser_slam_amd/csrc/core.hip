@@ -1043,10 +1043,35 @@ static int topk_device(lsa_ctx* c, const float* d_poses, const float* d_score, i
     if (e == hipSuccess) e = hipMemsetAsync(d_keys, 0, sizeof(unsigned long long) * k, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, sizeof(float) * 4 * k, c->stream);
     if (e == hipSuccess) {
-        for (int pass = 0; pass < k; ++pass)
-            hipLaunchKernelGGL(lsa::topk_pass_kernel, dim3(blocks_for((size_t)n, 256, 1024)), dim3(256), 0, c->stream, d_score, n, d_keys, pass);
+        bool selected = false;
+        if (n >= 4096 && k <= lsa::TOPK_CAND_MAX / 2) {
+            // radix select of the k-th best score, then a sort of the few candidates (ties of that score included)
+            uint32_t* d_st = nullptr; unsigned long long* d_cand = nullptr;
+            e = hipMalloc((void**)&d_st, sizeof(uint32_t) * (8 + 256));
+            if (e == hipSuccess) e = hipMalloc((void**)&d_cand, sizeof(unsigned long long) * lsa::TOPK_CAND_MAX);
+            if (e == hipSuccess) {
+                uint32_t st0[8 + 256] = {0};
+                st0[2] = (uint32_t)k;
+                e = hipMemcpyAsync(d_st, st0, sizeof st0, hipMemcpyHostToDevice, c->stream);
+                for (int shift = 24; shift >= 0 && e == hipSuccess; shift -= 8) {
+                    hipLaunchKernelGGL(lsa::topk_hist_kernel, dim3(blocks_for((size_t)n, 256, 1024)), dim3(256), 0, c->stream, d_score, n, d_st, shift, d_st + 8);
+                    hipLaunchKernelGGL(lsa::topk_pick_kernel, dim3(1), dim3(256), 0, c->stream, d_st, shift, d_st + 8);
+                }
+                hipLaunchKernelGGL(lsa::topk_collect_kernel, dim3(blocks_for((size_t)n, 256, 1024)), dim3(256), 0, c->stream, d_score, n, d_st, d_cand);
+                hipLaunchKernelGGL(lsa::topk_sort_kernel, dim3(1), dim3(1024), 0, c->stream, d_st, d_cand, k, d_keys);
+                uint32_t st1[8] = {0};
+                if (e == hipSuccess) e = hipMemcpyAsync(st1, d_st, sizeof st1, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                selected = e == hipSuccess && st1[4] == 0;             // (too many ties of the k-th score: the passes below)
+                if (!selected && e == hipSuccess) e = hipMemsetAsync(d_keys, 0, sizeof(unsigned long long) * k, c->stream);
+            }
+            hipFree(d_st); hipFree(d_cand);
+        }
+        if (!selected && e == hipSuccess)
+            for (int pass = 0; pass < k; ++pass)
+                hipLaunchKernelGGL(lsa::topk_pass_kernel, dim3(blocks_for((size_t)n, 256, 1024)), dim3(256), 0, c->stream, d_score, n, d_keys, pass);
         hipLaunchKernelGGL(lsa::topk_gather_kernel, dim3((k + 63) / 64), dim3(64), 0, c->stream, d_keys, k, d_poses, d_score, d_out, d_idx);
-        e = hipGetLastError();
+        if (e == hipSuccess) e = hipGetLastError();
     }
     index.resize(k); rec4.resize(4 * (size_t)k);
     if (e == hipSuccess) e = hipMemcpyAsync(index.data(), d_idx, sizeof(int) * k, hipMemcpyDeviceToHost, c->stream);

@@ -279,6 +279,75 @@ __global__ __launch_bounds__(256) void topk_pass_kernel(const float* __restrict_
     if ((threadIdx.x & 63) == 0 && best) atomicMax(&keys[pass], best);
 }
 
+// The same k best for large n without k passes over the scores: a radix select (four 8-bit digits of the ordered
+// score) finds the score of the k-th best, every element at least as good is collected (all the ties of that score
+// with it), and one workgroup sorts the few candidates by the full key - best score first, equal scores in index
+// order like topK.  st: [0] prefix found so far, [1] its mask, [2] how many are still wanted among the matching
+// elements, [3] candidate counter, [4] overflow flag; hist: 256 bins.
+constexpr int TOPK_CAND_MAX = 8192;
+
+__global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict__ score, int n, const uint32_t* __restrict__ st,
+                                                        int shift, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t prefix = st[0], mask = st[1];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t key = f_ord(score[i]);
+        if ((key & mask) == prefix) atomicAdd(&lh[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+
+__global__ void topk_pick_kernel(uint32_t* __restrict__ st, int shift, uint32_t* __restrict__ hist)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t want = st[2], above = 0;
+        int b = 255;
+        for (; b > 0; --b) { if (above + hist[b] >= want) break; above += hist[b]; }
+        st[0] |= (uint32_t)b << shift; st[1] |= 255u << shift; st[2] = want - above;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+}
+
+__global__ __launch_bounds__(256) void topk_collect_kernel(const float* __restrict__ score, int n, uint32_t* __restrict__ st,
+                                                           unsigned long long* __restrict__ cand)
+{
+    const uint32_t thr = st[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float sc = score[i];
+        if (f_ord(sc) >= thr) {
+            const uint32_t pos = atomicAdd(&st[3], 1u);
+            if (pos < (uint32_t)TOPK_CAND_MAX) cand[pos] = topk_key(sc, i); else st[4] = 1u;
+        }
+    }
+}
+
+// one workgroup: bitonic sort (descending) of the candidates' keys in LDS, the k largest go to keys[]
+__global__ __launch_bounds__(1024) void topk_sort_kernel(const uint32_t* __restrict__ st, const unsigned long long* __restrict__ cand,
+                                                         int k, unsigned long long* __restrict__ keys)
+{
+    __shared__ unsigned long long sk[TOPK_CAND_MAX];
+    const int m = st[3] < (uint32_t)TOPK_CAND_MAX ? (int)st[3] : TOPK_CAND_MAX;
+    int npad = 1;
+    while (npad < m) npad <<= 1;
+    for (int i = threadIdx.x; i < npad; i += blockDim.x) sk[i] = i < m ? cand[i] : 0ull;
+    __syncthreads();
+    for (int kk = 2; kk <= npad; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (npad >> 1); t += blockDim.x) {
+                const int i0 = ((t / j) * 2 * j) + (t % j), i1 = i0 + j;
+                const unsigned long long a = sk[i0], b = sk[i1];
+                if ((a < b) == ((i0 & kk) == 0)) { sk[i0] = b; sk[i1] = a; }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < k; i += blockDim.x) keys[i] = i < m ? sk[i] : 0ull;
+}
+
 // gathers the top-k poses and scores into a staging buffer: out[i] = {x, y, theta, score}
 __global__ void topk_gather_kernel(const unsigned long long* __restrict__ keys, int k, const float* __restrict__ poses,
                                    const float* __restrict__ score, float* __restrict__ out4, int* __restrict__ index)

@@ -339,3 +339,28 @@ def test_full_size_filter_step_properties(world):
     order = np.lexsort((np.arange(P), -sc))[:8]                      # best first, equal scores in index order
     assert np.array_equal(idx, order)
     assert float(sc[par].mean()) > float(sc.mean())                  # the offspring sit on better poses
+
+
+def test_topk_large_with_ties(world):
+    """lsa_pose_topk on large score lists (radix select + candidate sort): distinct scores, a few ties at the
+    k-th score, and more ties of the k-th score than the candidate buffer holds (falls back to the k passes) -
+    always the k best, best first, equal scores in index order like threadLocalization::topK."""
+    import torch
+    from laser_slam_amd import capi
+    ctx = world["ctx"]
+    rng = np.random.default_rng(12)
+
+    def check(sc, k):
+        d = torch.from_numpy(sc).cuda(); torch.cuda.synchronize()
+        idx, val = capi.pose_topk(ctx, d, len(sc), k)
+        order = np.lexsort((np.arange(len(sc)), -sc.astype(np.float64)))[:k]
+        assert np.array_equal(idx, order) and np.array_equal(val, sc[order])
+
+    n = 300000
+    check(rng.normal(0, 1, n).astype(np.float32), 60)
+    check(rng.normal(0, 1, n).astype(np.float32), 1)
+    check(-np.abs(rng.normal(0, 1, n)).astype(np.float32), 500)           # negative scores (log-likelihoods)
+    check(np.round(rng.normal(0, 1, n), 2).astype(np.float32), 60)          # ties everywhere, a few hundred at the k-th score
+    check(np.round(rng.normal(0, 1, n), 0).astype(np.float32), 60)          # tens of thousands of ties at the k-th score
+    sc = np.zeros(n, np.float32); sc[rng.integers(0, n, 7)] = 1.0
+    check(sc, 60)                                                            # 7 ones, then zeros in index order
