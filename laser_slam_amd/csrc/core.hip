@@ -384,6 +384,14 @@ int lsa_preprocess_stages_batch(lsa_ctx* c, int S, float* d_r, uint8_t* d_bad, u
     if ((stages & ~7) || stages == 0) return fail(LSA_E_ARG, "stages must be a non-empty subset of MEDIAN|FAR|SEGMENT");
     if (S <= 0) return LSA_OK;
     HIP_TRY(hipSetDevice(c->device));
+    const char* pre_env = getenv("LSA_PREPROCESS_PATH");
+    const bool lanes = pre_env ? !strcmp(pre_env, "lanes") : S >= 4096;      // (measured crossover: a small batch has too few waves that way)
+    if (stages == 7 && lanes && c->p.points >= 3) {
+        // batches: one lane per scan (the recurrences stay sequential, 64 scans share a wave)
+        hipLaunchKernelGGL(lsa::preprocess_lanes_kernel, dim3((S + 63) / 64), dim3(64), 0, c->stream, dev_param(c), S, d_r, d_bad, d_seg);
+        HIP_TRY(hipGetLastError());
+        return LSA_OK;
+    }
     hipLaunchKernelGGL(lsa::preprocess_kernel, dim3(S), dim3(64), pre_lds(c->p.points), c->stream,
                        dev_param(c), S, d_r, d_bad, d_seg, stages);
     HIP_TRY(hipGetLastError());

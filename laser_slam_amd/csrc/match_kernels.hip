@@ -386,4 +386,72 @@ __global__ __launch_bounds__(64) void preprocess_kernel(
     }
 }
 
+// The same three stages for batches: one LANE per scan.  Median filter and segmentation are recurrences along the
+// beam index, so a scan cannot be spread over lanes - but 64 scans can share a wave, each lane walking its own rows
+// of the global arrays (a lane reads and writes consecutive addresses, the caches merge them into lines) with the
+// recurrences' state in registers.  Identical arithmetic to preprocess_kernel's lane 0; 64 times the work per wave.
+__global__ __launch_bounds__(64) void preprocess_lanes_kernel(
+    DevParam P, int S, float* __restrict__ g_r, uint8_t* __restrict__ g_bad, uint16_t* __restrict__ g_seg)
+{
+    const int N = P.n;
+    const int s = blockIdx.x * 64 + (int)threadIdx.x;
+    if (s >= S || N < 3) return;
+    float* r = g_r + (size_t)s * N;
+    uint8_t* bad = g_bad + (size_t)s * N;
+    uint16_t* seg = g_seg + (size_t)s * N;
+    const float lim = LSA_SEG_MAX_DIST, far = (float)P.max_range;
+    // median state: f2, f1 = filtered r[i-2], r[i-1] (the live array's values); a0, a1, a2 = raw r[i], r[i+1], r[i+2]
+    float f2 = 0, f1 = 0, a0 = r[0], a1 = r[1], a2 = r[2];
+    // segmentation state (two beams behind are still open to the break handling)
+    float r1 = 0, r2 = 0;          // filtered r[i-1], r[i-2]
+    int b1 = 0, b2 = 0;            // flags of i-1, i-2 after the far test
+    int sg1 = 0, sg2 = 0;          // seg[i-1], seg[i-2] (may still change)
+    int id = 1, run = 0;
+    for (int i = 0; i < N; ++i) {
+        // --- median of the live window r[clamp(i-2 .. i+2)] (:1610-1639): left of i already filtered
+        float w[5];
+        w[0] = i >= 2 ? f2 : (i == 1 ? f1 : a0);          // clamp(i-2): r[0] - filtered once i >= 1
+        w[1] = i >= 1 ? f1 : a0;                           // clamp(i-1)
+        w[2] = a0;
+        w[3] = i + 1 <= N - 1 ? a1 : a0;                   // clamp(i+1) = r[N-1] = a0 when i = N-1
+        w[4] = i + 2 <= N - 1 ? a2 : (i + 1 <= N - 1 ? a1 : a0);
+        #pragma unroll
+        for (int hi = 4; hi > 0; --hi)
+            #pragma unroll
+            for (int k = 0; k < hi; ++k)
+                if (w[k] > w[k + 1]) { const float sw = w[k]; w[k] = w[k + 1]; w[k + 1] = sw; }
+        const float ri = w[2];
+        r[i] = ri;
+        f2 = f1; f1 = ri;
+        a0 = a1; a1 = a2; a2 = i + 3 < N ? r[i + 3] : 0.0f;
+        // --- far points (:1583-1590)
+        const int bi = (int)bad[i] | (ri > far ? 1 : 0);
+        bad[i] = (uint8_t)bi;
+        // --- segmentation (:1495-1576), finalising seg[i-2]
+        int sgi;
+        if (i == 0) { sgi = 0; }
+        else if (i == 1) {
+            if (fabsf_(r1 - ri) < lim) { sg1 = id; sgi = id; run = 2; } else { sg1 = 0; sgi = id; run = 1; }
+        } else {
+            bool brk = false;
+            sgi = 0;
+            const float ex = (float)((double)ri - (2.0 * (double)r1 - (double)r2));
+            if (bi) brk = true;
+            else if (fabsf_(ri - r1) < lim || (sg1 == sg2 && fabsf_(ex) < lim)) { run++; sgi = id; }
+            else brk = true;
+            if (brk) {
+                if (run == 1) {
+                    if (sg2 == 0 && bi == 0 && b1 == 0 && b2 == 0 && fabsf_(ex) < lim) { sgi = id; sg1 = id; sg2 = id; run = 3; }
+                    else { sg1 = 0; sgi = id; run = 1; }
+                } else { id++; sgi = id; run = 1; }
+            }
+            seg[i - 2] = (uint16_t)sg2;
+        }
+        sg2 = sg1; sg1 = sgi;
+        r2 = r1; r1 = ri; b2 = b1; b1 = bi;
+    }
+    seg[N - 2] = (uint16_t)sg2;
+    seg[N - 1] = (uint16_t)sg1;
+}
+
 } // namespace lsa
