@@ -332,6 +332,23 @@ def extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p):
     resample_step(); ctx.sync()
     t0 = time.perf_counter(); resample_step(); ctx.sync()
     res["pf_resample_1M_ms"] = (time.perf_counter() - t0) * 1e3
+    # one whole localisation step at 1 M particles as CParticles runs it (particles.cpp:119-153, 321-387): predict,
+    # likelihood-field scores, best pose, weights / N_eff, standard resampling, gather, roughening, estimate of the 8 best
+    d_nrm = torch.randn(P, 3, device="cuda"); d_cur = d_p.clone()
+
+    def pf_step():
+        capi.pf_predict(ctx, P, [10.0, 7.5, 0.0], [0.25, 0.25, 0.27], d_nrm, d_cur)
+        fld.score_poses(d_sx, d_sy, n, 3, d_cur, P, d_sc)
+        mm, _ = capi.pose_argmax(ctx, d_sc, P)
+        s1, s2 = capi.pf_weights(ctx, d_sc, P, mm, d_w)
+        if 1.0 / (1.0 + s2 / (s1 * s1)) < 0.5 * P:
+            capi.pf_resample_standard(ctx, d_w, P, d_u, P, d_par)
+            capi.gather_poses(ctx, d_cur, d_par, P, d_new)
+            capi.pf_roughen(ctx, P, 0.2, d_nrm, d_new)
+        return capi.pf_estimate(ctx, d_cur, d_sc, P, 8)
+    pf_step(); ctx.sync()
+    t0 = time.perf_counter(); pf_step(); ctx.sync()
+    res["pf_step_1M_ms"] = (time.perf_counter() - t0) * 1e3
     fld.close()
     grid.close()
     return res
