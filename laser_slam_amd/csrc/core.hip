@@ -56,6 +56,8 @@ struct lsa_ctx {
     char* d_stage = nullptr;
     char* h_stage = nullptr;
     size_t stage_bytes = 0, off_seg = 0, off_bad = 0, off_small = 0, off_ismall = 0, off_idx = 0;
+    char* d_scratch = nullptr;   // grow-only scratch of the calls that need large temporaries (a context serves one thread)
+    size_t scratch_cap = 0;
     double* d_trig = nullptr;    // point-to-line ICP: cos | sin of the beam bearings in double, 2*N (host libm, as CSM's ld_compute_cartesian on the CPU)
 };
 
@@ -344,7 +346,23 @@ void lsa_ctx_destroy(lsa_ctx* c)
     if (c->d_trig) hipFree(c->d_trig);
     if (c->d_stage) hipFree(c->d_stage);
     if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->d_scratch) hipFree(c->d_scratch);
     delete c;
+}
+
+// Large temporaries come from one grow-only block per context (an 8 MB hipMalloc + hipFree costs 170 us here, as
+// much as the kernels of a resampling step between them); the stream orders its reuse across calls.
+static int ctx_scratch(lsa_ctx* c, size_t bytes, char** out)
+{
+    if (c->scratch_cap < bytes) {
+        if (c->d_scratch) { HIP_TRY(hipStreamSynchronize(c->stream)); hipFree(c->d_scratch); c->d_scratch = nullptr; c->scratch_cap = 0; }
+        const size_t cap = bytes + bytes / 4 + 4096;
+        hipError_t e = hipMalloc((void**)&c->d_scratch, cap);
+        if (e != hipSuccess) return fail(LSA_E_NOMEM, "hipMalloc(scratch)", e);
+        c->scratch_cap = cap;
+    }
+    *out = c->d_scratch;
+    return LSA_OK;
 }
 
 // ---- memory helpers ---------------------------------------------------------
@@ -1300,10 +1318,10 @@ int lsa_pf_resample(lsa_ctx* c, const float* d_w, int P, double u0, int n_total,
     if (M == 0) return LSA_OK;
     HIP_TRY(hipSetDevice(c->device));
     const int per = lsa::SCAN_BLOCK * lsa::SCAN_ITEMS, nb = (P + per - 1) / per;
-    double *d_cum = nullptr, *d_bs = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_cum, sizeof(double) * (size_t)P));
-    hipError_t e = hipMalloc((void**)&d_bs, sizeof(double) * (size_t)(nb + 1));
-    if (e != hipSuccess) { hipFree(d_cum); return fail(LSA_E_NOMEM, "hipMalloc", e); }
+    char* scratch = nullptr;
+    int rc = ctx_scratch(c, sizeof(double) * ((size_t)P + nb + 1), &scratch); if (rc) return rc;
+    double* d_cum = (double*)scratch; double* d_bs = d_cum + P;
+    hipError_t e = hipSuccess;
     hipLaunchKernelGGL(lsa::scan_block_kernel, dim3(nb), dim3(lsa::SCAN_BLOCK), 0, c->stream, d_w, P, d_cum, d_bs);
     hipLaunchKernelGGL(lsa::scan_sums_kernel, dim3(1), dim3(64), 0, c->stream, d_bs, nb);
     hipLaunchKernelGGL(lsa::scan_apply_kernel, dim3(nb), dim3(lsa::SCAN_BLOCK), 0, c->stream, d_cum, P, d_bs);
@@ -1315,7 +1333,6 @@ int lsa_pf_resample(lsa_ctx* c, const float* d_w, int P, double u0, int n_total,
                            d_cum, P, total, u0, n_total, first, M, d_parent);
         e = hipStreamSynchronize(c->stream);
     }
-    hipFree(d_cum); hipFree(d_bs);
     if (e != hipSuccess) return fail(LSA_E_HIP, "lsa_pf_resample", e);
     if (!(total > 0)) return fail(LSA_E_ARG, "total likelihood zero");          // SIRFlt.cpp:150-152
     return LSA_OK;
@@ -1329,11 +1346,11 @@ int lsa_pf_resample_standard(lsa_ctx* c, const float* d_w, int P, const double* 
     if (n_u == 0 || M == 0) return LSA_OK;
     HIP_TRY(hipSetDevice(c->device));
     const int per = lsa::SCAN_BLOCK * lsa::SCAN_ITEMS, nb = (P + per - 1) / per;
-    double *d_cum = nullptr, *d_bs = nullptr;
-    float* d_cnt = nullptr;
-    hipError_t e = hipMalloc((void**)&d_cum, sizeof(double) * (size_t)P);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_bs, sizeof(double) * (size_t)(nb + 1));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_cnt, sizeof(float) * (size_t)P);
+    char* scratch = nullptr;
+    int rc = ctx_scratch(c, sizeof(double) * ((size_t)P + nb + 1) + sizeof(float) * (size_t)P, &scratch); if (rc) return rc;
+    double* d_cum = (double*)scratch; double* d_bs = d_cum + P;
+    float* d_cnt = (float*)(d_bs + nb + 1);
+    hipError_t e = hipSuccess;
     double total = 0;
     if (e == hipSuccess) {
         hipLaunchKernelGGL(lsa::scan_block_kernel, dim3(nb), dim3(lsa::SCAN_BLOCK), 0, c->stream, d_w, P, d_cum, d_bs);
@@ -1354,8 +1371,7 @@ int lsa_pf_resample_standard(lsa_ctx* c, const float* d_w, int P, const double* 
                            d_cum, P, (double)n_u, 0.5, n_u, first, M, d_parent);
         e = hipStreamSynchronize(c->stream);
     }
-    hipFree(d_cum); hipFree(d_bs); hipFree(d_cnt);
-    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? LSA_E_NOMEM : LSA_E_HIP, "lsa_pf_resample_standard", e);
+    if (e != hipSuccess) return fail(LSA_E_HIP, "lsa_pf_resample_standard", e);
     if (!(total > 0)) return fail(LSA_E_ARG, "zero cumulative weight sum");       // SIRFlt.cpp:72-73
     return LSA_OK;
 }
