@@ -1264,7 +1264,7 @@ int lsa_icp_goodness_scores(lsa_field* f, const float* d_prob, const float* d_po
     char* d = nullptr;
     const size_t bytes = pts * (2 * sizeof(float) + sizeof(unsigned long long) + sizeof(int)) + (size_t)(n_poses + 1) * sizeof(int)
                        + (size_t)n_poses * (3 + 16) * sizeof(double) + 64;
-    HIP_TRY(hipMalloc((void**)&d, bytes));
+    { const int rcs = ctx_scratch(c, bytes, &d); if (rcs) return rcs; }
     double* d_out = (double*)d; double* d_init = d_out + 16 * (size_t)n_poses;
     unsigned long long* d_owner = (unsigned long long*)(d_init + 3 * (size_t)n_poses);
     float* d_sx = (float*)(d_owner + pts); float* d_sy = d_sx + pts;
@@ -1285,7 +1285,6 @@ int lsa_icp_goodness_scores(lsa_field* f, const float* d_prob, const float* d_po
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d);
     if (e != hipSuccess) return fail(LSA_E_HIP, "icp goodness", e);
     return LSA_OK;
 }
@@ -1482,17 +1481,17 @@ int lsa_p2p_icp_batch(lsa_ctx* c, int B, const float* d_ref_x, const float* d_re
     if (o.max_iterations < 1 || !(o.alfa > 0 && o.alfa < 1) || !(o.threshold_dist > 0))
         return fail(LSA_E_ARG, "bad ICP options");
     HIP_TRY(hipSetDevice(c->device));
-    unsigned long long* d_owner = nullptr;
-    int* d_match = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_owner, sizeof(unsigned long long) * (size_t)(n_ref_total > 0 ? n_ref_total : 1)));
-    hipError_t e = hipMalloc((void**)&d_match, sizeof(int) * (size_t)(n_cur_total > 0 ? n_cur_total : 1));
-    if (e != hipSuccess) { hipFree(d_owner); return fail(LSA_E_NOMEM, "hipMalloc", e); }
+    const size_t nro = (size_t)(n_ref_total > 0 ? n_ref_total : 1), ncu = (size_t)(n_cur_total > 0 ? n_cur_total : 1);
+    char* scratch = nullptr;
+    { const int rcs = ctx_scratch(c, sizeof(unsigned long long) * nro + sizeof(int) * ncu, &scratch); if (rcs) return rcs; }
+    unsigned long long* d_owner = (unsigned long long*)scratch;
+    int* d_match = (int*)(d_owner + nro);
+    hipError_t e = hipSuccess;
     lsa::P2PParam P = {o.max_iterations, o.threshold_dist, o.threshold_ang, o.alfa, o.smallest_threshold_dist};
     hipLaunchKernelGGL(lsa::p2p_icp_kernel, dim3(B), dim3(lsa::P2P_THREADS), 0, c->stream, P, B, d_ref_x, d_ref_y,
                        d_ref_off, d_cur_x, d_cur_y, d_cur_off, d_init_pose, d_owner, d_match, d_out16, 0);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_owner); hipFree(d_match);
     if (e != hipSuccess) return fail(LSA_E_HIP, "p2p_icp_kernel", e);
     return LSA_OK;
 }
