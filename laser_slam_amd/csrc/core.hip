@@ -1046,7 +1046,7 @@ int lsa_pose_argmax(lsa_ctx* c, const float* d_score, int P, float* h_max, int32
     int rc = ensure_staging(c); if (rc) return rc;
     unsigned long long* key = (unsigned long long*)(c->d_small + 12);      // 8-byte aligned slot
     HIP_TRY(hipMemsetAsync(key, 0, 8, c->stream));
-    hipLaunchKernelGGL(lsa::argmax_kernel, dim3(blocks_for((size_t)P, 256, 1024)), dim3(256), 0, c->stream, d_score, P, key);
+    hipLaunchKernelGGL(lsa::argmax_kernel, dim3(blocks_for((size_t)P, 256, 512)), dim3(256), 0, c->stream, d_score, P, key);
     HIP_TRY(hipGetLastError());
     unsigned long long h = 0;
     HIP_TRY(hipMemcpyAsync(&h, key, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1080,7 +1080,7 @@ static int topk_device(lsa_ctx* c, const float* d_poses, const float* d_score, i
                 st0[2] = (uint32_t)k;
                 e = hipMemcpyAsync(d_st, st0, sizeof st0, hipMemcpyHostToDevice, c->stream);
                 for (int shift = 24; shift >= 0 && e == hipSuccess; shift -= 8) {
-                    hipLaunchKernelGGL(lsa::topk_hist_kernel, dim3(blocks_for((size_t)n, 256, 1024)), dim3(256), 0, c->stream, d_score, n, d_st, shift, d_st + 8);
+                    hipLaunchKernelGGL(lsa::topk_hist_kernel, dim3(blocks_for((size_t)n, 256, 512)), dim3(256), 0, c->stream, d_score, n, d_st, shift, d_st + 8);
                     hipLaunchKernelGGL(lsa::topk_pick_kernel, dim3(1), dim3(256), 0, c->stream, d_st, shift, d_st + 8);
                 }
                 hipLaunchKernelGGL(lsa::topk_collect_kernel, dim3(blocks_for((size_t)n, 256, 1024)), dim3(256), 0, c->stream, d_score, n, d_st, d_cand);
@@ -1172,7 +1172,7 @@ int lsa_pf_roughen(lsa_ctx* c, int n, double K, const float* d_normals, float* d
     uint32_t* mm = (uint32_t*)(c->d_small + 16);
     static const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     HIP_TRY(hipMemcpyAsync(mm, init, sizeof init, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(lsa::pf_minmax_kernel, dim3(blocks_for((size_t)n, 256, 1024)), dim3(256), 0, c->stream, n, d_poses, mm);
+    hipLaunchKernelGGL(lsa::pf_minmax_kernel, dim3(blocks_for((size_t)n, 256, 512)), dim3(256), 0, c->stream, n, d_poses, mm);
     const double scale = K * pow((double)n, -1.0 / 3.0);                    // SIRFlt.cpp:373, x_size = 3
     hipLaunchKernelGGL(lsa::pf_roughen_kernel, dim3(blocks_for((size_t)n, 256, 2048)), dim3(256), 0, c->stream, n, scale, mm, d_normals, d_poses);
     HIP_TRY(hipGetLastError());
