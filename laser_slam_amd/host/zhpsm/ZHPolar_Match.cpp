@@ -426,15 +426,83 @@ void CPolarMatch::runlog(int run_num)
     ofstream out(m_trajectory_path.c_str());
     if (!out.is_open()) cout << "failed to open output trajectory!" << endl;
     if (run_num < 0) run_num = (int)m_SickScans.size() + 1;
+    const int S = (int)m_SickScans.size() < run_num ? (int)m_SickScans.size() : run_num;
     const double odometry_thre = 0.6982, dis_squre_thre = 10000;
     const float err_thre = 10;
+
+    // The reference matches frame after frame, but every match starts from a zero prior on the previous frame: only
+    // the bookkeeping below is sequential.  So all frames are preprocessed in one batch and all consecutive pairs
+    // go through pm_psm, then pm_icp from pm_psm's result (from zero where pm_psm threw), then pm_error_index2 at
+    // the pose the frame is left with - three batched launches instead of 4 S single-pair calls, same numbers.
+    vector<float> rel((size_t)(S > 1 ? S - 1 : 0) * 3, 0.0f), exy((size_t)(S > 1 ? S - 1 : 0) * 2, 0.0f);
+    vector<int> failed_pair(S > 1 ? S - 1 : 0, 0);
+    if (S > 1) {
+        syncParam();
+        const int n = m_pParam->pm_l_points, B = S - 1;
+        vector<float> r((size_t)S * n);
+        vector<uint8_t> bad((size_t)S * n);
+        vector<uint16_t> seg((size_t)S * n);
+        vector<int32_t> ri(B), ai(B);
+        for (int k = 0; k < S; ++k) {
+            memcpy(&r[(size_t)k * n], m_SickScans[k]->r, sizeof(float) * n);
+            for (int i = 0; i < n; ++i) bad[(size_t)k * n + i] = (uint8_t)m_SickScans[k]->bad[i];
+        }
+        for (int b = 0; b < B; ++b) { ri[b] = b; ai[b] = b + 1; }
+        void *d_r = 0, *d_bad = 0, *d_seg = 0, *d_ri = 0, *d_ai = 0, *d_pose = 0, *d_st = 0, *d_init = 0, *d_exy = 0;
+        must(lsa_malloc(&d_r, r.size() * 4), "lsa_malloc"); must(lsa_malloc(&d_bad, bad.size()), "lsa_malloc");
+        must(lsa_malloc(&d_seg, bad.size() * 2), "lsa_malloc");
+        must(lsa_malloc(&d_ri, (size_t)B * 4), "lsa_malloc"); must(lsa_malloc(&d_ai, (size_t)B * 4), "lsa_malloc");
+        must(lsa_malloc(&d_pose, (size_t)B * 12), "lsa_malloc"); must(lsa_malloc(&d_st, (size_t)B * 4), "lsa_malloc");
+        must(lsa_malloc(&d_init, (size_t)B * 24), "lsa_malloc"); must(lsa_malloc(&d_exy, (size_t)B * 8), "lsa_malloc");
+        must(lsa_memcpy_h2d(m_ctx, d_r, r.data(), r.size() * 4), "h2d");
+        must(lsa_memcpy_h2d(m_ctx, d_bad, bad.data(), bad.size()), "h2d");
+        must(lsa_memcpy_h2d(m_ctx, d_ri, ri.data(), (size_t)B * 4), "h2d");
+        must(lsa_memcpy_h2d(m_ctx, d_ai, ai.data(), (size_t)B * 4), "h2d");
+        must(lsa_preprocess_batch(m_ctx, S, (float*)d_r, (uint8_t*)d_bad, (uint16_t*)d_seg), "lsa_preprocess_batch");
+        // the frames come back preprocessed, as pm_preprocessScan leaves them
+        must(lsa_memcpy_d2h(m_ctx, r.data(), d_r, r.size() * 4), "d2h");
+        must(lsa_memcpy_d2h(m_ctx, bad.data(), d_bad, bad.size()), "d2h");
+        must(lsa_memcpy_d2h(m_ctx, seg.data(), d_seg, seg.size() * 2), "d2h");
+        for (int k = 0; k < S; ++k) {
+            memcpy(m_SickScans[k]->r, &r[(size_t)k * n], sizeof(float) * n);
+            for (int i = 0; i < n; ++i) { m_SickScans[k]->bad[i] = bad[(size_t)k * n + i]; m_SickScans[k]->seg[i] = seg[(size_t)k * n + i]; }
+        }
+        vector<float> p_psm((size_t)B * 3), p_icp((size_t)B * 3), init((size_t)B * 6, 0.0f);
+        vector<int> st_psm(B), st_icp(B);
+        must(lsa_match_batch(m_ctx, LSA_MATCH_PSM, B, (float*)d_r, (uint8_t*)d_bad, (uint16_t*)d_seg, (int32_t*)d_ri, (int32_t*)d_ai,
+                             0, (float*)d_pose, 0, 0, 0, (int32_t*)d_st, 0), "lsa_match_batch");
+        must(lsa_memcpy_d2h(m_ctx, p_psm.data(), d_pose, (size_t)B * 12), "d2h");
+        must(lsa_memcpy_d2h(m_ctx, st_psm.data(), d_st, (size_t)B * 4), "d2h");
+        for (int b = 0; b < B; ++b)
+            if (st_psm[b] == 0) for (int d = 0; d < 3; ++d) init[(size_t)b * 6 + 3 + d] = p_psm[(size_t)b * 3 + d];
+        must(lsa_memcpy_h2d(m_ctx, d_init, init.data(), (size_t)B * 24), "h2d");
+        must(lsa_match_batch(m_ctx, LSA_MATCH_ICP, B, (float*)d_r, (uint8_t*)d_bad, (uint16_t*)d_seg, (int32_t*)d_ri, (int32_t*)d_ai,
+                             (float*)d_init, (float*)d_pose, 0, 0, 0, (int32_t*)d_st, 0), "lsa_match_batch");
+        must(lsa_memcpy_d2h(m_ctx, p_icp.data(), d_pose, (size_t)B * 12), "d2h");
+        must(lsa_memcpy_d2h(m_ctx, st_icp.data(), d_st, (size_t)B * 4), "d2h");
+        for (int b = 0; b < B; ++b) {
+            // pm_icp ok: its pose; pm_icp threw (the retry at :470-476 sees the same state and throws again): the pose
+            // pm_psm left, zero if that threw too
+            failed_pair[b] = st_icp[b] != 0;
+            for (int d = 0; d < 3; ++d) {
+                rel[(size_t)b * 3 + d] = st_icp[b] == 0 ? p_icp[(size_t)b * 3 + d] : init[(size_t)b * 6 + 3 + d];
+                init[(size_t)b * 6 + 3 + d] = rel[(size_t)b * 3 + d];
+            }
+        }
+        must(lsa_memcpy_h2d(m_ctx, d_init, init.data(), (size_t)B * 24), "h2d");
+        must(lsa_error_index2_batch(m_ctx, B, (float*)d_r, (uint8_t*)d_bad, (uint16_t*)d_seg, (int32_t*)d_ri, (int32_t*)d_ai,
+                                    (float*)d_init, (float*)d_exy, 0), "lsa_error_index2_batch");
+        must(lsa_memcpy_d2h(m_ctx, exy.data(), d_exy, (size_t)B * 8), "d2h");
+        lsa_free(d_r); lsa_free(d_bad); lsa_free(d_seg); lsa_free(d_ri); lsa_free(d_ai); lsa_free(d_pose); lsa_free(d_st);
+        lsa_free(d_init); lsa_free(d_exy);
+    } else if (S == 1) pm_preprocessScan(m_SickScans[0]);
+
     double rx = 0, ry = 0, th = 0;                                      // global pose, cm / rad
     PMScan* prev = 0;
     OrientedPoint2D last_odo;
     int n_gt = 0, n_angle = 0, n_err = 0;
-    for (int cnt = 0; cnt < (int)m_SickScans.size() && cnt < run_num; ++cnt) {
+    for (int cnt = 0; cnt < S; ++cnt) {
         PMScan* ls = m_SickScans[cnt];
-        pm_preprocessScan(ls);
         if (!prev) {
             last_odo = OrientedPoint2D(ls->rx, ls->ry, ls->th);
             rx = ls->rx * 100; ry = ls->ry * 100; th = ls->th;
@@ -448,21 +516,12 @@ void CPolarMatch::runlog(int run_num)
         bool bridge = big_turn;
         double xx = 0, yy = 0, tth = 0;
         if (!bridge) {
-            ls->rx = prev->rx = 0; ls->ry = prev->ry = 0; ls->th = prev->th = 0;      // no prior
-            bool failed = false;
-            try {
-                pm_error_index2(prev, ls);
-                pm_psm(prev, ls);
-                pm_icp(prev, ls);
-                pm_error_index2(prev, ls);
-            } catch (int) { cerr << "Error caught: psm failed match at: " << cnt + 1 << endl; failed = true; }
-            if (failed) {
-                failed = false;
-                try { pm_icp(prev, ls); }
-                catch (int) { cerr << "Error caught: icp failed match at: " << cnt + 1 << endl; failed = true; }
-            }
-            const pair<float, float> e = pm_error_index2(prev, ls);
-            const float err_idx = sqrtf(e.first + e.second);
+            const int b = cnt - 1;
+            prev->rx = prev->ry = prev->th = 0;
+            ls->rx = rel[(size_t)b * 3]; ls->ry = rel[(size_t)b * 3 + 1]; ls->th = rel[(size_t)b * 3 + 2];
+            const bool failed = failed_pair[b] != 0;
+            if (failed) cerr << "Error caught: matching failed at: " << cnt + 1 << endl;
+            const float err_idx = sqrtf(exy[(size_t)b * 2] + exy[(size_t)b * 2 + 1]);
             xx = ls->rx * cos(th) - ls->ry * sin(th) + rx;
             yy = ls->rx * sin(th) + ls->ry * cos(th) + ry;
             tth = th + ls->th;

@@ -250,3 +250,67 @@ def test_offline_driver_runlog_improved(exe, tmp_path):
     want = np.array(want)
     assert got.shape == want.shape and len(want) >= n - 3
     assert np.allclose(got, want, rtol=2e-5, atol=2e-5)          # the file holds 6 significant digits
+
+
+def test_offline_driver_runlog_flirt(exe, tmp_path):
+    """CPolarMatch::runFlirtFile -> runlog (ZHPolar_Match.cpp:332-341, 449-647) on the head of mit-cscail.log: the
+    drop-in batches the frames' matches (pm_psm, pm_icp from its result, pm_error_index2) and keeps only the
+    bookkeeping sequential; the trajectory file against the driver's logic replayed frame by frame with the oracle."""
+    from oracle_lib import Oracle
+    laser, fn, tag = SETS["mit"]
+    n = 40
+    out = str(tmp_path / "traj.log")
+    res = subprocess.run([exe, "runlog", "flirt", laser, os.path.join(GOLDEN, fn), out, str(n)],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    got = np.loadtxt(out).reshape(-1, 3)
+    o = Oracle(laser)
+    r_all, _, _, bad_all, pose_all = o.read_carmen(os.path.join(GOLDEN, fn), tag)
+
+    def ominus(a, b):       # a.ominus(b): b in a's frame
+        c, s = np.cos(a[2]), np.sin(a[2])
+        return np.array([(b[0] - a[0]) * c + (b[1] - a[1]) * s, -(b[0] - a[0]) * s + (b[1] - a[1]) * c, b[2] - a[2]])
+
+    def oplus(a, b):
+        c, s = np.cos(a[2]), np.sin(a[2])
+        return np.array([a[0] + b[0] * c - b[1] * s, a[1] + b[0] * s + b[1] * c, a[2] + b[2]])
+
+    want = []
+    prev = None
+    rx = ry = th = 0.0
+    last_odo = None
+    bridged = 0
+    for k in range(min(n, len(r_all))):
+        ls = o.preprocess(r_all[k], bad_all[k])
+        odo = pose_all[k].astype(np.float64)                         # PMScan keeps the log's pose as float
+        if prev is None:
+            last_odo = odo; rx, ry, th = odo[0] * 100, odo[1] * 100, odo[2]
+            want.append((odo[0], odo[1], th)); prev = ls
+            continue
+        big_turn = abs(odo[2] - th) > 0.6982
+        bridge = big_turn
+        if not bridge:
+            st, p_psm, _, _ = o.match(0, prev, ls)
+            init = p_psm if st == 0 else np.zeros(3, np.float32)
+            st2, p_icp, _, _ = o.match(1, prev, ls, (0, 0, 0), init)
+            failed = st2 != 0
+            rel = p_icp if st2 == 0 else init
+            exy, _ = o.error_index2(prev, ls, (0, 0, 0), rel)
+            err_idx = np.sqrt(np.float32(exy[0] + exy[1]))
+            xx = float(rel[0]) * np.cos(th) - float(rel[1]) * np.sin(th) + rx
+            yy = float(rel[0]) * np.sin(th) + float(rel[1]) * np.cos(th) + ry
+            tth = th + float(rel[2])
+            bridge = bool(err_idx > np.float32(10)) or (xx - rx) ** 2 + (yy - ry) ** 2 > 10000 or failed
+        if bridge:
+            bridged += 1
+            cur = oplus(np.array([rx / 100.0, ry / 100.0, th]), ominus(last_odo, odo))
+            rx, ry, th = cur[0] * 100, cur[1] * 100, cur[2]
+            want.append((cur[0], cur[1], cur[2]) if big_turn else (rx / 100.0, ry / 100.0, th))
+        else:
+            rx, ry, th = xx, yy, tth
+            want.append((xx / 100.0, yy / 100.0, tth))
+        prev = ls; last_odo = odo
+    want = np.array(want)
+    assert got.shape == want.shape == (min(n, len(r_all)), 3)
+    assert np.allclose(got, want, rtol=2e-5, atol=2e-5)          # the file holds 6 significant digits
+    assert bridged < len(want) // 2                                # most frames are matched, not bridged
