@@ -27,7 +27,7 @@ struct P2PParam {
     float thr_dist, thr_ang, alfa, smallest_thr;
 };
 
-constexpr int P2P_THREADS = 256, P2P_TILE = 2048;
+constexpr int P2P_THREADS = 256, P2P_TILE = 2048, P2P_LOCAL = 1024;   // clouds up to P2P_LOCAL points keep their pairing tables in LDS
 
 // deterministic block sum of `v` (double); result valid in every thread
 __device__ __forceinline__ double block_sum(double v, double* sh)
@@ -49,6 +49,8 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
 {
     __shared__ float2 tile[P2P_TILE];
     __shared__ uint16_t sid[P2P_TILE];                       // original index of the sorted first-map points
+    __shared__ unsigned long long lowner[P2P_LOCAL];         // small problems: owner / match tables here instead of in HBM
+    __shared__ int lmatch[P2P_LOCAL];
     __shared__ double sh[8];
     const int tid = threadIdx.x;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
@@ -76,7 +78,11 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
                 }
         }
         const int c0 = cur_off ? cur_off[b] : 0, n2 = cur_off ? cur_off[b + 1] - c0 : n_cur_shared;
-        int* const match_b = match + (cur_off ? (size_t)c0 : (size_t)b * n_cur_shared);       // per-problem scratch
+        // per-problem scratch: every iteration resets, scatters into and reads these tables - in LDS that costs no
+        // trip to memory (the addresses are generic: the same code runs on either)
+        const bool local = n1 <= P2P_LOCAL && n2 <= P2P_LOCAL;
+        int* const match_b = local ? lmatch : match + (cur_off ? (size_t)c0 : (size_t)b * n_cur_shared);
+        unsigned long long* const own_b = local ? lowner : owner + r0;
         double qx = init_pose[3 * b], qy = init_pose[3 * b + 1], qphi = init_pose[3 * b + 2];
         float thr_d = O.thr_dist, thr_a = O.thr_ang;
         int iter = 0, n_pairs = 0;
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
         bool keep = n1 > 0 && n2 > 0;
         while (keep && iter < O.max_iter) {
             const float cphi = (float)cos(qphi), sphi = (float)sin(qphi);
-            for (int j = tid; j < n1; j += P2P_THREADS) owner[r0 + j] = ~0ull;
+            for (int j = tid; j < n1; j += P2P_THREADS) own_b[j] = ~0ull;
             __syncthreads();
             // nearest first-map point of every second-map point
             for (int base = 0; base < n2; base += P2P_THREADS) {
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
                     if (best < lim2) {
                         mj = bj;
                         // the first-map point keeps its closest partner (ties: smaller index)
-                        atomicMin(&owner[r0 + bj], ((unsigned long long)f2u(best) << 32) | (unsigned)i);
+                        atomicMin(&own_b[bj], ((unsigned long long)f2u(best) << 32) | (unsigned)i);
                     }
                 }
                 if (i < n2) match_b[i] = mj;
@@ -153,11 +159,11 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
             double sq = 0;
             for (int i = tid; i < n2; i += P2P_THREADS) {
                 const int j = match_b[i];
-                if (j >= 0 && (unsigned)owner[r0 + j] == (unsigned)i) {
+                if (j >= 0 && (unsigned)own_b[j] == (unsigned)i) {
                     const double xa = ref_x[r0 + j], ya = ref_y[r0 + j], xb = cur_x[c0 + i], yb = cur_y[c0 + i];
                     s[0] += 1; s[1] += xa; s[2] += ya; s[3] += xb; s[4] += yb;
                     s[5] += xa * xb; s[6] += ya * yb; s[7] += xa * yb; s[8] += ya * xb;
-                    sq += (double)u2f((uint32_t)(owner[r0 + j] >> 32));
+                    sq += (double)u2f((uint32_t)(own_b[j] >> 32));
                 }
             }
             for (int k = 0; k < 9; ++k) s[k] = block_sum(s[k], sh);
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
             double h[4] = {0, 0, 0, 0};     // sum jx, sum jy, sum (jx^2 + jy^2), (n comes from n_pairs)
             for (int i = tid; i < n2; i += P2P_THREADS) {
                 const int j = match_b[i];
-                if (j >= 0 && (unsigned)owner[r0 + j] == (unsigned)i) {
+                if (j >= 0 && (unsigned)own_b[j] == (unsigned)i) {
                     const double xb = cur_x[c0 + i], yb = cur_y[c0 + i];
                     const double jx = -(ss * xb + cc * yb), jy = cc * xb - ss * yb;
                     h[0] += jx; h[1] += jy; h[2] += jx * jx + jy * jy;
