@@ -305,6 +305,7 @@ int lsa_ctx_set_param(lsa_ctx* c, const lsa_laser_param* p)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->p = *p;
+    if (c->d_trig) { hipFree(c->d_trig); c->d_trig = nullptr; }          // the point-to-line ICP's bearing table follows fi_min / dfi / points
     return upload_tables(c);
 }
 

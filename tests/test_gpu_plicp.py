@@ -115,3 +115,27 @@ def test_plicp_log_pairs_vs_oracle(name):
             restarted += want[5] > 10
     assert restarted > 0
     ctx.close()
+
+
+def test_plicp_follows_parameter_changes():
+    """The bearing table of the point-to-line ICP is cached per context: after lsa_ctx_set_param (what the CARMEN
+    readers' fi_min override ends in) it must be rebuilt - device against the oracle before and after the change."""
+    import torch
+    torch.zeros(1, device="cuda")
+    from laser_slam_amd import capi, synth
+    from oracle_lib import plicp
+    n_beams = 361
+    kw = dict(points=n_beams, fov_deg=270, max_range=3000, min_valid=90, window=60, fi_min_deg=-135, fi_max_deg=135)
+    p = capi.param_make(**kw)
+    ctx = capi.Context(p)
+    raw, _ = synth.make_scans(4, n_beams=n_beams)
+    a = capi.plicp_host(ctx, raw[0], raw[1])
+    wa = plicp(raw[0], raw[1], p.fi_min, p.dfi, p.min_range, p.max_range)
+    assert a[3] == wa[3] == 1.0 and np.allclose(a[:3], wa[:3], atol=5e-6)
+    p2 = capi.param_make(**dict(kw, fi_min_deg=-90, fi_max_deg=180))          # the same scans read with another zero bearing
+    ctx.set_param(p2)
+    b = capi.plicp_host(ctx, raw[0], raw[1])
+    wb = plicp(raw[0], raw[1], p2.fi_min, p2.dfi, p2.min_range, p2.max_range)
+    assert b[3] == wb[3] == 1.0 and np.allclose(b[:3], wb[:3], atol=5e-6)
+    assert np.abs(wb[:2] - wa[:2]).max() > 1e-3                                # the rotation of the frame is visible in the translation
+    ctx.close()

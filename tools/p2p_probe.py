@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Diagnostic: the ICP-goodness scorer's iteration counts and rate on the bench's pose cloud."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from laser_slam_amd import capi, synth
+import torch
+rng = np.random.default_rng(0)
+sx, sy, res = 800, 600, 0.05
+prob = np.full((sx, sy), 0.1, np.float32)
+prob[:, :3] = 0.9; prob[:, -3:] = 0.9; prob[:3, :] = 0.9; prob[-3:, :] = 0.9
+for _ in range(25):
+    a, b = rng.integers(20, sx - 60), rng.integers(20, sy - 60)
+    prob[a:a + rng.integers(6, 40), b:b + rng.integers(6, 40)] = 0.95
+ctx = capi.Context(capi.param_preset("LMS151"))
+fld = capi.Field(ctx, sx, sy, 0, 0, 0.0, 0.0, res)
+n, P = 541, 2048
+d_prob = torch.from_numpy(prob).cuda()
+centre = np.array([[20.0, 15.0, 0.3]], np.float32)
+poses = (centre + rng.normal(0, 1, (P, 3)) * [0.15, 0.15, 0.03]).astype(np.float32)
+d_c = torch.from_numpy(centre).cuda(); d_p = torch.from_numpy(poses).cuda()
+x = torch.zeros(1, n, device="cuda"); y = torch.zeros(1, n, device="cuda")
+r = torch.zeros(1, n, device="cuda"); bad = torch.zeros(1, n, dtype=torch.uint8, device="cuda")
+torch.cuda.synchronize()
+capi.simulate_scans(fld, d_prob, d_c, 1, n, r, bad); ctx.sync()
+ang = (-3.141592654 / 4.0 + np.arange(n) * (4.712388981 / (n - 1))).astype(np.float32)
+r1 = r.cpu().numpy()[0]
+d_ox = torch.from_numpy((r1 * np.cos(ang)).astype(np.float32)).cuda(); d_oy = torch.from_numpy((r1 * np.sin(ang)).astype(np.float32)).cuda()
+w = torch.zeros(P, device="cuda"); rel = torch.zeros(P, 3, device="cuda")
+capi.icp_goodness_scores(fld, d_prob, d_p, P, d_ox, d_oy, n, w, rel); ctx.sync()
+t0 = time.perf_counter(); capi.icp_goodness_scores(fld, d_prob, d_p, P, d_ox, d_oy, n, w, rel); ctx.sync(); dt = time.perf_counter() - t0
+print("goodness scorer: %.0f poses/s, mean weight %.3f, weight > 0.5: %.2f" % (P / dt, float(w.mean()), float((w > 0.5).float().mean())))
