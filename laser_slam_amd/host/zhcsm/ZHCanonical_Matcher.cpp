@@ -34,7 +34,6 @@ CCanonicalMatcher::~CCanonicalMatcher()
 {
     delete[] pm_fi; delete[] pm_si; delete[] pm_co;
     delete m_pKeyframe;
-    if (m_ctx) lsa_ctx_destroy(m_ctx);
     if (m_ownParam) delete m_pParam;
 }
 
@@ -58,10 +57,23 @@ bool CCanonicalMatcher::newKeyframeNeeded(double p[3])
     return x * x + y * y > threshold_dist_sq_;
 }
 
+// The reference builds one CCanonicalMatcher per pose node and never frees it (FlirterNode.cpp:75-168): a device
+// context (stream, tables, staging) per instance would pile up by the thousand.  All matchers of a thread share
+// one context, re-parameterised when a matcher with other laser parameters comes along; it lives as long as the thread.
+namespace {
+struct ThreadContext {
+    lsa_ctx* ctx;
+    ThreadContext() : ctx(0) {}
+    ~ThreadContext() { if (ctx) lsa_ctx_destroy(ctx); }
+};
+thread_local ThreadContext t_shared;
+}
+
 static lsa_ctx* ensure(lsa_ctx*& ctx, const Base_PARAM* p)
 {
     lsa_laser_param want = toCore(p);
-    if (!ctx) { must(lsa_ctx_create(&ctx, 0, &want), "lsa_ctx_create"); return ctx; }
+    if (!t_shared.ctx) must(lsa_ctx_create(&t_shared.ctx, 0, &want), "lsa_ctx_create");
+    ctx = t_shared.ctx;                                  // always the calling thread's context
     lsa_laser_param have;
     lsa_ctx_get_param(ctx, &have);
     if (have.points != want.points || have.max_range != want.max_range || have.fi_min != want.fi_min ||

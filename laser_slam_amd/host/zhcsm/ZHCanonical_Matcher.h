@@ -58,7 +58,7 @@ private:
     float matchPair(struct _PMScan* ref, struct _PMScan* cur);
     CCanonicalMatcher& operator=(const CCanonicalMatcher&);
     CCanonicalMatcher(const CCanonicalMatcher&);
-    lsa_ctx* m_ctx;
+    lsa_ctx* m_ctx;          // the thread's shared context (not owned)
     struct _PMScan* m_pKeyframe;     // internally owned copy, like the reference's LDP key frame
     bool m_ownParam, m_doCov;
     double m_cov[9];
