@@ -10,6 +10,13 @@ void must(int rc, const char* what)
 {
     if (rc != LSA_OK) throw std::runtime_error(std::string(what) + ": " + lsa_last_error());
 }
+
+// The maps of a thread share one device context (a grid needs it for its device and stream only): the reference
+// builds a CPMap per map node, and a stream plus tables per map would pile up.
+// It is never destroyed: a map with static storage duration is torn down after its thread's thread_local objects,
+// and its grid still needs the context then.
+struct ThreadContext { lsa_ctx* ctx; };
+thread_local ThreadContext t_shared = {0};
 }
 
 CPMap::CPMap(float prob_thre)
@@ -35,9 +42,12 @@ void CPMap::initializeMap(int size_x, int size_y, int start_x, int start_y, floa
     m_mapsum.assign(size_x, vector<float>(size_y, 0));
     m_mapprob.assign(size_x, vector<float>(size_y, 0));
     // the grid needs a context only for its device + stream; any valid laser block will do
-    lsa_laser_param p;
-    must(lsa_param_preset(&p, "LMS211"), "lsa_param_preset");
-    must(lsa_ctx_create(&m_ctx, 0, &p), "lsa_ctx_create");
+    if (!t_shared.ctx) {
+        lsa_laser_param p;
+        must(lsa_param_preset(&p, "LMS211"), "lsa_param_preset");
+        must(lsa_ctx_create(&t_shared.ctx, 0, &p), "lsa_ctx_create");
+    }
+    m_ctx = t_shared.ctx;
     must(lsa_grid_create(&m_grid, m_ctx, size_x, size_y, start_x, start_y, offset_x, offset_y, resolution), "lsa_grid_create");
 }
 
@@ -47,7 +57,7 @@ void CPMap::uninitMap()
     if (m_dx) { lsa_free(m_dx); lsa_free(m_dy); m_dx = m_dy = 0; m_dcap_pts = 0; }
     if (m_drob) { lsa_free(m_drob); lsa_free(m_dn); m_drob = m_dn = 0; m_dcap_scans = 0; }
     if (m_grid) { lsa_grid_destroy(m_grid); m_grid = 0; }
-    if (m_ctx) { lsa_ctx_destroy(m_ctx); m_ctx = 0; }
+    m_ctx = 0;                                           // (the thread's shared context stays)
 }
 
 // updateMap, PMap.cpp:46-91 (th is unused there as well); n < 0 == "finish"
