@@ -137,6 +137,17 @@ int ref_read_sick(void* hv, const char* filename)
     return (int)pm->m_SickScans.size();
 }
 
+// pm_is_corridor (ZHPolar_Match.cpp:2058-2186) on one preprocessed scan: 0 / 1, or 100 + the int it throws.
+int ref_is_corridor(void* hv, const float* r, const int* bad, const int* seg)
+{
+    CPolarMatch* pm = ((Handle*)hv)->pm;
+    const int n = pm->m_pParam->pm_l_points;
+    PMScan scan(n);
+    memcpy(scan.r, r, sizeof(float) * n); memcpy(scan.bad, bad, sizeof(int) * n); memcpy(scan.seg, seg, sizeof(int) * n);
+    try { return pm->pm_is_corridor(&scan) ? 1 : 0; }
+    catch (int e) { return 100 + e; }
+}
+
 // construct511Data (ZHPolar_Match.cpp:649-667): one "timestamp n r_1 .. r_n" [m] line; 1 = parsed.
 int ref_construct511(void* hv, const char* line, float* r, float* x, float* y, int* bad)
 {

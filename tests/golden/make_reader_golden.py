@@ -68,5 +68,36 @@ for k in range(Ss):
     refs.L.ref_get_scan(C.c_void_p(refs.h), k, rs[k].ctypes.data_as(C.c_void_p), xs[k].ctypes.data_as(C.c_void_p),
                         ys[k].ctypes.data_as(C.c_void_p), bs[k].ctypes.data_as(C.c_void_p), ps[k].ctypes.data_as(C.c_void_p))
 out.update(sick_r=rs, sick_x=xs, sick_y=ys, sick_bad=bs)
+# pm_is_corridor on the preprocessed scans of the golden sets (and on a few degenerate ones: it throws 3 / 2)
+from helpers import SETS, golden_param, load
+for name in ("mit", "fr079", "intel", "indoor"):
+    laser = SETS[name][0]
+    g = load(name); gp = golden_param(g)
+    rc = Ref(laser); rc.set_fimin_maxrange(np.float32(gp["fi_min"]), int(gp["max_range"]))
+    res = []
+    for k in range(g["pre_r"].shape[0]):
+        r_ = np.ascontiguousarray(g["pre_r"][k], f32); b_ = np.ascontiguousarray(g["pre_bad"][k], i32); s_ = np.ascontiguousarray(g["pre_seg"][k], i32)
+        res.append(rc.L.ref_is_corridor(C.c_void_p(rc.h), r_.ctypes.data_as(C.c_void_p), b_.ctypes.data_as(C.c_void_p), s_.ctypes.data_as(C.c_void_p)))
+    # a scan without any segment, and one with a single two-beam segment
+    z = np.zeros(g["pre_r"].shape[1], i32); one = z.copy(); one[10:12] = 1
+    r_ = np.ascontiguousarray(g["pre_r"][0], f32)
+    for s_ in (z, one):
+        res.append(rc.L.ref_is_corridor(C.c_void_p(rc.h), r_.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p), s_.ctypes.data_as(C.c_void_p)))
+    out["corridor_" + name] = np.array(res, i32)
+    print(name, "corridor flags:", np.bincount(np.array(res) % 100 if False else np.clip(res, 0, 103), minlength=2)[:2], "throws:", [v for v in res if v >= 100])
+# synthetic corridors and rooms (LMS511, 0..180 degrees): walls at +-w/2 beside the robot's heading, ends far away
+rc = Ref("LMS511")
+nn = 361
+th = np.deg2rad(np.linspace(0, 180, nn))
+syn_r, syn_b, syn_s, syn_res = [], [], [], []
+for k, (w, yaw, noise) in enumerate([(200, 0.0, 0.0), (200, 0.3, 0.5), (160, -0.2, 1.0), (300, 0.1, 3.0), (800, 0.0, 1.0), (200, 1.2, 0.5)]):
+    a = th - np.pi / 2 + yaw                                   # bearing relative to the corridor's axis
+    r = np.minimum((w / 2) / np.maximum(np.abs(np.sin(a)), 1e-3), 1500.0 if k != 4 else 500.0)
+    r = (r + rng.normal(0, noise, nn)).astype(f32)
+    r2, b2, s2 = rc.preprocess(r)
+    syn_r.append(r2); syn_b.append(b2); syn_s.append(s2)
+    syn_res.append(rc.L.ref_is_corridor(C.c_void_p(rc.h), r2.ctypes.data_as(C.c_void_p), b2.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p)))
+out.update(corridor_syn_r=np.stack(syn_r), corridor_syn_bad=np.stack(syn_b), corridor_syn_seg=np.stack(syn_s), corridor_syn=np.array(syn_res, i32))
+print("synthetic corridor flags:", syn_res)
 np.savez_compressed(os.path.join(HERE, "readers.npz"), **out)
 print("rawseed scans", S, "| 511 lines parsed", ok5)

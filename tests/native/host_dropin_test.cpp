@@ -188,8 +188,34 @@ static int run_readers(const char* kind, const char* laser, const char* file, co
     return 0;
 }
 
+// corridor <laser> <fi_min> <fi_max> <max_range> <in.bin> : in = int32 S, then per scan float r[n], int32 bad[n], int32 seg[n];
+// prints one number per scan: 0 / 1, or 100 + the int pm_is_corridor throws.  Needs no device.
+static int run_corridor(const char* laser, const char* fi_min, const char* fi_max, const char* max_range, const char* in)
+{
+    CPolarMatch m(laser);
+    if (strcmp(fi_min, "-")) {
+        m.m_pParam->pm_fi_min = (float)atof(fi_min); m.m_pParam->pm_fi_max = (float)atof(fi_max); m.m_pParam->pm_max_range = atoi(max_range);
+        m.pm_init();
+    }
+    const int n = m.m_pParam->pm_l_points;
+    FILE* f = fopen(in, "rb");
+    if (!f) return 2;
+    int S = 0;
+    if (fread(&S, 4, 1, f) != 1) return 3;
+    PMScan scan(n);
+    for (int k = 0; k < S; ++k) {
+        if (fread(scan.r, 4, n, f) != (size_t)n || fread(scan.bad, 4, n, f) != (size_t)n || fread(scan.seg, 4, n, f) != (size_t)n) return 3;
+        int res;
+        try { res = m.pm_is_corridor(&scan) ? 1 : 0; } catch (int e) { res = 100 + e; }
+        printf("%d\n", res);
+    }
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc >= 7 && !strcmp(argv[1], "corridor")) return run_corridor(argv[2], argv[3], argv[4], argv[5], argv[6]);
     if (argc >= 6 && !strcmp(argv[1], "readers")) return run_readers(argv[2], argv[3], argv[4], argv[5]);
     if (argc >= 6 && !strcmp(argv[1], "match")) return run_match(argv[2], argv[3], argv[4], atoi(argv[5]));
     if (argc >= 4 && !strcmp(argv[1], "pmap")) return run_pmap(argv[2], argv[3]);

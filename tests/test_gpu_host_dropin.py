@@ -155,48 +155,6 @@ def test_cpmap_dropin_queue(exe, tmp_path):
     print(res.stderr.strip().splitlines()[-1])               # the per-scan signature's rate, host buffers in
 
 
-def test_text_readers_vs_reference_fixtures(exe, tmp_path):
-    """CPolarMatch::readRawSeed, readSICK and construct511Data of the drop-in on synthetic files, against what the reference's
-    own readers (compiled in place, tests/golden/make_reader_golden.py) made of the same files."""
-    z = np.load(os.path.join(GOLDEN, "readers.npz"))
-    out = str(tmp_path / "rs.bin")
-    res = subprocess.run([exe, "readers", "rawseed", "LMS211", os.path.join(GOLDEN, "readers_rawseed.csv"), out],
-                         capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr[-2000:]
-    raw = open(out, "rb").read()
-    S = struct.unpack_from("<i", raw, 0)[0]
-    n = z["rawseed_r"].shape[1]
-    assert S == z["rawseed_r"].shape[0]
-    rec = np.frombuffer(raw, np.float32, S * 4 * n, 4).reshape(S, 4, n)
-    assert same_bits(rec[:, 0], z["rawseed_r"]) and same_bits(rec[:, 1], z["rawseed_x"]) and same_bits(rec[:, 2], z["rawseed_y"])
-    assert np.array_equal(rec[:, 3].view(np.int32), z["rawseed_bad"])
-    out = str(tmp_path / "sk.bin")
-    res = subprocess.run([exe, "readers", "sick", "LMS511", os.path.join(GOLDEN, "readers_sick.txt"), out],
-                         capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr[-2000:]
-    raw = open(out, "rb").read()
-    S = struct.unpack_from("<i", raw, 0)[0]
-    n = z["sick_r"].shape[1]
-    assert S == z["sick_r"].shape[0]
-    rec = np.frombuffer(raw, np.float32, S * 4 * n, 4).reshape(S, 4, n)
-    assert same_bits(rec[:, 0], z["sick_r"]) and same_bits(rec[:, 1], z["sick_x"]) and same_bits(rec[:, 2], z["sick_y"])
-    assert np.array_equal(rec[:, 3].view(np.int32), z["sick_bad"])
-    out = str(tmp_path / "t5.bin")
-    res = subprocess.run([exe, "readers", "511", "LMS511", os.path.join(GOLDEN, "readers_511.txt"), out],
-                         capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr[-2000:]
-    raw = open(out, "rb").read()
-    S = struct.unpack_from("<i", raw, 0)[0]
-    n = z["t511_r"].shape[1]
-    assert S == len(z["t511_ok"])
-    rec = np.frombuffer(raw, np.int32, S * (1 + 4 * n), 4).reshape(S, 1 + 4 * n)
-    assert np.array_equal(rec[:, 0], z["t511_ok"])
-    ok = z["t511_ok"] == 1
-    body = rec[:, 1:].reshape(S, 4, n)
-    assert np.array_equal(body[ok, 0], z["t511_r"][ok].view(np.int32)) and np.array_equal(body[ok, 1], z["t511_x"][ok].view(np.int32))
-    assert np.array_equal(body[ok, 2], z["t511_y"][ok].view(np.int32)) and np.array_equal(body[ok, 3], z["t511_bad"][ok])
-
-
 def test_offline_driver_runlog_improved(exe, tmp_path):
     """CPolarMatch::runOurFile -> runlogImproved (ZHPolar_Match.cpp:353-360, 736-852) on the in-house
     LMS151 log: the trajectory file against the same driver logic replayed with the CPU oracle."""
