@@ -614,3 +614,42 @@ def test_grid_survives_wild_end_points(torch_mod):
         part4.update(gx[s][keep[s]], gy[s][keep[s]], float(rob[s, 0]), float(rob[s, 1]))
     assert (g2.layers()[1] >= part4.layers()[1]).all() and (g2.layers()[0] >= part4.layers()[0]).all()
     g2.close(); grid.close(); ctx.close()
+
+
+def test_contexts_are_reentrant_across_threads(torch_mod):
+    """one matcher object per thread, several objects running concurrently.  Four threads, each with its
+    own context (own HIP stream and scratch), match, preprocess and score at the same time; every thread must get
+    the bits a lone context gets."""
+    import threading
+    torch = torch_mod
+    from laser_slam_amd import capi, synth
+    raw = np.concatenate([synth.make_scans(40, noise_seed=12345 + j)[0] for j in range(2)], 0)
+    S, n = raw.shape
+    base = np.array([(s * 40 + k - 1, s * 40 + k) for s in range(2) for k in range(1, 40)], np.int32)
+    B = 2048
+    sel = np.arange(B) % len(base)
+
+    def work(which, out, key):
+        ctx = capi.Context(capi.param_make(**synth.SYN1081))
+        d_r = torch.from_numpy(raw).cuda(); d_bad = torch.zeros(S, n, dtype=torch.uint8, device="cuda"); d_seg = torch.zeros(S, n, dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        ctx.preprocess_batch(S, d_r, d_bad, d_seg)
+        ri = torch.from_numpy(np.ascontiguousarray(base[sel, 0])).cuda(); ai = torch.from_numpy(np.ascontiguousarray(base[sel, 1])).cuda()
+        pose = torch.zeros(B, 3, device="cuda"); st = torch.zeros(B, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(3):
+            ctx.match_batch(which, B, d_r, d_bad, d_seg, ri, ai, pose, d_status=st)
+            ctx.sync()
+        out[key] = (pose.cpu().numpy().copy(), st.cpu().numpy().copy())
+        ctx.close()
+
+    ref = {}
+    work(1, ref, "icp"); work(0, ref, "psm")
+    res = {}
+    threads = [threading.Thread(target=work, args=(w, res, (w, t))) for t in range(2) for w in (0, 1)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert len(res) == 4
+    for (w, t), (pose, st) in res.items():
+        want = ref["icp" if w == 1 else "psm"]
+        assert np.array_equal(st, want[1]) and same_bits(pose, want[0]), (w, t)
