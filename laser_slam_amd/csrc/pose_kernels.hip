@@ -82,6 +82,18 @@ __global__ __launch_bounds__(256) void field_row_kernel(FieldParam F, const uint
     }
 }
 
+// x2idx / y2idx (VPmap.cpp:98-104): (int)(center + ((double)(r - off) + 0.0005) / res).  Multiplying by 1 / res is
+// within a few 1e-12 cells of the quotient, so the truncation can only differ next to a cell boundary: there the
+// division is redone (the same device as the scan simulator's march).
+__device__ __forceinline__ int field_idx(float r, float off, int center, double res, double inv_res)
+{
+    const double t = (double)(r - off) + 0.0005;
+    const double v = (double)center + t * inv_res;
+    const double f = v - floor(v);
+    if (__builtin_expect(!(f > 1e-6 && f < 1.0 - 1e-6), 0)) return (int)((double)center + t / res);
+    return (int)v;
+}
+
 // One thread per pose; scan points staged in LDS; log-likelihoods summed in beam order in double.
 __global__ __launch_bounds__(256) void score_poses_kernel(
     FieldParam F, const float* __restrict__ loglik, const float* __restrict__ sx, const float* __restrict__ sy,
@@ -96,6 +108,7 @@ __global__ __launch_bounds__(256) void score_poses_kernel(
     const double min_lik = (double)(0.05f / 50.0f) + (double)0.95f * exp(-0.5 / (0.35 * 0.35) * max_sq);   // :364
     const double log_min = log(min_lik);
     const unsigned sx1 = (unsigned)(F.size_x - 1), sy1 = (unsigned)(F.size_y - 1);
+    const double inv_res = 1.0 / F.res;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         const double px = poses[3 * (size_t)p], py = poses[3 * (size_t)p + 1];
         // th = normAngle(theta - M_PI/2, -M_PI), :366.  VPmap.cpp includes PolarParameter.h, so M_PI is
@@ -110,8 +123,8 @@ __global__ __launch_bounds__(256) void score_poses_kernel(
             const float2 q = pts[k];
             const float gx = (float)((double)(cs * q.x - sn * q.y) + px);      // :380
             const float gy = (float)((double)(-cs * q.y - sn * q.x) + py);     // :381
-            const int cx = (int)((double)F.center_x + ((double)(gx - F.off_x) + 0.0005) / F.res);   // x2idx :102-104
-            const int cy = (int)((double)F.center_y + ((double)(gy - F.off_y) + 0.0005) / F.res);
+            const int cx = field_idx(gx, F.off_x, F.center_x, F.res, inv_res);                     // x2idx :102-104
+            const int cy = field_idx(gy, F.off_y, F.center_y, F.res, inv_res);
             if ((unsigned)cx >= sx1 || (unsigned)cy >= sy1) acc += log_min;   // :388-392
             else acc += (double)loglik[(size_t)cx * F.size_y + cy];
         }
