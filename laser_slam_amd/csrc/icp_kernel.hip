@@ -607,7 +607,12 @@ __device__ __forceinline__ float ordered_sum(const float* arr, int cnt)
 // NC > 0: the beam count as a compile-time constant (the sensors' usual sizes), so that the LDS
 // layout and the trip counts are immediates instead of scalar registers; NC = 0: any size.
 template <int NC>
-__global__ __launch_bounds__(ICP_THREADS, LSA_ICP_WG_PER_CU) void icp_kernel(
+// up to 541 beams the LDS would allow more workgroups per CU than 96 registers do: eight (64 registers, some spills)
+// measured 9-14 % faster than five at 181 / 361 / 541 beams
+#ifndef LSA_ICP_WG_PER_CU_SMALL
+#define LSA_ICP_WG_PER_CU_SMALL 8
+#endif
+__global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PER_CU_SMALL) : (LSA_ICP_WG_PER_CU)) void icp_kernel(
     DevParam P_, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
     const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
     const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
