@@ -504,7 +504,12 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
 }
 
 // scans: [S][n] ranges in cm (PMScan::r); out8[b] = {x, y, theta (m, m, rad), valid, error, iterations, kept, 0}
-__global__ __launch_bounds__(PLICP_THREADS, 2) void plicp_kernel(PlicpParam P, int B, const float* __restrict__ g_r,
+// 128 registers: four workgroups per CU wherever the LDS allows (up to 541 beams; 1081 beams fit two and lose
+// nothing to the tighter register budget) - measured 11-18 % faster than 256 registers at 181 / 361 / 541 beams
+#ifndef LSA_PLICP_WG_PER_CU
+#define LSA_PLICP_WG_PER_CU 4
+#endif
+__global__ __launch_bounds__(PLICP_THREADS, LSA_PLICP_WG_PER_CU) void plicp_kernel(PlicpParam P, int B, const float* __restrict__ g_r,
                                                               const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
                                                               const double* __restrict__ trig, double* __restrict__ out8)
 {
