@@ -37,13 +37,14 @@ __device__ unsigned long long lsa_plicp_cycles[8];
 __device__ double lsa_plicp_trace[8 * 128];
 __device__ int lsa_plicp_trace_n;
 #endif
-__host__ __device__ inline int plicp_lds_bytes(int n) { int Np = (n + 63) & ~63; return Np * (6 * 8 + 4 + 4 + 4) + 1024 + 2 * 1088; }
+__host__ __device__ inline int plicp_lds_bytes(int n) { int Np = (n + 63) & ~63; return Np * (4 * 8 + 4 + 4 + 4) + 1024 + 2 * 1088; }   // 51 KB at 1081 beams: three workgroups per CU
 
 struct PlicpLds {
-    double *rx, *ry, *sx, *sy, *d2, *dist;                // ref / sens points, NN distance^2, segment distance
+    double *rx, *ry, *d2, *dist;                          // reference points (1e150 where invalid), NN distance^2, segment distance
+    float* sr;                                             // current scan's ranges in cm, -1 where invalid (the points are
+    const double* trig;                                    //   recomputed from these and the bearing table where they are used)
     uint16_t *nup, *ndown;                                 // next valid reference ray above / below (0xffff = none)
     int* corr;                                             // j1 | j2 << 16, -1 = none
-    uint8_t *rvalid, *svalid;
     unsigned long long* dj;                                // aliases `dist` during the doubles test
     double* red;                                           // reduction scratch, broadcast slots, remembered hashes
     int* hist;                                             // 2 x 264 ints of the radix select
@@ -203,6 +204,13 @@ __device__ bool plicp_gpm_multiplier(double trS, double detS, double hh, double 
     return plicp_quartic_largest_root(a3, a2, a1, a0, root);
 }
 
+// point i of the current scan in its own frame, exactly as the set-up computed it: cos | sin (host table) x r / 100
+__device__ __forceinline__ void plicp_sens_point(const PlicpLds& L, int n, int i, double& px, double& py)
+{
+    const double rm = (double)L.sr[i] / 100.0;
+    px = L.trig[i] * rm; py = L.trig[n + i] * rm;
+}
+
 // one icp_loop from q0; returns ok, x_new, total error, kept correspondences, iterations (all uniform)
 __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double q0[3], double x_new[3], double& total_error,
                            int& nvalid, int& iterations)
@@ -225,8 +233,10 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
         for (int i = tid; i < n; i += PLICP_THREADS) {
             int rec = -1;
             double best = 0;
-            if (L.svalid[i]) {
-                const double wx = cs * L.sx[i] - sn * L.sy[i] + x_old[0], wy = sn * L.sx[i] + cs * L.sy[i] + x_old[1];
+            if (L.sr[i] >= 0.0f) {
+                double spx, spy;
+                plicp_sens_point(L, n, i, spx, spy);
+                const double wx = cs * spx - sn * spy + x_old[0], wy = sn * spx + cs * spy + x_old[1];
                 int j1 = -1;
                 const double lim = P.max_correspondence_dist * P.max_correspondence_dist;
                 // The reference scans the window start_cell +- ceil((45 deg + atan(0.5 m / rho)) / res) around the
@@ -248,13 +258,13 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
                 int lo0 = 0, hi0 = -1, nseg = 1, lo1 = 0, hi1 = -1, lo2 = 0, hi2 = -1;
                 if (fast) {
                     double bound = lim;
-                    if (L.rvalid[c0f]) { const double d = plicp_dist2(wx, wy, L.rx[c0f], L.ry[c0f]); bound = d < bound ? d : bound; }
+                    if (L.rx[c0f] < 1e100) { const double d = plicp_dist2(wx, wy, L.rx[c0f], L.ry[c0f]); bound = d < bound ? d : bound; }
                     else {      // the nearest valid rays on either side of an invalid one (inside the +-45 deg of every window)
                         const int su = L.nup[c0f], sd = L.ndown[c0f];
                         if (su != 0xffff && su - c0f <= range_min - 8) { const double d = plicp_dist2(wx, wy, L.rx[su], L.ry[su]); bound = d < bound ? d : bound; }
                         if (sd != 0xffff && c0f - sd <= range_min - 8) { const double d = plicp_dist2(wx, wy, L.rx[sd], L.ry[sd]); bound = d < bound ? d : bound; }
                     }
-                    if (prev >= 0 && abs(prev - c0f) <= range_min - 8 && L.rvalid[prev]) { const double d = plicp_dist2(wx, wy, L.rx[prev], L.ry[prev]); bound = d < bound ? d : bound; }
+                    if (prev >= 0 && abs(prev - c0f) <= range_min - 8 && L.rx[prev] < 1e100) { const double d = plicp_dist2(wx, wy, L.rx[prev], L.ry[prev]); bound = d < bound ? d : bound; }
                     // a poor bound (a quarter of the point's range or more) would mean a scan of hundreds of rays that
                     // the whole wave waits for: a few more seeds at growing offsets usually find something closer
                     if (__ballot(bound > 0.0625 * (double)(rho_f * rho_f))) {
@@ -292,8 +302,8 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
                     from = from < 0 ? 0 : (from > n - 1 ? n - 1 : from); to = to < 0 ? 0 : (to > n - 1 ? n - 1 : to);
                     double bound = lim;
                     const int cen = start_cell < from ? from : (start_cell > to ? to : start_cell);
-                    if (L.rvalid[cen]) { const double d = plicp_dist2(wx, wy, L.rx[cen], L.ry[cen]); bound = d < bound ? d : bound; }
-                    if (prev >= from && prev <= to && L.rvalid[prev]) { const double d = plicp_dist2(wx, wy, L.rx[prev], L.ry[prev]); bound = d < bound ? d : bound; }
+                    if (L.rx[cen] < 1e100) { const double d = plicp_dist2(wx, wy, L.rx[cen], L.ry[cen]); bound = d < bound ? d : bound; }
+                    if (prev >= from && prev <= to && L.rx[prev] < 1e100) { const double d = plicp_dist2(wx, wy, L.rx[prev], L.ry[prev]); bound = d < bound ? d : bound; }
                     const double sb = sqrt(bound) * (1.0 + 1e-9) + 1e-12;
                     lo0 = from; hi0 = to;
 #ifdef LSA_PLICP_DIAG_FULLSCAN
@@ -374,7 +384,9 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
             double d = -1.0;
             if (L.corr[i] >= 0) {
                 const int j1 = L.corr[i] & 0xffff, j2 = L.corr[i] >> 16;
-                d = plicp_seg_dist(L.rx[j1], L.ry[j1], L.rx[j2], L.ry[j2], cs * L.sx[i] - sn * L.sy[i] + x_old[0], sn * L.sx[i] + cs * L.sy[i] + x_old[1]);
+                double spx, spy;
+                plicp_sens_point(L, n, i, spx, spy);
+                d = plicp_seg_dist(L.rx[j1], L.ry[j1], L.rx[j2], L.ry[j2], cs * spx - sn * spy + x_old[0], sn * spx + cs * spy + x_old[1]);
                 mine++;
             }
             L.dist[i] = d;                                  // -1 = no correspondence
@@ -408,7 +420,9 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
         for (int i = tid; i < n; i += PLICP_THREADS) {
             if (L.corr[i] < 0) continue;
             const int j1 = L.corr[i] & 0xffff, j2 = L.corr[i] >> 16;
-            const double px = L.sx[i], py = L.sy[i], qx = L.rx[j1], qy = L.ry[j1];
+            double px, py;
+            plicp_sens_point(L, n, i, px, py);
+            const double qx = L.rx[j1], qy = L.ry[j1];
             const double d0 = L.rx[j1] - L.rx[j2], d1 = L.ry[j1] - L.ry[j2];
             const double inv = 1 / sqrt(d0 * d0 + d1 * d1);
             const double n0 = d1 * inv, n1 = -d0 * inv;
@@ -516,13 +530,14 @@ __global__ __launch_bounds__(PLICP_THREADS, LSA_PLICP_WG_PER_CU) void plicp_kern
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = P.n, Np = (n + 63) & ~63, tid = threadIdx.x;
     PlicpLds L;
-    L.rx = (double*)smem; L.ry = L.rx + Np; L.sx = L.ry + Np; L.sy = L.sx + Np;
-    L.d2 = L.sy + Np; L.dist = L.d2 + Np; L.dj = (unsigned long long*)L.dist;
+    L.rx = (double*)smem; L.ry = L.rx + Np;
+    L.d2 = L.ry + Np; L.dist = L.d2 + Np; L.dj = (unsigned long long*)L.dist;
+    L.trig = trig;
     L.corr = (int*)(L.dist + Np);
-    L.rvalid = (uint8_t*)(L.corr + Np); L.svalid = L.rvalid + Np;       // (2 Np bytes inside the 4 Np reserved)
-    L.nup = (uint16_t*)(L.rvalid + 4 * Np); L.ndown = L.nup + Np;
-    L.red = (double*)(smem + (size_t)Np * (6 * 8 + 4 + 4 + 4));
-    L.hist = (int*)(smem + (size_t)Np * (6 * 8 + 4 + 4 + 4) + 1024);
+    L.sr = (float*)(L.corr + Np);
+    L.nup = (uint16_t*)(L.sr + Np); L.ndown = L.nup + Np;
+    L.red = (double*)(smem + (size_t)Np * (4 * 8 + 4 + 4 + 4));
+    L.hist = (int*)(smem + (size_t)Np * (4 * 8 + 4 + 4 + 4) + 1024);
     const double min_reading = P.min_range_cm / 100., max_reading = P.max_range_cm / 100.;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
@@ -534,15 +549,15 @@ __global__ __launch_bounds__(PLICP_THREADS, LSA_PLICP_WG_PER_CU) void plicp_kern
                 const double rm = valid ? r / 100.0 : -1.0;
                 if (valid && !(rm > min_reading && rm < max_reading)) valid = false;
                 const double x = cth * rm, y = sth * rm;
-                if (w) { L.sx[i] = x; L.sy[i] = y; L.svalid[i] = valid; }
-                else { L.rx[i] = valid ? x : 1e150; L.ry[i] = valid ? y : 1e150; L.rvalid[i] = valid; }     // (never read when invalid, except by the window scan)
+                if (w) L.sr[i] = valid ? (float)r : -1.0f;       // (the point is cth | sth x r / 100 again wherever it is used)
+                else { L.rx[i] = valid ? x : 1e150; L.ry[i] = valid ? y : 1e150; }     // (1e150: invalid; its distance exceeds every limit)
             }
         }
         __syncthreads();
         for (int j = tid; j < n; j += PLICP_THREADS) {                    // ld_next_valid_up / _down as tables
             int up = j + 1, down = j - 1;
-            while (up < n && !L.rvalid[up]) ++up;
-            while (down >= 0 && !L.rvalid[down]) --down;
+            while (up < n && !(L.rx[up] < 1e100)) ++up;
+            while (down >= 0 && !(L.rx[down] < 1e100)) --down;
             L.nup[j] = up < n ? (uint16_t)up : (uint16_t)0xffff;
             L.ndown[j] = down >= 0 ? (uint16_t)down : (uint16_t)0xffff;
         }
