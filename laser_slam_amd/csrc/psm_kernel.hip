@@ -260,7 +260,11 @@ __device__ __forceinline__ void load_pair_psm(const DevParam& P, Lds& L, const f
 #endif
 // NC > 0: the beam count as a compile-time constant (see icp_kernel)
 template <int NC>
-__global__ __launch_bounds__(PSM_THREADS, LSA_PSM_WG_PER_CU) void psm_kernel(
+// up to 541 beams the LDS leaves room for eight workgroups per CU (64 registers): 23-27 % faster than five there
+#ifndef LSA_PSM_WG_PER_CU_SMALL
+#define LSA_PSM_WG_PER_CU_SMALL 8
+#endif
+__global__ __launch_bounds__(PSM_THREADS, (NC > 0 && NC <= 541) ? (LSA_PSM_WG_PER_CU_SMALL) : (LSA_PSM_WG_PER_CU)) void psm_kernel(
     DevParam P_, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
     const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
     const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
