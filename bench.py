@@ -303,8 +303,8 @@ def extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p):
     ms = timed(lambda: capi.beam_model_scores(fld, d_prob, d_p, P2, d_or, d_ob, nb2, d_s2), reps=2)
     res["beam_model_poses_per_s"] = P2 / (ms * 1e-3)
     res["beam_model_rays_per_s"] = P2 * nb2 / (ms * 1e-3)
-    # ICP-goodness scorer (obsLikelyhood): virtual 541-beam scan + point-to-point ICP per pose, 2048 poses
-    P3 = 2048
+    # ICP-goodness scorer (obsLikelyhood): virtual 541-beam scan + point-to-point ICP per pose, 16384 poses
+    P3 = 16384
     ang = (-3.141592654 / 4.0 + np.arange(nb2) * (4.712388981 / (nb2 - 1))).astype(np.float32)
     d_r1 = torch.zeros(1, nb2, device="cuda"); d_b1 = torch.zeros(1, nb2, dtype=torch.uint8, device="cuda")
     d_c = torch.tensor([[10.0, 7.5, 0.0]], device="cuda")

@@ -1279,8 +1279,9 @@ int lsa_icp_goodness_scores(lsa_field* f, const float* d_prob, const float* d_po
                            n_poses, (float*)nullptr, (uint8_t*)nullptr, d_sx, d_sy);
         hipLaunchKernelGGL(lsa::iota_scaled_kernel, dim3((n_poses + 256) / 256), dim3(256), 0, c->stream, n_poses + 1, n_beams, d_off);
         lsa::P2PParam P = {o.max_iterations, o.threshold_dist, o.threshold_ang, o.alfa, o.smallest_threshold_dist};
-        hipLaunchKernelGGL(lsa::p2p_icp_kernel, dim3(n_poses), dim3(lsa::P2P_THREADS), 0, c->stream, P, n_poses, d_sx, d_sy, d_off,
-                           d_obs_x, d_obs_y, (const int*)nullptr, d_init, d_owner, d_match, d_out, n_beams);
+        const int cap = lsa::p2p_cap_for(n_beams);
+        hipLaunchKernelGGL(lsa::p2p_icp_kernel, dim3(n_poses), dim3(lsa::P2P_THREADS), lsa::p2p_lds_bytes(cap), c->stream, P, n_poses, d_sx, d_sy, d_off,
+                           d_obs_x, d_obs_y, (const int*)nullptr, d_init, d_owner, d_match, d_out, n_beams, cap);
         hipLaunchKernelGGL(lsa::icp_goodness_extract_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, c->stream, n_poses, d_out,
                            d_weight, d_rel_pose);
         e = hipGetLastError();
@@ -1489,8 +1490,9 @@ int lsa_p2p_icp_batch(lsa_ctx* c, int B, const float* d_ref_x, const float* d_re
     int* d_match = (int*)(d_owner + nro);
     hipError_t e = hipSuccess;
     lsa::P2PParam P = {o.max_iterations, o.threshold_dist, o.threshold_ang, o.alfa, o.smallest_threshold_dist};
-    hipLaunchKernelGGL(lsa::p2p_icp_kernel, dim3(B), dim3(lsa::P2P_THREADS), 0, c->stream, P, B, d_ref_x, d_ref_y,
-                       d_ref_off, d_cur_x, d_cur_y, d_cur_off, d_init_pose, d_owner, d_match, d_out16, 0);
+    const int cap = lsa::p2p_cap_for(n_ref_total > n_cur_total ? n_ref_total : n_cur_total);      // (no cloud is larger than the totals)
+    hipLaunchKernelGGL(lsa::p2p_icp_kernel, dim3(B), dim3(lsa::P2P_THREADS), lsa::p2p_lds_bytes(cap), c->stream, P, B, d_ref_x, d_ref_y,
+                       d_ref_off, d_cur_x, d_cur_y, d_cur_off, d_init_pose, d_owner, d_match, d_out16, 0, cap);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(LSA_E_HIP, "p2p_icp_kernel", e);

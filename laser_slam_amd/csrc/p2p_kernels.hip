@@ -29,6 +29,13 @@ struct P2PParam {
 
 constexpr int P2P_THREADS = 256, P2P_TILE = 2048, P2P_LOCAL = 1024;   // clouds up to P2P_LOCAL points keep their pairing tables in LDS
 
+// LDS of a launch whose largest cloud has `cap` points (a power of two, 64 .. P2P_TILE): the sorted first map, its
+// original indices, and - up to P2P_LOCAL points - the pairing tables.  Sized per launch: at 541 points a workgroup
+// needs 14 KB instead of the 32 KB of the largest case, and eight of them share a CU instead of five.
+__host__ __device__ inline int p2p_local_cap(int cap) { return cap < P2P_LOCAL ? cap : P2P_LOCAL; }
+__host__ __device__ inline int p2p_lds_bytes(int cap) { return cap * (8 + 2) + p2p_local_cap(cap) * (8 + 4); }
+__host__ inline int p2p_cap_for(int n_max) { int c = 64; while (c < n_max && c < P2P_TILE) c <<= 1; return c; }
+
 // deterministic block sum of `v` (double); result valid in every thread
 __device__ __forceinline__ double block_sum(double v, double* sh)
 {
@@ -45,17 +52,19 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
     P2PParam O, int B, const float* __restrict__ ref_x, const float* __restrict__ ref_y, const int* __restrict__ ref_off,
     const float* __restrict__ cur_x, const float* __restrict__ cur_y, const int* __restrict__ cur_off,
     const double* __restrict__ init_pose, unsigned long long* __restrict__ owner, int* __restrict__ match,
-    double* __restrict__ out, int n_cur_shared /* cur_off == nullptr: every problem aligns the same second map */)
+    double* __restrict__ out, int n_cur_shared /* cur_off == nullptr: every problem aligns the same second map */,
+    int cap /* LDS sized for clouds of up to this many points (p2p_lds_bytes); larger first maps are streamed in tiles of it */)
 {
-    __shared__ float2 tile[P2P_TILE];
-    __shared__ uint16_t sid[P2P_TILE];                       // original index of the sorted first-map points
-    __shared__ unsigned long long lowner[P2P_LOCAL];         // small problems: owner / match tables here instead of in HBM
-    __shared__ int lmatch[P2P_LOCAL];
+    extern __shared__ __attribute__((aligned(16))) char p2p_smem[];
+    float2* tile = (float2*)p2p_smem;
+    unsigned long long* lowner = (unsigned long long*)(tile + cap);          // small problems: owner / match tables here instead of in HBM
+    int* lmatch = (int*)(lowner + p2p_local_cap(cap));
+    uint16_t* sid = (uint16_t*)(lmatch + p2p_local_cap(cap));                // original index of the sorted first-map points
     __shared__ double sh[8];
     const int tid = threadIdx.x;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const int r0 = ref_off[b], n1 = ref_off[b + 1] - r0;
-        const bool sorted = n1 > 0 && n1 <= P2P_TILE;
+        const bool sorted = n1 > 0 && n1 <= cap;
         if (sorted) {                                        // first map by (x, original index), padded with +inf to a power of two
             int npad = 1;
             while (npad < n1) npad <<= 1;
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
         const int c0 = cur_off ? cur_off[b] : 0, n2 = cur_off ? cur_off[b + 1] - c0 : n_cur_shared;
         // per-problem scratch: every iteration resets, scatters into and reads these tables - in LDS that costs no
         // trip to memory (the addresses are generic: the same code runs on either)
-        const bool local = n1 <= P2P_LOCAL && n2 <= P2P_LOCAL;
+        const bool local = n1 <= p2p_local_cap(cap) && n2 <= p2p_local_cap(cap);
         int* const match_b = local ? lmatch : match + (cur_off ? (size_t)c0 : (size_t)b * n_cur_shared);
         unsigned long long* const own_b = local ? lowner : owner + r0;
         double qx = init_pose[3 * b], qy = init_pose[3 * b + 1], qphi = init_pose[3 * b + 2];
@@ -131,8 +140,8 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
                         }
                     }
                 } else
-                for (int t0 = 0; t0 < n1; t0 += P2P_TILE) {
-                    const int tn = n1 - t0 < P2P_TILE ? n1 - t0 : P2P_TILE;
+                for (int t0 = 0; t0 < n1; t0 += cap) {
+                    const int tn = n1 - t0 < cap ? n1 - t0 : cap;
                     __syncthreads();
                     for (int k = tid; k < tn; k += P2P_THREADS) tile[k] = make_float2(ref_x[r0 + t0 + k], ref_y[r0 + t0 + k]);
                     __syncthreads();

@@ -15,7 +15,7 @@ for _ in range(25):
     prob[a:a + rng.integers(6, 40), b:b + rng.integers(6, 40)] = 0.95
 ctx = capi.Context(capi.param_preset("LMS151"))
 fld = capi.Field(ctx, sx, sy, 0, 0, 0.0, 0.0, res)
-n, P = 541, 2048
+n, P = 541, int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 d_prob = torch.from_numpy(prob).cuda()
 centre = np.array([[20.0, 15.0, 0.3]], np.float32)
 poses = (centre + rng.normal(0, 1, (P, 3)) * [0.15, 0.15, 0.03]).astype(np.float32)
