@@ -11,7 +11,12 @@ from laser_slam_amd import capi, synth
 from oracle_lib import SYN1081, Oracle
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
-raw = np.concatenate([synth.make_scans(60, noise_seed=synth.WORLD_SEED + 500 + j)[0] for j in range(6)], 0)
+NB = int(sys.argv[3]) if len(sys.argv) > 3 else 1081          # 1081 (the benchmark sensor) or one of the reference's sizes
+if NB != 1081:
+    _w = {181: 20, 361: 40, 541: 50}[NB]
+    SYN1081 = dict(points=NB, fov_deg=270, max_range=3000, min_valid=NB // 4, window=_w, fi_min_deg=-135, fi_max_deg=135)
+    synth.SYN1081 = SYN1081
+raw = np.concatenate([synth.make_scans(60, noise_seed=synth.WORLD_SEED + 500 + j, **({} if NB == 1081 else dict(n_beams=NB)))[0] for j in range(6)], 0)
 o = Oracle(**SYN1081)
 pre = [o.preprocess(raw[k]) for k in range(len(raw))]
 r = np.stack([q[0] for q in pre]); bad = np.stack([q[1] for q in pre]); seg = np.stack([q[2] for q in pre])
