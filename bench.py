@@ -34,8 +34,9 @@ def build_scan_set(n_scans, seeds):
     return np.concatenate(sets, 0)
 
 
-def cpu_baseline(raw, n_pairs, which):
-    """Time the CPU path on a bounded sample of the same workload (rank 0 only)."""
+def cpu_baseline(raw, n_pairs, which, gpu_match=None):
+    """Time the CPU path on a bounded sample of the same workload (rank 0 only).  With `gpu_match` the device's
+    poses for the very same pairs are set against the CPU's: BASELINE.json's "pose RMSE vs CPU ref"."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     from laser_slam_amd import synth
@@ -43,15 +44,25 @@ def cpu_baseline(raw, n_pairs, which):
     eng = oracle_lib.Ref(**synth.SYN1081) if use_ref else oracle_lib.Oracle(**synth.SYN1081)
     pre = [eng.preprocess(raw[k]) for k in range(n_pairs + 1)]
     t0 = time.perf_counter()
-    ok = 0
+    cpu_pose = np.zeros((n_pairs, 3), np.float32); cpu_st = np.zeros(n_pairs, np.int32)
     for b in range(n_pairs):
         res = eng.match(which, pre[b], pre[b + 1])
-        ok += res[0] == 0
+        cpu_st[b] = res[0]; cpu_pose[b] = res[1]
     dt = time.perf_counter() - t0
-    return {"value": n_pairs / dt, "unit": "scan-matches/s", "cores": 1,
-            "kind": "reference" if use_ref else "port",
-            "sample": "%d consecutive synthetic 1081-beam pairs, pm_icp, single thread, preprocessing excluded (%.1f s)"
-                      % (n_pairs, dt)}
+    out = {"value": n_pairs / dt, "unit": "scan-matches/s", "cores": 1,
+           "kind": "reference" if use_ref else "port",
+           "sample": "%d consecutive synthetic 1081-beam pairs, pm_icp, single thread, preprocessing excluded (%.1f s)"
+                     % (n_pairs, dt)}
+    if gpu_match is not None:
+        g_pose, g_st = gpu_match(n_pairs)
+        ok = (cpu_st == 0) & (g_st == 0)
+        d = (g_pose[ok].astype(np.float64) - cpu_pose[ok].astype(np.float64))
+        out["pose_rmse_vs_cpu"] = {
+            "pairs": int(n_pairs), "matched_by_both": int(ok.sum()), "status_mismatches": int(((cpu_st == 0) != (g_st == 0)).sum()),
+            "xy_m": float(np.sqrt(np.mean(d[:, 0] ** 2 + d[:, 1] ** 2)) * 0.01) if ok.any() else None,
+            "theta_rad": float(np.sqrt(np.mean(d[:, 2] ** 2))) if ok.any() else None,
+            "bit_identical": bool(np.array_equal(g_pose[ok].view(np.uint32), cpu_pose[ok].view(np.uint32)))}
+    return out
 
 
 def main():
@@ -179,7 +190,13 @@ def main():
         if args.extras:
             out["extras"] = extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p)
         if not args.no_cpu and world == 1:                   # (rank 0 at N = 1 only: the other ranks would wait for it)
-            out["cpu_baseline"] = cpu_baseline(raw, args.cpu_pairs, 1 if which == capi.MATCH_ICP else 0)
+            def gpu_match(m):                              # the CPU sample's pairs (k, k + 1) on the device
+                ri = torch.arange(0, m, dtype=torch.int32, device="cuda"); ai = ri + 1
+                gp = torch.zeros(m, 3, device="cuda"); gs = torch.zeros(m, dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
+                ctx.match_batch(which, m, d_r, d_bad, d_seg, ri, ai, gp, d_status=gs); ctx.sync()
+                return gp.cpu().numpy(), gs.cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(raw, args.cpu_pairs, 1 if which == capi.MATCH_ICP else 0, gpu_match)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
