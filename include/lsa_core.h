@@ -19,7 +19,18 @@
  *    one-instance-per-thread, src/slam/threadLocal1.cpp:144).
  *  - there is NO CPU fallback: without a HIP device every call fails with
  *    LSA_E_NODEVICE.
+ *
+ * Limits a caller must respect (checked, LSA_E_ARG otherwise)
+ *  - beams per scan (lsa_laser_param.points): 8 .. LSA_MAX_POINTS (1280).  The matchers keep a whole
+ *    scan pair in one workgroup's LDS; 1280 beams is what fits at the occupancy the kernels are tuned for.
+ *  - pm_icp trims the worst 20 % of its matches (ZHPolar_Match.cpp:1836): (int)(0.2 * points) must not
+ *    exceed LSA_MAX_TRIM (256), which 1280 beams satisfy exactly.
+ *  - scan sets, pair lists and outputs of the batched calls must live on the context's device.
+ *  - lsa_ctx_create takes the device index explicitly; the C++ drop-in classes bind to device 0 unless the
+ *    environment variable LSA_DEVICE names another one (one matcher object per thread, one device per object).
  */
+#define LSA_MAX_POINTS 1280
+#define LSA_MAX_TRIM   256
 #ifndef LSA_CORE_H
 #define LSA_CORE_H
 
@@ -71,6 +82,8 @@ typedef struct lsa_grid lsa_grid;
 /* ---- library / device ---------------------------------------------------- */
 const char* lsa_version(void);
 int lsa_device_count(void);
+/* device the C++ drop-in classes bind to: the value of the environment variable LSA_DEVICE, else 0 */
+int lsa_default_device(void);
 const char* lsa_last_error(void);
 
 /* ---- parameters: Base_PARAM ctor + presets (PolarParameter.h:57-83),
@@ -99,6 +112,11 @@ int lsa_free(void* d_ptr);
 int lsa_memcpy_h2d(lsa_ctx* c, void* d_dst, const void* h_src, uint64_t bytes);
 int lsa_memcpy_d2h(lsa_ctx* c, void* h_dst, const void* d_src, uint64_t bytes);
 int lsa_memset(lsa_ctx* c, void* d_dst, int value, uint64_t bytes);
+/* One grow-only device block per context for the CALLER's temporaries (the drop-in's log drivers carve their scan
+ * set, pair lists and result arrays from it instead of nine lsa_malloc / lsa_free per call).  The pointer stays valid
+ * until the next lsa_ctx_arena call on the same context that asks for more bytes (contents are then lost), and the
+ * block is freed with the context.  Distinct from the library's own internal scratch. */
+int lsa_ctx_arena(lsa_ctx* c, uint64_t bytes, void** d_ptr);
 
 /* ---- CARMEN reader: CPolarMatch::readCarmon, ZHPolar_Match.cpp:172-284 ------
  * Host-side text parsing into SoA host arrays (malloc'd, free with lsa_host_free).
@@ -288,6 +306,16 @@ int lsa_plicp_batch(lsa_ctx* c, int n_pairs, const float* d_r, const int32_t* d_
                     const lsa_plicp_options* opt, double* d_out8);
 /* CCanonicalMatcher::FMatch(LDP, LDP) (ZHCanonical_Matcher.cpp:248-284) for one pair of host scans */
 int lsa_plicp_host(lsa_ctx* c, const float* h_ref_r, const float* h_cur_r, const lsa_plicp_options* opt, double h_out8[8]);
+/* The same with sm_icp's covariance of the result (sm_params.do_compute_covariance, CCanonicalMatcher::setCov ->
+ * FMatchKeyFrame2 reads sm_result.cov_x_m, ZHCanonical_Matcher.cpp:79-81, 287-298; it feeds the UKF at
+ * tcp_slam/clientFrontend.cpp:282): d_cov9 [B][9] = row-major 3x3 over (x [m], y [m], theta [rad]) =
+ * sigma^2 H^-1 (A1 A1^T + A2 A2^T) H^-1 (A. Censi, "An accurate closed-form estimate of ICP's covariance", ICRA 2007)
+ * over the final correspondences; sigma = sm_params.sigma (0.04 m in the reference, :104).  A failed pair gets zeros.
+ * d_cov9 / h_cov9 NULL = lsa_plicp_batch / lsa_plicp_host. */
+int lsa_plicp_batch_cov(lsa_ctx* c, int n_pairs, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
+                        const lsa_plicp_options* opt, double sigma, double* d_out8, double* d_cov9);
+int lsa_plicp_host_cov(lsa_ctx* c, const float* h_ref_r, const float* h_cur_r, const lsa_plicp_options* opt, double sigma,
+                       double h_out8[8], double h_cov9[9]);
 
 /* ---- point-to-point ICP on 2D point clouds: CICPWarpper, src/zhicp/ZHIcp_Warpper.{h,cpp}
  *      (forwards to MRPT 0.9.6 CICP::Align, icpClassic — third-party, PARITY UNPINNED) ---- */

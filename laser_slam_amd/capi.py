@@ -109,6 +109,9 @@ def lib():
     L.lsa_beam_model_scores.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, vp]
     L.lsa_plicp_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.lsa_plicp_host.argtypes = [vp, vp, vp, vp, vp]
+    L.lsa_plicp_batch_cov.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_double, vp, vp]
+    L.lsa_plicp_host_cov.argtypes = [vp, vp, vp, vp, C.c_double, vp, vp]
+    L.lsa_ctx_arena.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     L.lsa_icp_goodness_scores.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp, vp]
     L.lsa_gather_poses.argtypes = [vp, vp, vp, C.c_int, vp]
     L.lsa_p2p_icp_host.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp]
@@ -485,6 +488,19 @@ def gather_poses(ctx, d_src, d_parent, M, d_dst):
 def plicp_batch(ctx, B, d_r, d_ref_idx, d_act_idx, d_out8):
     """CCanonicalMatcher's point-to-line ICP for B pairs of the device scan set d_r (cm); d_out8 [B][8] doubles."""
     check(lib().lsa_plicp_batch(ctx.h, B, _dp(d_r), _dp(d_ref_idx), _dp(d_act_idx), None, _dp(d_out8)), "lsa_plicp_batch")
+
+
+def plicp_batch_cov(ctx, B, d_r, d_ref_idx, d_act_idx, sigma, d_out8, d_cov9):
+    """lsa_plicp_batch_cov: the batch above plus sm_icp's covariance per pair (d_cov9 [B][9] doubles)."""
+    check(lib().lsa_plicp_batch_cov(ctx.h, B, _dp(d_r), _dp(d_ref_idx), _dp(d_act_idx), None, float(sigma), _dp(d_out8),
+                                    _dp(d_cov9)), "lsa_plicp_batch_cov")
+
+
+def plicp_host_cov(ctx, ref_r, cur_r, sigma=0.04):
+    a = np.ascontiguousarray(ref_r, np.float32); b = np.ascontiguousarray(cur_r, np.float32)
+    out = np.zeros(8, np.float64); cov = np.zeros(9, np.float64)
+    check(lib().lsa_plicp_host_cov(ctx.h, _hp(a), _hp(b), None, float(sigma), _hp(out), _hp(cov)), "lsa_plicp_host_cov")
+    return out, cov.reshape(3, 3)
 
 
 def plicp_host(ctx, ref_r, cur_r):

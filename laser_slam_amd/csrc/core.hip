@@ -56,6 +56,8 @@ struct lsa_ctx {
     char* d_stage = nullptr;
     char* h_stage = nullptr;
     size_t stage_bytes = 0, off_seg = 0, off_bad = 0, off_small = 0, off_ismall = 0, off_idx = 0;
+    char* d_arena = nullptr;     // grow-only block handed to the caller (lsa_ctx_arena)
+    size_t arena_cap = 0;
     char* d_scratch = nullptr;   // grow-only scratch of the calls that need large temporaries (a context serves one thread)
     size_t scratch_cap = 0;
     double* d_trig = nullptr;    // point-to-line ICP: cos | sin of the beam bearings in double, 2*N (host libm, as CSM's ld_compute_cartesian on the CPU)
@@ -86,10 +88,10 @@ static int pre_lds(int n) { int Np = (n + 63) & ~63; return 12 * Np; }
 static int check_param(const lsa_laser_param* p)
 {
     if (!p) return fail(LSA_E_ARG, "null laser parameter block");
-    if (p->points < 8 || p->points > 1280) return fail(LSA_E_ARG, "points must be in [8,1280]");
+    if (p->points < 8 || p->points > LSA_MAX_POINTS) return fail(LSA_E_ARG, "points must be in [8,1280] (LSA_MAX_POINTS)");
     if (p->window < 1 || 2 * p->window + 1 > ((p->points + 63) & ~63))
         return fail(LSA_E_ARG, "scan window must satisfy 2W+1 <= points (rounded up to 64)");
-    if ((int)(p->points * 0.2) > 256) return fail(LSA_E_ARG, "trim pool supports at most 256 dropped pairs");
+    if ((int)(p->points * 0.2) > LSA_MAX_TRIM) return fail(LSA_E_ARG, "trim pool supports at most 256 dropped pairs (LSA_MAX_TRIM)");
     if (!(p->dfi > 0)) return fail(LSA_E_ARG, "dfi must be positive");
     return LSA_OK;
 }
@@ -153,7 +155,7 @@ int lsa_debug_plicp_trace(double* out, int* n)
 }
 #endif
 
-const char* lsa_version(void) { return "laser_slam_amd 0.1 (gfx950)"; }
+const char* lsa_version(void) { return "laser_slam_amd 0.2 (gfx950)"; }
 
 const char* lsa_last_error(void) { return g_err.c_str(); }
 
@@ -162,6 +164,12 @@ int lsa_device_count(void)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int lsa_default_device(void)
+{
+    const char* e = getenv("LSA_DEVICE");
+    return e && *e ? atoi(e) : 0;
 }
 
 // ---- parameters (host) ----------------------------------------------------
@@ -226,7 +234,7 @@ static int ensure_staging(lsa_ctx* c)
     c->off_seg = sizeof(float) * 2 * (size_t)n;
     c->off_bad = c->off_seg + sizeof(uint16_t) * 2 * (size_t)n;
     c->off_small = (c->off_bad + 2 * (size_t)n + 15) & ~(size_t)15;
-    c->off_ismall = c->off_small + sizeof(float) * 32;                  // small[16..21]: min/max slots of lsa_pf_roughen
+    c->off_ismall = c->off_small + sizeof(float) * 48;                  // small[16..21]: min/max slots of lsa_pf_roughen; the point-to-line ICP's 17 doubles
     c->off_idx = c->off_ismall + sizeof(int) * 4;
     c->stage_bytes = c->off_idx + sizeof(int) * 2;
     HIP_TRY(hipMalloc((void**)&c->d_stage, c->stage_bytes));
@@ -348,6 +356,7 @@ void lsa_ctx_destroy(lsa_ctx* c)
     if (c->d_stage) hipFree(c->d_stage);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->d_scratch) hipFree(c->d_scratch);
+    if (c->d_arena) hipFree(c->d_arena);
     delete c;
 }
 
@@ -367,6 +376,20 @@ static int ctx_scratch(lsa_ctx* c, size_t bytes, char** out)
 }
 
 // ---- memory helpers ---------------------------------------------------------
+int lsa_ctx_arena(lsa_ctx* c, uint64_t bytes, void** d_ptr)
+{
+    if (!c || !d_ptr) return fail(LSA_E_ARG, "null argument");
+    if (c->arena_cap < bytes) {
+        HIP_TRY(hipSetDevice(c->device));
+        if (c->d_arena) { HIP_TRY(hipStreamSynchronize(c->stream)); hipFree(c->d_arena); c->d_arena = nullptr; c->arena_cap = 0; }
+        const size_t cap = (size_t)bytes + (size_t)bytes / 4 + 4096;
+        hipError_t e = hipMalloc((void**)&c->d_arena, cap);
+        if (e != hipSuccess) return fail(LSA_E_NOMEM, "hipMalloc(arena)", e);
+        c->arena_cap = cap;
+    }
+    *d_ptr = c->d_arena;
+    return LSA_OK;
+}
 int lsa_malloc(void** d, uint64_t bytes)
 {
     if (!d) return fail(LSA_E_ARG, "null output");
@@ -1400,8 +1423,28 @@ int lsa_plicp_options_default(lsa_plicp_options* o)                  // ZHCanoni
     return LSA_OK;
 }
 
-int lsa_plicp_batch(lsa_ctx* c, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
-                    const lsa_plicp_options* opt, double* d_out8)
+extern "C++" {
+template <int WG, bool COV>
+static int plicp_launch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
+                        double* d_out8, double sigma, double* d_cov9)
+{
+    {   // more than 64 KB of dynamic LDS: opt in once per device and instance (contexts of several devices may live in one process)
+        static std::atomic<unsigned long long> done{0};
+        const unsigned long long bit = 1ull << (c->device & 63);
+        if (!(done.load(std::memory_order_acquire) & bit)) {
+            HIP_TRY(hipFuncSetAttribute((const void*)lsa::plicp_kernel<WG, COV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            done.fetch_or(bit, std::memory_order_release);
+        }
+    }
+    hipLaunchKernelGGL((lsa::plicp_kernel<WG, COV>), dim3(B), dim3(lsa::PLICP_THREADS), lsa::plicp_lds_bytes(P.n), c->stream, P, B, d_r,
+                       d_ref_idx, d_act_idx, c->d_trig, d_out8, sigma, d_cov9);
+    HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+}   // extern "C++"
+
+int lsa_plicp_batch_cov(lsa_ctx* c, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
+                        const lsa_plicp_options* opt, double sigma, double* d_out8, double* d_cov9)
 {
     if (!c || !d_r || !d_ref_idx || !d_act_idx || !d_out8) return fail(LSA_E_ARG, "null argument");
     if (B <= 0) return LSA_OK;
@@ -1426,37 +1469,43 @@ int lsa_plicp_batch(lsa_ctx* c, int B, const float* d_r, const int32_t* d_ref_id
         HIP_TRY(hipMalloc((void**)&c->d_trig, sizeof(double) * t.size()));
         HIP_TRY(hipMemcpy(c->d_trig, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
     }
-    {   // more than 64 KB of dynamic LDS: opt in once per device (contexts of several devices may live in one process)
-        static std::atomic<unsigned long long> done{0};
-        const unsigned long long bit = 1ull << (c->device & 63);
-        if (!(done.load(std::memory_order_acquire) & bit)) {
-            HIP_TRY(hipFuncSetAttribute((const void*)lsa::plicp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            done.fetch_or(bit, std::memory_order_release);
-        }
-    }
-    hipLaunchKernelGGL(lsa::plicp_kernel, dim3(B), dim3(lsa::PLICP_THREADS), lsa::plicp_lds_bytes(P.n), c->stream, P, B, d_r,
-                       d_ref_idx, d_act_idx, c->d_trig, d_out8);
-    HIP_TRY(hipGetLastError());
-    return LSA_OK;
+    // four workgroups per CU fit while 4 x LDS <= 160 KB; larger scans get the instance budgeted for three
+    const bool four = 4 * (size_t)lsa::plicp_lds_bytes(P.n) <= 160 * 1024;
+    if (d_cov9) return four ? plicp_launch<4, true>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9)
+                            : plicp_launch<3, true>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9);
+    return four ? plicp_launch<4, false>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, 0.0, nullptr)
+                : plicp_launch<3, false>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, 0.0, nullptr);
 }
 
-// CCanonicalMatcher::FMatch(LDP, LDP) for one host pair: ranges in cm as in PMScan (the caller median-filters)
-int lsa_plicp_host(lsa_ctx* c, const float* ref_r, const float* cur_r, const lsa_plicp_options* opt, double out8[8])
+int lsa_plicp_batch(lsa_ctx* c, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
+                    const lsa_plicp_options* opt, double* d_out8)
+{
+    return lsa_plicp_batch_cov(c, B, d_r, d_ref_idx, d_act_idx, opt, 0.0, d_out8, nullptr);
+}
+
+int lsa_plicp_host_cov(lsa_ctx* c, const float* ref_r, const float* cur_r, const lsa_plicp_options* opt, double sigma,
+                       double out8[8], double cov9[9])
 {
     if (!c || !ref_r || !cur_r || !out8) return fail(LSA_E_ARG, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_staging(c); if (rc) return rc;
     const int n = c->p.points;
-    // through the pinned staging block: the two range rows down, the 8-double record (the block's small slots) up
+    // through the pinned staging block: the two range rows down, the 8-double record (+ 9 of the covariance) up
     memcpy(c->h_stage, ref_r, sizeof(float) * n);
     memcpy(c->h_stage + sizeof(float) * (size_t)n, cur_r, sizeof(float) * n);
     HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    rc = lsa_plicp_batch(c, 1, c->d_r, c->d_idx, c->d_idx + 1, opt, (double*)c->d_small);
+    double* d_out = (double*)c->d_small;
+    rc = lsa_plicp_batch_cov(c, 1, c->d_r, c->d_idx, c->d_idx + 1, opt, sigma, d_out, cov9 ? d_out + 8 : nullptr);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(c->h_stage + c->off_small, c->d_small, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_stage + c->off_small, c->d_small, sizeof(double) * 17, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(out8, c->h_stage + c->off_small, sizeof(double) * 8);
+    if (cov9) memcpy(cov9, c->h_stage + c->off_small + sizeof(double) * 8, sizeof(double) * 9);
     return LSA_OK;
+}
+int lsa_plicp_host(lsa_ctx* c, const float* ref_r, const float* cur_r, const lsa_plicp_options* opt, double out8[8])
+{
+    return lsa_plicp_host_cov(c, ref_r, cur_r, opt, 0.0, out8, nullptr);
 }
 
 // ---- point-to-point ICP on point clouds (CICPWarpper) ----------------------------------

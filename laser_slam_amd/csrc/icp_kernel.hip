@@ -23,24 +23,23 @@
 
 constexpr int ICP_THREADS = 256;
 
-// Diagnostic build only (-DLSA_PHASE_STAMPS): per-phase cycle shares, accumulated by
-// thread 0 of each workgroup into lsa_phase_cycles[] (never compiled into the product).
-#ifdef LSA_NN_STATS
-// diagnostic build only: candidate-list statistics of the NN search, per 64-beam block
-__device__ unsigned long long lsa_nn_stats[24];
-__device__ __forceinline__ int nn_bucket(int len) { return len <= 8 ? 0 : len <= 16 ? 1 : len <= 32 ? 2 : len <= 64 ? 3 : len <= 128 ? 4 : 5; }
-__device__ __forceinline__ int wave_max_i(int v) { for (int o = 32; o; o >>= 1) { int w = __shfl_xor(v, o); v = w > v ? w : v; } return v; }
-__device__ __forceinline__ int wave_sum_i(int v) { for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o); return v; }
-#endif
+// ---- diagnostics (the only conditional code in this file) ------------------------------------------------
+// -DLSA_PHASE_STAMPS: thread 0 of every workgroup adds the cycles it spent per phase to lsa_phase_cycles[]
+// (tools/phase_shares.py reads them through lsa_debug_phase_cycles).  Never compiled into the product.
 #ifdef LSA_PHASE_STAMPS
 __device__ unsigned long long lsa_phase_cycles[16];
 #define STAMP(slot) do { if (tid == 0) { unsigned long long t_ = __builtin_readcyclecounter(); ph[slot] += t_ - t_last; t_last = t_; } } while (0)
 // sub-phase stamp: `dep` is a value the stamped work produced (forces completion before the clock read)
 #define SUBSTAMP(slot, dep) do { if (tid == 0) { float d_ = (dep); asm volatile("" :: "v"(d_)); unsigned long long t_ = __builtin_readcyclecounter(); ph[slot] += t_ - t_sub; t_sub = t_; } } while (0)
+#define STAMP_ARGS , unsigned long long* ph, unsigned long long& t_sub
+#define STAMP_PASS , ph, t_sub
 #else
 #define STAMP(slot) do {} while (0)
 #define SUBSTAMP(slot, dep) do {} while (0)
+#define STAMP_ARGS
+#define STAMP_PASS
 #endif
+// ------------------------------------------------------------------------------------------------------------
 constexpr float NN_CAP = 10001.0f;     // matches with d^2 >= 100^2 are rejected anyway (:1811)
 
 constexpr int TRIM_CHUNK = 256;        // records consumed per step of the partial bubble sort
@@ -119,13 +118,25 @@ __device__ __forceinline__ float bcast_f(float v, int src)
 }
 __device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
-// candidate reference-side point for the pair (cur point p -> ref j), :1883-1917
-__device__ __forceinline__ float2 interp_candidate(const Lds& L, int N, float2 p, int j)
+// Reference rays that pm_icp must not match (ref.bad != 0, :1796) carry this coordinate pair in L.ref_xy: their
+// squared distance to anything (2e36) loses every comparison, so the search needs no flag test per candidate.
+// Where their true coordinates matter (as a neighbour in the interpolation) they are formed again from the range.
+constexpr float REF_FAR = 1.0e18f;
+
+__device__ __forceinline__ float2 ref_point(const DevParam& P, const Lds& L, int j)
 {
-    float2 rj = L.ref_xy[j];
+    float2 q = L.ref_xy[j];
+    if (q.x >= 0.5f * REF_FAR) { const float rr = L.g_ref_r[j]; q = make_float2(rr * P.co[j], rr * P.si[j]); }   // :1710-1711
+    return q;
+}
+
+// candidate reference-side point for the pair (cur point p -> ref j), :1883-1917
+__device__ __forceinline__ float2 interp_candidate(const DevParam& P, const Lds& L, int N, float2 p, int j)
+{
+    float2 rj = L.ref_xy[j];                   // (a matched ray is a usable one)
     float d1 = -1.0f, d2 = -1.0f, f1x = 0, f1y = 0, f2x = 0, f2y = 0;
-    if (j > 0) { float2 a = L.ref_xy[j - 1]; d1 = seg_foot(a.x, a.y, rj.x, rj.y, p.x, p.y, f1x, f1y); }
-    if (j < N - 1) { float2 b = L.ref_xy[j + 1]; d2 = seg_foot(rj.x, rj.y, b.x, b.y, p.x, p.y, f2x, f2y); }
+    if (j > 0) { float2 a = ref_point(P, L, j - 1); d1 = seg_foot(a.x, a.y, rj.x, rj.y, p.x, p.y, f1x, f1y); }
+    if (j < N - 1) { float2 b = ref_point(P, L, j + 1); d2 = seg_foot(rj.x, rj.y, b.x, b.y, p.x, p.y, f2x, f2y); }
     float2 out = rj;
     float d0 = sqrtf((rj.x - p.x) * (rj.x - p.x) + (rj.y - p.y) * (rj.y - p.y));
     if (d1 > 0 && d1 < d0) { out.x = f1x; out.y = f1y; d0 = d1; }
@@ -145,105 +156,100 @@ __device__ __forceinline__ float2 cur_point(const DevParam& P, const float* g_ac
 // ---------------------------------------------------------------------------
 // Nearest reference point inside [i-W, i+W), :1785-1810, exact.
 //
-// A reference point on the ray at bearing fi_j is at least rho*sin(|fi_j - phi|) away
-// from p = (rho, phi), so only rays within asin(sqrt(best)/rho) of phi can hold the
-// minimum; asin(t) <= t + (pi/2 - 1) t^3 on [0,1] keeps the bound free of
-// transcendentals.  `best` comes from the three rays around the bearing of p.  The
-// candidate set is the union of up to three index ranges (the bearing and its images
-// one turn away, for fields of view wider than 180 deg), visited in increasing j; the
-// minimum keeps the reference's tie rule (first strict minimum = smallest j).
-struct NnPlan { int lo, hi, c0, M; };     // window [lo,hi), centre, half width (M < 0: whole window)
-
-// Ray j is excluded only if |j - c| > M with c within half a ray of the bearing of p (one ray
-// for the images, whose period is rounded), i.e. its angular distance exceeds
-// (M - 1/2) dfi >= asin bound + dfi/2 for M = floor(bound/dfi) + 2 (images: + 3).
-__device__ __forceinline__ void nn_range(const NnPlan& pl, int T, int im, int& done, int& s0, int& e0)
-{
-    if (pl.M < 0) { s0 = im == -1 ? pl.lo : 1; e0 = im == -1 ? pl.hi - 1 : 0; return; }
-    const int cc = pl.c0 + im * T, m = im == 0 ? pl.M : pl.M + 1;
-    s0 = cc - m > done + 1 ? cc - m : done + 1;
-    e0 = cc + m < pl.hi - 1 ? cc + m : pl.hi - 1;
-    if (e0 > done) done = e0;
-}
+// A reference point on the ray at bearing fi_j is at least rho sin|fi_j - phi| away from p = (rho, phi) (rho, beyond a
+// right angle), so only rays within asin(sqrt(best)/rho) of phi can hold the minimum; asin t <= t + (pi/2 - 1) t^3 on
+// [0,1] keeps the bound free of transcendentals.  `best` comes from two seeds: the ray at the bearing of p and last
+// iteration's match.  In ray units, with x = (phi - fi_min)/dfi the real-valued index of the bearing and
+// B = asin-bound/dfi, the candidates are the rays j with |j - x| <= B + NN_SLACK, and the same around the images
+// x -+ T one turn away (fields of view wider than 180 deg), each clipped to the window, visited in increasing j: the
+// minimum keeps the reference's tie rule (first strict minimum = smallest j).  Any further ray of the WINDOW may be
+// evaluated as well without changing the result, which the straight-line path uses to skip all masking.
+//
+// Margins.  sqrt(best) is enlarged by 0.1 %, rho reduced by 0.1 % + 0.01 cm: far more than the rounding of the
+// distances (1e-7 relative), so an excluded ray is strictly farther than the minimum even in floating point.
+// NN_SLACK = 1/4 ray covers what separates x from the true index of p's bearing: x comes from the projection's
+// (pr, pf), which differ from the polar coordinates of p (formed by :1757-1758, another expression) by a few ulp of
+// coordinates of at most ~10^4 cm, i.e. < 5e-3 cm / rho in angle - below 1/16 ray for every sensor up to 1280 beams over
+// 270 deg once rho exceeds NN_RHO_MIN = 20 cm (closer points search the whole window) - plus ~1e-3 ray of float
+// rounding in x itself and in the bearing table.
+constexpr float NN_SLACK = 0.25f;
+constexpr float NN_RHO_MIN = 20.0f;
 
 __device__ __forceinline__ void nn_eval(const Lds& L, float2 p, int j, float& best, int& best_j)
 {
-    if ((L.good[j >> 5] >> (j & 31)) & 1u) {
-        const float2 rj = L.ref_xy[j];
-        const float ex = p.x - rj.x, ey = p.y - rj.y;
-        const float d = ex * ex + ey * ey;                 // :1803
-        if (d < best || (d == best && j < best_j)) { best = d; best_j = j; }
-    }
-}
-
-// usable-flags of rays j .. j+31 (bit o = ray j+o); the mask has a spare word at the end
-__device__ __forceinline__ uint32_t good_window(const Lds& L, int j)
-{
-    const int q = j >> 5;
-    return __builtin_amdgcn_alignbit(L.good[q + 1], L.good[q], (uint32_t)j & 31u);
+    const float2 rj = L.ref_xy[j];
+    const float ex = p.x - rj.x, ey = p.y - rj.y;
+    const float d = ex * ex + ey * ey;                 // :1803
+    if (d < best) { best = d; best_j = j; }
 }
 
 // four consecutive rays with their loads issued together (ascending j: the first strict minimum wins)
 __device__ __forceinline__ void nn_eval4(const Lds& L, float2 p, int j, float& best, int& best_j)
 {
-    const uint32_t g = good_window(L, j);
     const float2 r0 = L.ref_xy[j], r1 = L.ref_xy[j + 1], r2 = L.ref_xy[j + 2], r3 = L.ref_xy[j + 3];
     float ex, ey, d;
-    ex = p.x - r0.x; ey = p.y - r0.y; d = ex * ex + ey * ey; if ((g & 1u) && d < best) { best = d; best_j = j; }
-    ex = p.x - r1.x; ey = p.y - r1.y; d = ex * ex + ey * ey; if ((g & 2u) && d < best) { best = d; best_j = j + 1; }
-    ex = p.x - r2.x; ey = p.y - r2.y; d = ex * ex + ey * ey; if ((g & 4u) && d < best) { best = d; best_j = j + 2; }
-    ex = p.x - r3.x; ey = p.y - r3.y; d = ex * ex + ey * ey; if ((g & 8u) && d < best) { best = d; best_j = j + 3; }
+    ex = p.x - r0.x; ey = p.y - r0.y; d = ex * ex + ey * ey; if (d < best) { best = d; best_j = j; }
+    ex = p.x - r1.x; ey = p.y - r1.y; d = ex * ex + ey * ey; if (d < best) { best = d; best_j = j + 1; }
+    ex = p.x - r2.x; ey = p.y - r2.y; d = ex * ex + ey * ey; if (d < best) { best = d; best_j = j + 2; }
+    ex = p.x - r3.x; ey = p.y - r3.y; d = ex * ex + ey * ey; if (d < best) { best = d; best_j = j + 3; }
 }
 
-#ifndef LSA_NN_FLAT
-#define LSA_NN_FLAT 8
-#endif
-constexpr int NN_FLAT = LSA_NN_FLAT;   // candidate counts up to this are evaluated straight-line
+constexpr int NN_FLAT = 8;             // candidate counts up to this are evaluated straight-line
 
 // per-beam search state
 struct NnBeam {
     float2 p;
-    NnPlan pl;
-    int s0, e0;          // main range (image 0), already clipped to the window
-    int len;             // total candidates over the three images
-    bool live, flat;     // flat: one range of at most NN_FLAT rays
+    int lo, hi;          // the reference's window [lo, hi)
+    float x, B;          // real-valued index of the bearing, half width in rays (B < 0: the whole window)
+    int s0, e0;          // main range, clipped to the window
+    bool live, flat;     // flat: the candidates are NN_FLAT consecutive rays of the window starting at s0
     float best;
     int best_j;
 };
 
-// predicated evaluation of ray j (LDS address clamped so that the loads are unconditional)
-__device__ __forceinline__ void nn_eval_pred(const Lds& L, int N, float2 p, int j, bool pred, float& best, int& best_j)
+// seed evaluation of ray j (LDS address clamped so that the load is unconditional)
+__device__ __forceinline__ void nn_seed(const Lds& L, int N, float2 p, int j, bool pred, float& best)
 {
     const int jc = j < 0 ? 0 : (j > N - 1 ? N - 1 : j);
-    const bool ok = (L.good[jc >> 5] >> (jc & 31)) & 1u;
     const float2 rj = L.ref_xy[jc];
     const float ex = p.x - rj.x, ey = p.y - rj.y;
-    const float d = ex * ex + ey * ey;                 // :1803
-    const bool take = pred && ok && (d < best || (d == best && j < best_j));
-    best = take ? d : best;
-    best_j = take ? j : best_j;
+    const float d = ex * ex + ey * ey;
+    best = pred && d < best ? d : best;
 }
 
-// plan for beam i (straight-line): centre from the projected bearing, seed distance from the
-// ray at that bearing and last iteration's match, half width from the asin bound
+// candidate range of image im (-1, 0, +1) clipped to the window and to what the ranges before it covered
+__device__ __forceinline__ void nn_range(const NnBeam& b, float T, int im, int& done, int& s, int& e)
+{
+    if (b.B < 0.0f) { s = im == 0 ? b.lo : 1; e = im == 0 ? b.hi - 1 : 0; return; }
+    const float xc = b.x + (float)im * T, w = im == 0 ? b.B : b.B + 0.05f;     // (the period's own rounding)
+    const float fs = xc - w, fe = xc + w;
+    // float -> int conversions saturate; the window clips whatever is far outside
+    s = (int)__builtin_ceilf(fs); e = (int)__builtin_floorf(fe);
+    s = s > done + 1 ? s : done + 1;
+    e = e < b.hi - 1 ? e : b.hi - 1;
+    if (e > done) done = e;
+}
+
+// plan for beam i (straight-line): bearing index from the projection, seed distance from the ray at that bearing and
+// last iteration's match, half width from the asin bound
 __device__ __forceinline__ void nn_plan(const DevParam& P, const Lds& L, int i, bool live, float2 p, int jprev,
-                                        int T, float inv_dfi, NnBeam& b)
+                                        float T, float inv_dfi, NnBeam& b)
 {
     const int N = P.n, W = P.window;
     const int ic = i < N ? i : N - 1;
     b.p = p; b.live = live;
-    b.pl.lo = ic - W < 0 ? 0 : ic - W;
-    b.pl.hi = ic + W > N ? N : ic + W;
+    b.lo = ic - W < 0 ? 0 : ic - W;
+    b.hi = ic + W > N ? N : ic + W;
     const float rho = L.pr[ic] * 0.999f - 0.01f;
     const float half = 0.5f * (float)(N - 1) * P.dfi;
     float a = L.pf[ic] - (P.fi_min + half);
     a -= 6.2831853f * rintf(a * 0.15915494f);
-    b.pl.c0 = (int)rintf((a + half) / P.dfi);
-    const int c = b.pl.c0 < b.pl.lo ? b.pl.lo : (b.pl.c0 > b.pl.hi - 1 ? b.pl.hi - 1 : b.pl.c0);
+    b.x = (a + half) * inv_dfi;
+    const int c0 = (int)rintf(b.x);
+    const int c = c0 < b.lo ? b.lo : (c0 > b.hi - 1 ? b.hi - 1 : c0);
     float b1 = 1000000.0f;
-    int bj1 = 0x7fffffff;
-    nn_eval_pred(L, N, p, c, true, b1, bj1);
-    nn_eval_pred(L, N, p, jprev, jprev >= b.pl.lo && jprev < b.pl.hi, b1, bj1);
+    nn_seed(L, N, p, c, true, b1);
+    nn_seed(L, N, p, jprev, jprev >= b.lo && jprev < b.hi, b1);
     // neither seed usable (the ray at the bearing is bad and there is no previous match): take the
     // usable rays nearest to the bearing on either side from the bit mask, so that the search
     // stays bounded; a window without any usable ray has no match at all
@@ -252,78 +258,72 @@ __device__ __forceinline__ void nn_plan(const DevParam& P, const Lds& L, int i, 
     if (__ballot(unseeded)) {
         int jl = -1, jr = -1;
         if (unseeded) {
-            const int wmin = b.pl.lo >> 5, wmax = (b.pl.hi - 1) >> 5;
+            const int wmin = b.lo >> 5, wmax = (b.hi - 1) >> 5;
             int w = c >> 5;
             uint32_t m = L.good[w] & (0xffffffffu << (c & 31));
             while (m == 0 && w < wmax) m = L.good[++w];
-            if (m) { const int j = (w << 5) + __builtin_ctz(m); if (j < b.pl.hi) jr = j; }
+            if (m) { const int j = (w << 5) + __builtin_ctz(m); if (j < b.hi) jr = j; }
             w = c >> 5;
             m = L.good[w] & (0xffffffffu >> (31 - (c & 31)));
             while (m == 0 && w > wmin) m = L.good[--w];
-            if (m) { const int j = (w << 5) + 31 - __builtin_clz(m); if (j >= b.pl.lo) jl = j; }
+            if (m) { const int j = (w << 5) + 31 - __builtin_clz(m); if (j >= b.lo) jl = j; }
         }
-        nn_eval_pred(L, N, p, jl, unseeded && jl >= 0, b1, bj1);
-        nn_eval_pred(L, N, p, jr, unseeded && jr >= 0, b1, bj1);
+        nn_seed(L, N, p, jl, unseeded && jl >= 0, b1);
+        nn_seed(L, N, p, jr, unseeded && jr >= 0, b1);
         nothing = unseeded && jl < 0 && jr < 0;
     }
     // planning only (conservative margins absorb the approximate sqrt / reciprocal)
     const float tcap = b1 < NN_CAP ? b1 : NN_CAP;
     const float t = __builtin_amdgcn_sqrtf(tcap) * 1.001f * __builtin_amdgcn_rcpf(rho > 1e-3f ? rho : 1e-3f);
     // (without any seed the radius is that of NN_CAP: a match farther than 100 cm is rejected anyway, :1811)
-    const bool bounded = rho > 0.0f && t < 1.0f;
-    b.pl.M = bounded ? (int)((t + 0.5708f * t * t * t) * inv_dfi) + 2 : -1;
-    int done = b.pl.lo - 1, s0, e0, len = 0, l0 = 0;
-    nn_range(b.pl, T, -1, done, s0, e0); len += e0 >= s0 ? e0 - s0 + 1 : 0;
-    if (b.pl.M < 0) { b.s0 = s0; b.e0 = e0; l0 = len; }
-    nn_range(b.pl, T, 0, done, s0, e0); len += e0 >= s0 ? e0 - s0 + 1 : 0;
-    if (b.pl.M >= 0) { b.s0 = s0; b.e0 = e0; l0 = e0 >= s0 ? e0 - s0 + 1 : 0; }
-    nn_range(b.pl, T, 1, done, s0, e0); len += e0 >= s0 ? e0 - s0 + 1 : 0;
-    b.len = live ? len : 0;
-    b.flat = live && len == l0 && len <= NN_FLAT;
-    if (nothing) { b.len = 0; b.flat = true; b.s0 = 0; b.e0 = -1; }
+    const bool bounded = rho > NN_RHO_MIN && t < 1.0f;
+    b.B = bounded ? (t + 0.5708f * t * t * t) * inv_dfi + NN_SLACK : -1.0f;
+    int done = b.lo - 1, s, e, len = 0;
+    nn_range(b, T, -1, done, s, e); len += e >= s ? e - s + 1 : 0;
+    nn_range(b, T, 0, done, b.s0, b.e0); const int l0 = b.e0 >= b.s0 ? b.e0 - b.s0 + 1 : 0; len += l0;
+    nn_range(b, T, 1, done, s, e); len += e >= s ? e - s + 1 : 0;
+    // straight-line path: one range of at most NN_FLAT rays, and the NN_FLAT rays from its start lie inside the window
+    // and the scan (any ray of the window may be evaluated on top of the candidates)
+    b.flat = live && len == l0 && l0 <= NN_FLAT && b.s0 >= b.lo && b.s0 + NN_FLAT <= b.hi;
+    if (nothing || (live && len == 0)) { b.live = false; b.flat = false; }
     b.best = 1000000.0f;
     b.best_j = 0x7fffffff;
 }
 
-// up to NN_FLAT (= 8) consecutive rays s0 .. e0, straight-line: one flag window, loads at fixed
-// offsets from one base (shifted down near the end of the scan so that all eight stay inside it)
+// NN_FLAT (= 8) consecutive rays from s0, straight-line, loads at fixed offsets from one base
 __device__ __forceinline__ void nn_flat(const Lds& L, int N, NnBeam& b)
 {
     static_assert(NN_FLAT == 8, "nn_flat is written for eight rays");
-#ifdef LSA_DIAG_OLD_FLAT
-    #pragma unroll
-    for (int o = 0; o < NN_FLAT; ++o) nn_eval_pred(L, N, b.p, b.s0 + o, b.flat && b.s0 + o <= b.e0, b.best, b.best_j);
-    return;
-#endif
-    const int base = b.s0 < N - 8 ? (b.s0 > 0 ? b.s0 : 0) : N - 8;
-    const int off = b.s0 - base;                                       // 0 unless clamped
-    const int cnt = b.flat && b.e0 >= b.s0 ? b.e0 - b.s0 + 1 : 0;      // 0 .. 8 (an empty range may have e0 < s0 - 1)
-    const uint32_t act = good_window(L, base) & (((1u << cnt) - 1u) << off) & 0xffu;
+    const int base = b.flat ? b.s0 : 0;                                 // (N >= 8, host-checked)
     const float2* r = L.ref_xy + base;
+    float best = 1000000.0f;
+    int best_j = 0x7fffffff;
     #pragma unroll
     for (int o = 0; o < 8; ++o) {
         const float2 rj = r[o];
         const float ex = b.p.x - rj.x, ey = b.p.y - rj.y;
         const float d = ex * ex + ey * ey;                             // :1803
-        const bool take = (act & (1u << o)) && d < b.best;             // ascending j: first strict minimum
-        b.best = take ? d : b.best;
-        b.best_j = take ? base + o : b.best_j;
+        const bool take = d < best;                                    // ascending j: first strict minimum
+        best = take ? d : best;
+        best_j = take ? base + o : best_j;
     }
+    if (b.flat) { b.best = best; b.best_j = best_j; }
 }
 
-// the general path: candidate lists that are longer than NN_FLAT or span several images, per lane.
-// (A wave-cooperative scan of the rare long lists was measured slower than letting the lane loop:
-// its LDS hand-offs stall the whole wave.)
-__device__ __forceinline__ void nn_general(const DevParam& P, const Lds& L, int T, NnBeam& b)
+// the general path: candidate lists that are longer than NN_FLAT, span several images or touch the window's edge, per
+// lane.  (A wave-cooperative scan of the rare long lists was measured slower than letting the lane loop: its LDS
+// hand-offs stall the whole wave.)
+__device__ __forceinline__ void nn_general(const Lds& L, float T, NnBeam& b)
 {
     if (b.live && !b.flat) {
-        int done = b.pl.lo - 1, s0, e0;
+        int done = b.lo - 1, s, e;
         #pragma unroll
         for (int im = -1; im <= 1; ++im) {
-            nn_range(b.pl, T, im, done, s0, e0);
-            int j = s0;
-            for (; j + 3 <= e0; j += 4) nn_eval4(L, b.p, j, b.best, b.best_j);
-            for (; j <= e0; ++j) nn_eval(L, b.p, j, b.best, b.best_j);
+            nn_range(b, T, im, done, s, e);
+            int j = s;
+            const int eq = e + 3 < b.hi - 1 ? e + 3 : b.hi - 1;         // quads may run past e inside the window
+            for (; j + 3 <= eq && j <= e; j += 4) nn_eval4(L, b.p, j, b.best, b.best_j);
+            for (; j <= e; ++j) nn_eval(L, b.p, j, b.best, b.best_j);
         }
     }
 }
@@ -385,9 +385,7 @@ __device__ __forceinline__ int count_split(const float* row, int cnt, float d, i
     const int t1 = (int)f2u(d), t2 = t1 - 1;
     const int nq = (cnt + 3) >> 2, qa = limit >> 2;      // quads [0,qa) lie entirely below `limit`
     int c = 0, qd = 0;
-#ifndef LSA_NO_UNROLL
     #pragma unroll 4
-#endif
     for (; qd < qa; ++qd) {
         const int4 v = r4[qd];
         c += (v.x > t1) + (v.y > t1) + (v.z > t1) + (v.w > t1);
@@ -401,9 +399,7 @@ __device__ __forceinline__ int count_split(const float* row, int cnt, float d, i
         c += (p + 3 < cnt && v.w > (p + 3 < limit ? t1 : t2)) ? 1 : 0;
         ++qd;
     }
-#ifndef LSA_NO_UNROLL
     #pragma unroll 4
-#endif
     for (; qd < nq; ++qd) {
         const int4 v = r4[qd];
         c += (v.x > t2) + (v.y > t2) + (v.z > t2) + (v.w > t2);
@@ -426,9 +422,7 @@ __device__ __forceinline__ int count_ge_from(const float* row, int cnt, float d,
         c += (p + 3 >= from && v.w > t2) ? 1 : 0;
         ++qd;
     }
-#ifndef LSA_NO_UNROLL
     #pragma unroll 4
-#endif
     for (; qd < nq; ++qd) {
         const int4 v = r4[qd];
         c += (v.x > t2) + (v.y > t2) + (v.z > t2) + (v.w > t2);
@@ -436,17 +430,7 @@ __device__ __forceinline__ int count_ge_from(const float* row, int cnt, float d,
     return c;
 }
 
-// diagnostics: the same pure computation once more (opaque to CSE), results averaged
-#define LSA_TWICE(flag, var, expr_with_dd) do { float dd = d; asm volatile("" : "+v"(dd)); const int v2_ = (expr_with_dd); var = (var + v2_) >> 1; } while (0)
-#ifdef LSA_TRIM_NOINLINE
-__device__ __noinline__ void trim_worst(const Lds& L, int n, int k, int* wcnt)
-#else
-__device__ void trim_worst(const Lds& L, int n, int k, int* wcnt
-#ifdef LSA_PHASE_STAMPS
-                           , unsigned long long* ph, unsigned long long& t_sub
-#endif
-                           )
-#endif
+__device__ void trim_worst(const Lds& L, int n, int k, int* wcnt STAMP_ARGS)
 {
     const int tid = threadIdx.x;
     unsigned long long* A = L.key;
@@ -468,22 +452,12 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt
         __syncthreads();
         const int seg = k - 64 * wave < 64 ? k - 64 * wave : 64;        // records of this wave (may be <= 0)
         int rank = 0;
-#ifdef LSA_DIAG_OLD_FIRSTK
-        if (tid < k) Pc[count_split(cd, k, d, tid + 1)] = rec;
-        __syncthreads();
-        if (false) {
-#else
         if (tid < k) {
-#endif
             rank = count_split(cd + 64 * wave, seg, d, lane + 1);
             ce[64 * wave + rank] = d;
         }
         __syncthreads();
-#ifdef LSA_DIAG_OLD_FIRSTK
-        if (false) {
-#else
         if (tid < k) {
-#endif
             const int t1 = (int)f2u(d);
             const int* srt = (const int*)ce;
             for (int b = 0; 64 * b < k; ++b) {
@@ -528,9 +502,6 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt
         SUBSTAMP(15, (float)g1);
         // earlier records of this step that are strictly greater (later ones never count)
         int g2 = cand ? count_split(cd, cpos, d, cpos) : 0;
-#ifdef LSA_DUP_G2
-        LSA_TWICE(0, g2, cand ? count_split(cd, cpos, dd, cpos) : 0);
-#endif
         const bool ent = cand && (g1 + g2 < k);
         int E;
         const int epos = block_rank(ent, E, wcnt, phase);
@@ -546,9 +517,6 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt
         // itself (its count of greater predecessors is no larger), so the entering records ahead
         // of this one number g2 plus the later ones that are greater or equal.
         int h = ent ? g2 + count_ge_from(ce, E, d, epos + 1) : 0;
-#ifdef LSA_DUP_H
-        LSA_TWICE(0, h, ent ? g2 + count_ge_from(ce, E, dd, epos + 1) : 0);
-#endif
         if (ent) se[h] = d;
         __syncthreads();
         const int top = k + E - 1;
@@ -629,18 +597,16 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
     const int VS = icp_v_bytes(N) / 16;                       // floats per list (multiple of 4, + slack)
     float* const V0 = (float*)L.V;
 
-#ifndef LSA_SERIAL_WAVE
-#define LSA_SERIAL_WAVE 0
-#endif
-    const int sw = (LSA_SERIAL_WAVE);       // the wave that runs the order-bound single-wave phases
+    const int sw = 0;                       // the wave that runs the order-bound single-wave phases
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const size_t ro = (size_t)ref_idx[b] * N, ao = (size_t)act_idx[b] * N;
         L.g_act_r = g_r + ao;
+        L.g_ref_r = g_r + ro;
         __syncthreads();
         for (int i = tid; i < N; i += ICP_THREADS) {
             float rr = g_r[ro + i];
-            L.ref_xy[i] = make_float2(rr * P.co[i], rr * P.si[i]);      // :1710-1711
             const uint8_t rb = g_bad[ro + i];
+            L.ref_xy[i] = rb == 0 ? make_float2(rr * P.co[i], rr * P.si[i]) : make_float2(REF_FAR, REF_FAR);      // :1710-1711
             bool ok = false;
             if (i >= 1) {
                 uint16_t s1 = g_seg[ao + i], s0 = g_seg[ao + i - 1];
@@ -671,31 +637,21 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
 #endif
 
         int iter = -1;
-#ifdef LSA_FIXED_ITERS      // diagnostics: data-independent trip count, so that skip-a-phase variants are comparable
-        while (++iter < LSA_FIXED_ITERS) {
-#else
         while (++iter < LSA_ITER_ICP && small < 3) {
-#endif
             if (((double)(fabsf_(dx) + fabsf_(dy)) + (double)fabsf_(dth) * LSA_ZR2D) < LSA_STOP_ICP) small++;
             else small = 0;                                                     // :1728
 
             co = nco; si = nsi;
             scan_project(P, L, ax, ay, ath);                                    // flags only, :1750
-#ifdef LSA_DUP_PROJ      // diagnostics: an idempotent phase run twice; its instruction count = the PMC delta
-            scan_project(P, L, ax, ay, ath);
-#endif
             STAMP(0);
 #ifdef LSA_PHASE_STAMPS
             t_sub = t_last;
 #endif
 
             {
-                // this wave's beams, 64 at a time; the seed matches live in LDS between iterations
-                const int T = (int)rintf(6.2831853f / P.dfi);
+                // this wave's beams, 64 at a time; last iteration's matches (the seeds) live in registers
                 const float inv_dfi = 1.0f / P.dfi;
-#ifdef LSA_DUP_NN
-                for (int rep = 0; rep < 2; ++rep)
-#endif
+                const float T = 6.2831853f * inv_dfi;                 // one turn in rays
                 for (int base = wave * WAVE, trip = 0; base < N; base += ICP_THREADS, ++trip) {
                     const int i0 = base + lane;
                     const bool lv0 = i0 < N && key_bad(L.key[i0 < N ? i0 : 0]) == 0;
@@ -704,42 +660,8 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
                     const int jp0 = (int)((trip & 1) ? jpw >> 16 : jpw & 0xffffu) - 1;   // -1 in the first iteration
                     NnBeam b0;
                     nn_plan(P, L, i0, lv0, p0, jp0, T, inv_dfi, b0);
-#ifdef LSA_NN_STATS
-                    {
-                        const bool nf = b0.live && !b0.flat;
-                        const int mx = wave_max_i(nf ? b0.len : 0), sm = wave_sum_i(b0.len), lv = wave_sum_i(b0.live ? 1 : 0), nfc = wave_sum_i(nf ? 1 : 0);
-                        const int nfs = wave_sum_i(nf ? b0.len : 0), fmx = wave_max_i(b0.flat ? b0.len : 0);
-                        if (lane == 0) {
-                            atomicAdd(&lsa_nn_stats[0], 1ull); atomicAdd(&lsa_nn_stats[1], (unsigned long long)sm);
-                            atomicAdd(&lsa_nn_stats[2], mx > 0 ? 1ull : 0ull); atomicAdd(&lsa_nn_stats[3], (unsigned long long)mx);
-                            atomicAdd(&lsa_nn_stats[4], (unsigned long long)lv); atomicAdd(&lsa_nn_stats[5], (unsigned long long)nfc);
-                            atomicAdd(&lsa_nn_stats[6], (unsigned long long)nfs); atomicAdd(&lsa_nn_stats[7], (unsigned long long)fmx);
-                            atomicAdd(&lsa_nn_stats[16 + nn_bucket(mx)], 1ull);
-                        }
-                        if (b0.live) atomicAdd(&lsa_nn_stats[8 + nn_bucket(b0.len)], 1ull);
-                        if (b0.live && b0.pl.M < 0) atomicAdd(&lsa_nn_stats[14], 1ull);
-                    }
-#endif
                     nn_flat(L, N, b0);
-#if defined(LSA_DUP_NN) && defined(LSA_DUP_NN_PLANFLAT)
-                    if (rep == 1) { if (b0.best_j == 12345678) L.key[0] = 0; continue; }
-#endif
-                    if (__ballot(b0.live && !b0.flat)) nn_general(P, L, T, b0);
-#if defined(LSA_DUP_NN) && defined(LSA_DUP_NN_NOSTORE)
-                    if (rep == 1) { if (b0.best_j == 12345678) L.key[0] = 0; continue; }
-#endif
-#ifdef LSA_NN_STATS
-                    {   // list length the final best distance would have allowed
-                        const float rho = L.pr[i0 < N ? i0 : N - 1] * 0.999f - 0.01f;
-                        const float tc = b0.best < NN_CAP ? b0.best : NN_CAP;
-                        const float t = __builtin_amdgcn_sqrtf(tc) * 1.001f * __builtin_amdgcn_rcpf(rho > 1e-3f ? rho : 1e-3f);
-                        int ls = 2 * P.window;
-                        if (b0.best < 1000000.0f && rho > 0.0f && t < 1.0f) { int M = (int)((t + 0.5708f * t * t * t) * inv_dfi) + 2; ls = 2 * M + 1 < ls ? 2 * M + 1 : ls; }
-                        if (!b0.live) ls = 0;
-                        const int sm = wave_sum_i(ls), mx = wave_max_i(ls > 8 ? ls : 0);
-                        if (lane == 0) { atomicAdd(&lsa_nn_stats[15], (unsigned long long)sm); atomicAdd(&lsa_nn_stats[22], (unsigned long long)mx); }
-                    }
-#endif
+                    if (__ballot(b0.live && !b0.flat)) nn_general(L, T, b0);
                     const int m0 = nn_store(L, N, i0, b0);
                     {
                         const uint32_t nv = (uint32_t)(m0 + 1) & 0xffffu;
@@ -770,22 +692,16 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
             if (n < P.min_valid) { status = LSA_ST_FEW_POINTS; break; }                  // :1825-1832
             drop = (int)((double)n * 0.2);                                              // :1836
             keep = n - drop;
-#ifdef LSA_SKIP_TRIM
-#elif defined(LSA_PHASE_STAMPS)
+#ifdef LSA_PHASE_STAMPS
             t_sub = __builtin_readcyclecounter();
-            trim_worst(L, n, drop, imisc + 40, ph, t_sub);
-#else
-            trim_worst(L, n, drop, imisc + 40);
-#endif                                          // :1839-1857
+#endif
+            trim_worst(L, n, drop, imisc + 40 STAMP_PASS);                               // :1839-1857
             __syncthreads();
             STAMP(3);
 
             // ---- interpolation of the reference side, :1867-1926 ---------------------
             // ix/iy are indexed by the reference beam and later pairs overwrite earlier
             // ones: the pair with the largest list position owns the beam.
-#ifdef LSA_DUP_OWNER
-            for (int rep = 0; rep < 2; ++rep) {
-#endif
             for (int i = tid; i < N; i += ICP_THREADS) L.owner[i] = 0;                   // (aliases the D region)
             __syncthreads();
             for (int k = tid; k < keep; k += ICP_THREADS)
@@ -809,24 +725,17 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
                         const int io = ko[u] == k ? i : (int)((uint32_t)(L.key[ko[u]] >> 32) & 0xffff);
                         const float2 p = cur_point(P, L.g_act_r, i, co, si, ax, ay);
                         const float2 po = io == i ? p : cur_point(P, L.g_act_r, io, co, si, ax, ay);
-                        const float2 q = interp_candidate(L, N, po, j);
+                        const float2 q = interp_candidate(P, L, N, po, j);
                         V0[k] = p.x; V0[VS + k] = p.y; V0[2 * VS + k] = q.x; V0[3 * VS + k] = q.y;
                     }
                 }
             }
             __syncthreads();
-#ifdef LSA_DUP_OWNER
-            }
-#endif
             STAMP(4);
 
             // ---- closed-form rigid fit, :1936-1986: ordered sums, one lane per sum -------
             if (wave == sw && lane < 4) fmisc[lane] = ordered_sum(V0 + lane * VS, keep) / (float)keep;
             __syncthreads();
-#ifdef LSA_DUP_SUM
-            if (wave == sw && lane < 4) fmisc[lane] = ordered_sum(V0 + lane * VS, keep) / (float)keep;
-            __syncthreads();
-#endif
             STAMP(5);
             const float mpx = fmisc[0], mpy = fmisc[1], mqx = fmisc[2], mqy = fmisc[3];
             for (int k = tid; k < keep; k += ICP_THREADS) {
@@ -870,7 +779,7 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
             for (int k = tid; k < drop; k += ICP_THREADS) {
                 const uint32_t ij = (uint32_t)(L.key[k] >> 32);
                 const float2 p = cur_point(P, L.g_act_r, ij & 0xffff, co, si, pax, pay);
-                const float2 c = interp_candidate(L, N, p, ij >> 16);
+                const float2 c = interp_candidate(P, L, N, p, ij >> 16);
                 resid[k] = sqrtf((p.x - c.x) * (p.x - c.x) + (p.y - c.y) * (p.y - c.y));
             }
             __syncthreads();

@@ -53,7 +53,8 @@ struct Lds {
     uint8_t* new_bad;
     float* pool_d;
     uint32_t* pool_ij;
-    const float* g_act_r;      // ICP v2 reads the current scan's ranges from HBM/L2 (act_r == nullptr)
+    const float* g_act_r;      // ICP reads the current scan's ranges from HBM/L2 (act_r == nullptr)
+    const float* g_ref_r;      // ICP: the reference scan's ranges (unusable rays carry a far sentinel in ref_xy)
     float4* V;                 // ICP v2: ordered value list (nx, ny, ix, iy) -> products
     unsigned long long* poolA; // ICP v2 trim pool (double buffered) + eviction scratch
     unsigned long long* poolB;

@@ -211,6 +211,156 @@ __device__ __forceinline__ void plicp_sens_point(const PlicpLds& L, int n, int i
     px = L.trig[i] * rm; py = L.trig[n + i] * rm;
 }
 
+// find_correspondences of one iteration: for every valid point of the current scan moved by x, the nearest valid
+// reference point inside the reference's window and within the correspondence limit (j1), and the nearer of the
+// adjacent valid reference rays (j2); L.corr[i] = j1 | j2 << 16 or -1, L.d2[i] = the squared distance.  Last call's
+// L.corr seeds the pruned scan.  Returns this thread's number of correspondences.
+__device__ __forceinline__ int plicp_correspondences(const PlicpParam& P, const PlicpLds& L, const double x_old[3], double cs, double sn)
+{
+    const int n = P.n, tid = threadIdx.x;
+    const double PI = 3.14159265358979323846;
+    const double min_theta = (double)(P.fi_min + P.dfi * 0), max_theta = (double)(P.fi_min + P.dfi * (n - 1));
+    const double angle_res = (max_theta - min_theta) / n;
+#ifdef LSA_PLICP_STAMPS
+    unsigned long long pt_ = __builtin_readcyclecounter();
+#endif
+    int mine = 0;
+    for (int i = tid; i < n; i += PLICP_THREADS) {
+        int rec = -1;
+        double best = 0;
+        if (L.sr[i] >= 0.0f) {
+            double spx, spy;
+            plicp_sens_point(L, n, i, spx, spy);
+            const double wx = cs * spx - sn * spy + x_old[0], wy = sn * spx + cs * spy + x_old[1];
+            int j1 = -1;
+            const double lim = P.max_correspondence_dist * P.max_correspondence_dist;
+            // The reference scans the window start_cell +- ceil((45 deg + atan(0.5 m / rho)) / res) around the
+            // point's bearing.  Exact pruning of that scan: a reference point on a ray at angular distance a
+            // from the bearing is at least rho sin(a) away (rho, if a >= 90 deg), so only rays within
+            // asin(sqrt(bound) / rho) of the bearing - or of its images one turn away - can hold the minimum;
+            // bound = the smaller of the correspondence limit and the distance of two seeds (the ray at the
+            // bearing, last iteration's match).  Fast path (nearly every point): the bearing lies inside the
+            // scan's field of view and the pruned range is well inside the +-45 deg that every window has, so
+            // the window itself never matters and single precision suffices for the range's centre and half
+            // width (the margins cover its error); the distances are always evaluated in double.
+            const int prev = L.corr[i] >= 0 ? (L.corr[i] & 0xffff) : -1;
+            const float wxf = (float)wx, wyf = (float)wy;
+            const float rho_f = sqrtf(wxf * wxf + wyf * wyf) * 0.99999f;
+            const float phi_f = atan2f(wyf, wxf);
+            const int c0f = (int)rintf((phi_f - (float)min_theta) / P.dfi);
+            const int range_min = (int)(fabs(P.max_angular_correction_deg * (PI / 180.0)) / angle_res);
+            bool fast = phi_f > (float)min_theta + 1e-3f && phi_f < (float)max_theta - 1e-3f && c0f >= 0 && c0f <= n - 1;
+            int lo0 = 0, hi0 = -1, nseg = 1, lo1 = 0, hi1 = -1, lo2 = 0, hi2 = -1;
+            if (fast) {
+                double bound = lim;
+                if (L.rx[c0f] < 1e100) { const double d = plicp_dist2(wx, wy, L.rx[c0f], L.ry[c0f]); bound = d < bound ? d : bound; }
+                else {      // the nearest valid rays on either side of an invalid one (inside the +-45 deg of every window)
+                    const int su = L.nup[c0f], sd = L.ndown[c0f];
+                    if (su != 0xffff && su - c0f <= range_min - 8) { const double d = plicp_dist2(wx, wy, L.rx[su], L.ry[su]); bound = d < bound ? d : bound; }
+                    if (sd != 0xffff && c0f - sd <= range_min - 8) { const double d = plicp_dist2(wx, wy, L.rx[sd], L.ry[sd]); bound = d < bound ? d : bound; }
+                }
+                if (prev >= 0 && abs(prev - c0f) <= range_min - 8 && L.rx[prev] < 1e100) { const double d = plicp_dist2(wx, wy, L.rx[prev], L.ry[prev]); bound = d < bound ? d : bound; }
+                // a poor bound (a quarter of the point's range or more) would mean a scan of hundreds of rays that
+                // the whole wave waits for: a few more seeds at growing offsets usually find something closer
+                if (__ballot(bound > 0.0625 * (double)(rho_f * rho_f))) {
+                    #pragma unroll
+                    for (int o = 2; o <= 32; o *= 2) {
+                        const int ja = c0f - o, jb = c0f + o;
+                        if (ja >= 0) { const double d = plicp_dist2(wx, wy, L.rx[ja], L.ry[ja]); bound = d < bound ? d : bound; }   // (invalid rays: 1e150)
+                        if (jb <= n - 1) { const double d = plicp_dist2(wx, wy, L.rx[jb], L.ry[jb]); bound = d < bound ? d : bound; }
+                    }
+                }
+                const float tq = sqrtf((float)bound) * 1.0001f / rho_f;
+                const int M = tq < 1.0f ? (int)((tq + 0.5708f * tq * tq * tq) / P.dfi) + 5 : n;      // asin t <= t + (pi/2 - 1) t^3
+                fast = M + 8 <= range_min;
+#ifdef LSA_PLICP_DIAG_FULLSCAN          // diagnostic build only: the reference's whole window, no pruning
+                fast = false;
+#endif
+                lo0 = c0f - M > 0 ? c0f - M : 0; hi0 = c0f + M < n - 1 ? c0f + M : n - 1;
+                // (Scanning in rings outwards from the bearing with a half width that shrinks as closer points
+                //  turn up was measured slower than this one ascending scan from the seeds' bound.)
+            }
+#ifdef LSA_PLICP_DIAG_NOSLOW
+            if (false) {
+#else
+            if (!fast) {
+#endif
+                const double rho = sqrt(wx * wx + wy * wy);
+                const double phi = atan2(wy, wx);
+                const double delta = fabs(P.max_angular_correction_deg * (PI / 180.0)) + fabs(atan(P.max_linear_correction / rho));
+                const int range = (int)ceil(delta / angle_res);
+                double start_theta = phi;
+                if (start_theta < min_theta) start_theta += 2 * PI;
+                if (start_theta > max_theta) start_theta -= 2 * PI;
+                const int start_cell = (int)((start_theta - min_theta) / (max_theta - min_theta) * n);
+                int from = start_cell - range, to = start_cell + range;
+                from = from < 0 ? 0 : (from > n - 1 ? n - 1 : from); to = to < 0 ? 0 : (to > n - 1 ? n - 1 : to);
+                double bound = lim;
+                const int cen = start_cell < from ? from : (start_cell > to ? to : start_cell);
+                if (L.rx[cen] < 1e100) { const double d = plicp_dist2(wx, wy, L.rx[cen], L.ry[cen]); bound = d < bound ? d : bound; }
+                if (prev >= from && prev <= to && L.rx[prev] < 1e100) { const double d = plicp_dist2(wx, wy, L.rx[prev], L.ry[prev]); bound = d < bound ? d : bound; }
+                const double sb = sqrt(bound) * (1.0 + 1e-9) + 1e-12;
+                lo0 = from; hi0 = to;
+#ifdef LSA_PLICP_DIAG_FULLSCAN
+                if (false) {
+#else
+                if (sb < rho) {
+#endif
+                    const double tq = sb / rho;                                      // asin t <= t + (pi/2 - 1) t^3 on [0, 1]
+                    const int M = (int)((tq + 0.5708 * tq * tq * tq) / (double)P.dfi) + 3;   // bearings are float(fi_min + dfi j): margin
+                    const int T = (int)rint(2 * PI / (double)P.dfi);
+                    const int c0 = (int)rint((phi - min_theta) / (double)P.dfi);
+                    // images c0 - T, c0, c0 + T in increasing order, each clipped to [from, to] and past the previous one
+                    int done = from - 1;
+                    lo0 = c0 - T - M > done + 1 ? c0 - T - M : done + 1; hi0 = c0 - T + M < to ? c0 - T + M : to; if (hi0 > done) done = hi0;
+                    lo1 = c0 - M > done + 1 ? c0 - M : done + 1;         hi1 = c0 + M < to ? c0 + M : to;         if (hi1 > done) done = hi1;
+                    lo2 = c0 + T - M > done + 1 ? c0 + T - M : done + 1; hi2 = c0 + T + M < to ? c0 + T + M : to;
+                    nseg = 3;
+                }
+            }
+#ifdef LSA_PLICP_COUNTS
+            {
+                const int cand = (hi0 >= lo0 ? hi0 - lo0 + 1 : 0) + (hi1 >= lo1 ? hi1 - lo1 + 1 : 0) + (hi2 >= lo2 ? hi2 - lo2 + 1 : 0);
+                atomicAdd(&lsa_plicp_cycles[6], fast ? 0ull : (nseg == 3 ? 1ull : 1ull << 20));          // slow bounded | slow unbounded << 20
+                atomicAdd(&lsa_plicp_cycles[7], (unsigned long long)cand | ((unsigned long long)(cand > 64) << 32));
+            }
+#endif
+            PSTAMP(6);
+            for (int sg = 0; sg < nseg; ++sg) {
+                const int a = sg == 0 ? lo0 : sg == 1 ? lo1 : lo2, e = sg == 0 ? hi0 : sg == 1 ? hi1 : hi2;
+                // (invalid reference rays carry coordinates of 1e150: their distance exceeds every limit)
+                int j = a;
+#ifdef LSA_PLICP_DIAG_NOSCAN
+                j = e + 1;
+#endif
+                for (; j + 3 <= e; j += 4) {
+                    const double d0 = plicp_dist2(wx, wy, L.rx[j], L.ry[j]), d1 = plicp_dist2(wx, wy, L.rx[j + 1], L.ry[j + 1]);
+                    const double d2 = plicp_dist2(wx, wy, L.rx[j + 2], L.ry[j + 2]), d3 = plicp_dist2(wx, wy, L.rx[j + 3], L.ry[j + 3]);
+                    if (!(d0 > lim) && (j1 == -1 || d0 < best)) { j1 = j; best = d0; }
+                    if (!(d1 > lim) && (j1 == -1 || d1 < best)) { j1 = j + 1; best = d1; }
+                    if (!(d2 > lim) && (j1 == -1 || d2 < best)) { j1 = j + 2; best = d2; }
+                    if (!(d3 > lim) && (j1 == -1 || d3 < best)) { j1 = j + 3; best = d3; }
+                }
+                for (; j <= e; ++j) {
+                    const double d = plicp_dist2(wx, wy, L.rx[j], L.ry[j]);
+                    if (!(d > lim) && (j1 == -1 || d < best)) { j1 = j; best = d; }
+                }
+            }
+            PSTAMP(7);
+            if (!(j1 == -1 || j1 == 0 || j1 == n - 1)) {
+                const int up = L.nup[j1] == 0xffff ? -1 : (int)L.nup[j1], down = L.ndown[j1] == 0xffff ? -1 : (int)L.ndown[j1];
+                int j2 = -1;
+                if (up == -1) j2 = down;
+                else if (down == -1) j2 = up;
+                else j2 = plicp_dist2(wx, wy, L.rx[up], L.ry[up]) < plicp_dist2(wx, wy, L.rx[down], L.ry[down]) ? up : down;
+                if (j2 >= 0) { rec = j1 | (j2 << 16); mine++; }
+            }
+        }
+        L.corr[i] = rec; L.d2[i] = best;
+    }
+    return mine;
+}
+
 // one icp_loop from q0; returns ok, x_new, total error, kept correspondences, iterations (all uniform)
 __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double q0[3], double x_new[3], double& total_error,
                            int& nvalid, int& iterations)
@@ -219,8 +369,6 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
     const double PI = 3.14159265358979323846;
     double x_old[3] = {q0[0], q0[1], q0[2]};
     uint32_t* hashes = (uint32_t*)(L.red + 96);            // up to 64 remembered correspondence sets (red: 0-3 sums, 10 flag, 12-19 histogram, 22-23 hash parts, 24-79 sums<14>)
-    const double min_theta = (double)(P.fi_min + P.dfi * 0), max_theta = (double)(P.fi_min + P.dfi * (n - 1));
-    const double angle_res = (max_theta - min_theta) / n;
     bool ok = true;
     int it;
 #ifdef LSA_PLICP_STAMPS
@@ -228,141 +376,7 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
 #endif
     for (it = 0; it < P.max_iterations; ++it) {
         const double cs = cos(x_old[2]), sn = sin(x_old[2]);
-        // moved points and correspondences
-        int mine = 0;
-        for (int i = tid; i < n; i += PLICP_THREADS) {
-            int rec = -1;
-            double best = 0;
-            if (L.sr[i] >= 0.0f) {
-                double spx, spy;
-                plicp_sens_point(L, n, i, spx, spy);
-                const double wx = cs * spx - sn * spy + x_old[0], wy = sn * spx + cs * spy + x_old[1];
-                int j1 = -1;
-                const double lim = P.max_correspondence_dist * P.max_correspondence_dist;
-                // The reference scans the window start_cell +- ceil((45 deg + atan(0.5 m / rho)) / res) around the
-                // point's bearing.  Exact pruning of that scan: a reference point on a ray at angular distance a
-                // from the bearing is at least rho sin(a) away (rho, if a >= 90 deg), so only rays within
-                // asin(sqrt(bound) / rho) of the bearing - or of its images one turn away - can hold the minimum;
-                // bound = the smaller of the correspondence limit and the distance of two seeds (the ray at the
-                // bearing, last iteration's match).  Fast path (nearly every point): the bearing lies inside the
-                // scan's field of view and the pruned range is well inside the +-45 deg that every window has, so
-                // the window itself never matters and single precision suffices for the range's centre and half
-                // width (the margins cover its error); the distances are always evaluated in double.
-                const int prev = L.corr[i] >= 0 ? (L.corr[i] & 0xffff) : -1;
-                const float wxf = (float)wx, wyf = (float)wy;
-                const float rho_f = sqrtf(wxf * wxf + wyf * wyf) * 0.99999f;
-                const float phi_f = atan2f(wyf, wxf);
-                const int c0f = (int)rintf((phi_f - (float)min_theta) / P.dfi);
-                const int range_min = (int)(fabs(P.max_angular_correction_deg * (PI / 180.0)) / angle_res);
-                bool fast = phi_f > (float)min_theta + 1e-3f && phi_f < (float)max_theta - 1e-3f && c0f >= 0 && c0f <= n - 1;
-                int lo0 = 0, hi0 = -1, nseg = 1, lo1 = 0, hi1 = -1, lo2 = 0, hi2 = -1;
-                if (fast) {
-                    double bound = lim;
-                    if (L.rx[c0f] < 1e100) { const double d = plicp_dist2(wx, wy, L.rx[c0f], L.ry[c0f]); bound = d < bound ? d : bound; }
-                    else {      // the nearest valid rays on either side of an invalid one (inside the +-45 deg of every window)
-                        const int su = L.nup[c0f], sd = L.ndown[c0f];
-                        if (su != 0xffff && su - c0f <= range_min - 8) { const double d = plicp_dist2(wx, wy, L.rx[su], L.ry[su]); bound = d < bound ? d : bound; }
-                        if (sd != 0xffff && c0f - sd <= range_min - 8) { const double d = plicp_dist2(wx, wy, L.rx[sd], L.ry[sd]); bound = d < bound ? d : bound; }
-                    }
-                    if (prev >= 0 && abs(prev - c0f) <= range_min - 8 && L.rx[prev] < 1e100) { const double d = plicp_dist2(wx, wy, L.rx[prev], L.ry[prev]); bound = d < bound ? d : bound; }
-                    // a poor bound (a quarter of the point's range or more) would mean a scan of hundreds of rays that
-                    // the whole wave waits for: a few more seeds at growing offsets usually find something closer
-                    if (__ballot(bound > 0.0625 * (double)(rho_f * rho_f))) {
-                        #pragma unroll
-                        for (int o = 2; o <= 32; o *= 2) {
-                            const int ja = c0f - o, jb = c0f + o;
-                            if (ja >= 0) { const double d = plicp_dist2(wx, wy, L.rx[ja], L.ry[ja]); bound = d < bound ? d : bound; }   // (invalid rays: 1e150)
-                            if (jb <= n - 1) { const double d = plicp_dist2(wx, wy, L.rx[jb], L.ry[jb]); bound = d < bound ? d : bound; }
-                        }
-                    }
-                    const float tq = sqrtf((float)bound) * 1.0001f / rho_f;
-                    const int M = tq < 1.0f ? (int)((tq + 0.5708f * tq * tq * tq) / P.dfi) + 5 : n;      // asin t <= t + (pi/2 - 1) t^3
-                    fast = M + 8 <= range_min;
-#ifdef LSA_PLICP_DIAG_FULLSCAN          // diagnostic build only: the reference's whole window, no pruning
-                    fast = false;
-#endif
-                    lo0 = c0f - M > 0 ? c0f - M : 0; hi0 = c0f + M < n - 1 ? c0f + M : n - 1;
-                    // (Scanning in rings outwards from the bearing with a half width that shrinks as closer points
-                    //  turn up was measured slower than this one ascending scan from the seeds' bound.)
-                }
-#ifdef LSA_PLICP_DIAG_NOSLOW
-                if (false) {
-#else
-                if (!fast) {
-#endif
-                    const double rho = sqrt(wx * wx + wy * wy);
-                    const double phi = atan2(wy, wx);
-                    const double delta = fabs(P.max_angular_correction_deg * (PI / 180.0)) + fabs(atan(P.max_linear_correction / rho));
-                    const int range = (int)ceil(delta / angle_res);
-                    double start_theta = phi;
-                    if (start_theta < min_theta) start_theta += 2 * PI;
-                    if (start_theta > max_theta) start_theta -= 2 * PI;
-                    const int start_cell = (int)((start_theta - min_theta) / (max_theta - min_theta) * n);
-                    int from = start_cell - range, to = start_cell + range;
-                    from = from < 0 ? 0 : (from > n - 1 ? n - 1 : from); to = to < 0 ? 0 : (to > n - 1 ? n - 1 : to);
-                    double bound = lim;
-                    const int cen = start_cell < from ? from : (start_cell > to ? to : start_cell);
-                    if (L.rx[cen] < 1e100) { const double d = plicp_dist2(wx, wy, L.rx[cen], L.ry[cen]); bound = d < bound ? d : bound; }
-                    if (prev >= from && prev <= to && L.rx[prev] < 1e100) { const double d = plicp_dist2(wx, wy, L.rx[prev], L.ry[prev]); bound = d < bound ? d : bound; }
-                    const double sb = sqrt(bound) * (1.0 + 1e-9) + 1e-12;
-                    lo0 = from; hi0 = to;
-#ifdef LSA_PLICP_DIAG_FULLSCAN
-                    if (false) {
-#else
-                    if (sb < rho) {
-#endif
-                        const double tq = sb / rho;                                      // asin t <= t + (pi/2 - 1) t^3 on [0, 1]
-                        const int M = (int)((tq + 0.5708 * tq * tq * tq) / (double)P.dfi) + 3;   // bearings are float(fi_min + dfi j): margin
-                        const int T = (int)rint(2 * PI / (double)P.dfi);
-                        const int c0 = (int)rint((phi - min_theta) / (double)P.dfi);
-                        // images c0 - T, c0, c0 + T in increasing order, each clipped to [from, to] and past the previous one
-                        int done = from - 1;
-                        lo0 = c0 - T - M > done + 1 ? c0 - T - M : done + 1; hi0 = c0 - T + M < to ? c0 - T + M : to; if (hi0 > done) done = hi0;
-                        lo1 = c0 - M > done + 1 ? c0 - M : done + 1;         hi1 = c0 + M < to ? c0 + M : to;         if (hi1 > done) done = hi1;
-                        lo2 = c0 + T - M > done + 1 ? c0 + T - M : done + 1; hi2 = c0 + T + M < to ? c0 + T + M : to;
-                        nseg = 3;
-                    }
-                }
-#ifdef LSA_PLICP_COUNTS
-                {
-                    const int cand = (hi0 >= lo0 ? hi0 - lo0 + 1 : 0) + (hi1 >= lo1 ? hi1 - lo1 + 1 : 0) + (hi2 >= lo2 ? hi2 - lo2 + 1 : 0);
-                    atomicAdd(&lsa_plicp_cycles[6], fast ? 0ull : (nseg == 3 ? 1ull : 1ull << 20));          // slow bounded | slow unbounded << 20
-                    atomicAdd(&lsa_plicp_cycles[7], (unsigned long long)cand | ((unsigned long long)(cand > 64) << 32));
-                }
-#endif
-                PSTAMP(6);
-                for (int sg = 0; sg < nseg; ++sg) {
-                    const int a = sg == 0 ? lo0 : sg == 1 ? lo1 : lo2, e = sg == 0 ? hi0 : sg == 1 ? hi1 : hi2;
-                    // (invalid reference rays carry coordinates of 1e150: their distance exceeds every limit)
-                    int j = a;
-#ifdef LSA_PLICP_DIAG_NOSCAN
-                    j = e + 1;
-#endif
-                    for (; j + 3 <= e; j += 4) {
-                        const double d0 = plicp_dist2(wx, wy, L.rx[j], L.ry[j]), d1 = plicp_dist2(wx, wy, L.rx[j + 1], L.ry[j + 1]);
-                        const double d2 = plicp_dist2(wx, wy, L.rx[j + 2], L.ry[j + 2]), d3 = plicp_dist2(wx, wy, L.rx[j + 3], L.ry[j + 3]);
-                        if (!(d0 > lim) && (j1 == -1 || d0 < best)) { j1 = j; best = d0; }
-                        if (!(d1 > lim) && (j1 == -1 || d1 < best)) { j1 = j + 1; best = d1; }
-                        if (!(d2 > lim) && (j1 == -1 || d2 < best)) { j1 = j + 2; best = d2; }
-                        if (!(d3 > lim) && (j1 == -1 || d3 < best)) { j1 = j + 3; best = d3; }
-                    }
-                    for (; j <= e; ++j) {
-                        const double d = plicp_dist2(wx, wy, L.rx[j], L.ry[j]);
-                        if (!(d > lim) && (j1 == -1 || d < best)) { j1 = j; best = d; }
-                    }
-                }
-                PSTAMP(7);
-                if (!(j1 == -1 || j1 == 0 || j1 == n - 1)) {
-                    const int up = L.nup[j1] == 0xffff ? -1 : (int)L.nup[j1], down = L.ndown[j1] == 0xffff ? -1 : (int)L.ndown[j1];
-                    int j2 = -1;
-                    if (up == -1) j2 = down;
-                    else if (down == -1) j2 = up;
-                    else j2 = plicp_dist2(wx, wy, L.rx[up], L.ry[up]) < plicp_dist2(wx, wy, L.rx[down], L.ry[down]) ? up : down;
-                    if (j2 >= 0) { rec = j1 | (j2 << 16); mine++; }
-                }
-            }
-            L.corr[i] = rec; L.d2[i] = best;
-        }
+        int mine = plicp_correspondences(P, L, x_old, cs, sn);
         const int num = (int)plicp_block_sum((double)mine, L.red);
         PSTAMP(0);
         const double fail_perc = 0.05;
@@ -517,15 +531,111 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
     return ok;
 }
 
+
+// n n^T (xx, xy, yy) of the line through a and b, as sm_icp's compute_C_k forms it (normal at pi/2 + atan2 of the direction)
+__device__ __forceinline__ void plicp_proj_C(double ax, double ay, double bx, double by, double C[3])
+{
+    const double alpha = 3.14159265358979323846 / 2 + atan2(by - ay, bx - ax);
+    const double c = cos(alpha), s = sin(alpha);
+    C[0] = c * c; C[1] = c * s; C[2] = s * s;
+}
+// d(n n^T) / d|a|: sm_icp's forward difference of 1 mm along the ray of a
+__device__ __forceinline__ void plicp_dC_drho(double ax, double ay, double bx, double by, double D[3])
+{
+    const double eps = 0.001, na = sqrt(ax * ax + ay * ay);
+    double C0[3], C1[3];
+    plicp_proj_C(ax, ay, bx, by, C0);
+    plicp_proj_C(ax + ax / na * eps, ay + ay / na * eps, bx, by, C1);
+    #pragma unroll
+    for (int k = 0; k < 3; ++k) D[k] = (C1[k] - C0[k]) / eps;
+}
+__device__ __forceinline__ double plicp_quad(const double u[2], const double C[3], const double v[2])
+{
+    return u[0] * (C[0] * v[0] + C[1] * v[1]) + u[1] * (C[1] * v[0] + C[2] * v[1]);
+}
+
+// sm_icp's covariance of the result (do_compute_covariance; A. Censi, ICRA 2007):
+//     cov = sigma^2 H^-1 (A1 A1^T + A2 A2^T) H^-1,  H = d2J/dx2,  A1 | A2 = d2J / dx d(reference | current readings),
+// over the correspondences in L.corr at the pose x.  The columns of A1 gather the contributions of every point matched
+// to a reference ray (as j1 or as j2): three LDS rows, accumulated with LDS double atomics, that take the place of the
+// reference points (rx, ry) and of d2 - the reference points are recomputed from the ranges in HBM/L2, bit for bit as
+// the set-up formed them.  Everything else is per point and summed with the fixed-order tree.
+__device__ void plicp_covariance(const PlicpParam& P, const PlicpLds& L, const float* __restrict__ g_ref_r, const double x[3],
+                                 double sigma, double* __restrict__ cov9)
+{
+    const int n = P.n, tid = threadIdx.x;
+    const double th = x[2], cs = cos(th), sn = sin(th);
+    double* a1x = L.rx; double* a1y = L.ry; double* a1t = L.d2;
+    __syncthreads();
+    for (int j = tid; j < n; j += PLICP_THREADS) { a1x[j] = 0; a1y[j] = 0; a1t[j] = 0; }
+    __syncthreads();
+    double s[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};          // H: xx xy xt yy yt tt | A2 A2^T: the same six
+    for (int i = tid; i < n; i += PLICP_THREADS) {
+        if (L.corr[i] < 0) continue;
+        const int j1 = L.corr[i] & 0xffff, j2 = L.corr[i] >> 16;
+        double px, py;
+        plicp_sens_point(L, n, i, px, py);
+        const double r1 = (double)g_ref_r[j1] / 100.0, r2 = (double)g_ref_r[j2] / 100.0;
+        const double q1x = L.trig[j1] * r1, q1y = L.trig[n + j1] * r1, q2x = L.trig[j2] * r2, q2y = L.trig[n + j2] * r2;
+        const double Rp[2] = {cs * px - sn * py, sn * px + cs * py};
+        const double v1[2] = {-sn * px - cs * py, cs * px - sn * py};                 // rot(theta + pi/2) p
+        const double v2[2] = {Rp[0] + x[0] - q1x, Rp[1] + x[1] - q1y};
+        const double vn[2] = {-Rp[0], -Rp[1]};                                         // rot(theta + pi) p
+        const double a = th + (double)(P.fi_min + P.dfi * i);
+        const double ca = cos(a), sa = sin(a);
+        const double v3[2] = {ca, sa}, v4[2] = {-sa, ca};
+        double C[3], D1[3], D2[3];
+        plicp_proj_C(q1x, q1y, q2x, q2y, C);
+        plicp_dC_drho(q1x, q1y, q2x, q2y, D1);
+        plicp_dC_drho(q2x, q2y, q1x, q1y, D2);
+        s[0] += 2 * C[0]; s[1] += 2 * C[1]; s[3] += 2 * C[2];
+        s[2] += 2 * (C[0] * v1[0] + C[1] * v1[1]); s[4] += 2 * (C[1] * v1[0] + C[2] * v1[1]);
+        s[5] += 2 * (plicp_quad(v2, C, vn) + plicp_quad(v1, C, v1));
+        const double a2[3] = {2 * (C[0] * v3[0] + C[1] * v3[1]), 2 * (C[1] * v3[0] + C[2] * v3[1]),
+                              2 * (plicp_quad(v2, C, v4) + plicp_quad(v3, C, v1))};
+        s[6] += a2[0] * a2[0]; s[7] += a2[0] * a2[1]; s[8] += a2[0] * a2[2]; s[9] += a2[1] * a2[1]; s[10] += a2[1] * a2[2]; s[11] += a2[2] * a2[2];
+        const double vj[2] = {L.trig[j1], L.trig[n + j1]};
+        atomicAdd(&a1x[j1], -2 * (C[0] * vj[0] + C[1] * vj[1]) + 2 * (D1[0] * v2[0] + D1[1] * v2[1]));
+        atomicAdd(&a1y[j1], -2 * (C[1] * vj[0] + C[2] * vj[1]) + 2 * (D1[1] * v2[0] + D1[2] * v2[1]));
+        atomicAdd(&a1t[j1], -2 * plicp_quad(vj, C, v1) + 2 * plicp_quad(v2, D1, v1));
+        atomicAdd(&a1x[j2], 2 * (D2[0] * v2[0] + D2[1] * v2[1]));
+        atomicAdd(&a1y[j2], 2 * (D2[1] * v2[0] + D2[2] * v2[1]));
+        atomicAdd(&a1t[j2], 2 * plicp_quad(v2, D2, v1));
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += PLICP_THREADS) {
+        const double ax = a1x[j], ay = a1y[j], at = a1t[j];
+        s[6] += ax * ax; s[7] += ax * ay; s[8] += ax * at; s[9] += ay * ay; s[10] += ay * at; s[11] += at * at;
+    }
+    plicp_block_sums<12>(s, L.red);
+    if (tid == 0) {
+        const double h00 = s[0], h01 = s[1], h02 = s[2], h11 = s[3], h12 = s[4], h22 = s[5];
+        const double c00 = h11 * h22 - h12 * h12, c01 = h02 * h12 - h01 * h22, c02 = h01 * h12 - h02 * h11;
+        const double c11 = h00 * h22 - h02 * h02, c12 = h01 * h02 - h00 * h12, c22 = h00 * h11 - h01 * h01;
+        const double det = h00 * c00 + h01 * c01 + h02 * c02;
+        if (!(fabs(det) > 1e-300)) { for (int k = 0; k < 9; ++k) cov9[k] = 0; }
+        else {
+            const double I[3][3] = {{c00 / det, c01 / det, c02 / det}, {c01 / det, c11 / det, c12 / det}, {c02 / det, c12 / det, c22 / det}};
+            const double Sm[3][3] = {{s[6], s[7], s[8]}, {s[7], s[9], s[10]}, {s[8], s[10], s[11]}};
+            double T[3][3];
+            for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) { T[r][k] = 0; for (int m = 0; m < 3; ++m) T[r][k] += I[r][m] * Sm[m][k]; }
+            for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) { double v = 0; for (int m = 0; m < 3; ++m) v += T[r][m] * I[m][k]; cov9[3 * r + k] = sigma * sigma * v; }
+        }
+    }
+    __syncthreads();
+}
+
 // scans: [S][n] ranges in cm (PMScan::r); out8[b] = {x, y, theta (m, m, rad), valid, error, iterations, kept, 0}
 // 128 registers: four workgroups per CU wherever the LDS allows (up to 541 beams; 1081 beams fit two and lose
 // nothing to the tighter register budget) - measured 11-18 % faster than 256 registers at 181 / 361 / 541 beams
-#ifndef LSA_PLICP_WG_PER_CU
-#define LSA_PLICP_WG_PER_CU 4
-#endif
-__global__ __launch_bounds__(PLICP_THREADS, LSA_PLICP_WG_PER_CU) void plicp_kernel(PlicpParam P, int B, const float* __restrict__ g_r,
+// WG = workgroups per CU the registers are budgeted for: 4 wherever the LDS allows four (up to 541 beams); beyond that the
+// LDS holds three at most, and the instance budgeted for three (168 registers instead of 128) keeps in registers what the
+// four-per-CU budget spills to scratch (540 B per lane there).  COV: also sm_icp's covariance of the result (d_cov9).
+template <int WG, bool COV>
+__global__ __launch_bounds__(PLICP_THREADS, WG) void plicp_kernel(PlicpParam P, int B, const float* __restrict__ g_r,
                                                               const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
-                                                              const double* __restrict__ trig, double* __restrict__ out8)
+                                                              const double* __restrict__ trig, double* __restrict__ out8,
+                                                              double sigma, double* __restrict__ cov9)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = P.n, Np = (n + 63) & ~63, tid = threadIdx.x;
@@ -568,7 +678,9 @@ __global__ __launch_bounds__(PLICP_THREADS, LSA_PLICP_WG_PER_CU) void plicp_kern
         int nvalid = 0, iters = 0;
         if (plicp_loop(P, L, q0, x, error, nvalid, iters)) {
             double best_error = error, best[3] = {x[0], x[1], x[2]};
+            bool restarted = false;
             if (P.restart && error / nvalid > P.restart_threshold_mean_error) {
+                restarted = true;
                 const double dt = P.restart_dt, dth = P.restart_dtheta;
                 for (int a = 0; a < 6; ++a) {
                     const double start[3] = {x[0] + (a == 0 ? dt : a == 1 ? -dt : 0.0), x[1] + (a == 2 ? dt : a == 3 ? -dt : 0.0),
@@ -582,6 +694,16 @@ __global__ __launch_bounds__(PLICP_THREADS, LSA_PLICP_WG_PER_CU) void plicp_kern
                 }
             }
             res[0] = best[0]; res[1] = best[1]; res[2] = best[2]; res[3] = 1; res[4] = best_error; res[5] = iters; res[6] = nvalid;
+            if (COV) {
+                if (restarted) {                  // sm_icp recomputes the correspondences at the result after restarts (no outlier rejection)
+                    __syncthreads();
+                    plicp_correspondences(P, L, best, cos(best[2]), sin(best[2]));
+                }
+                plicp_covariance(P, L, g_r + (size_t)ref_idx[b] * n, best, sigma, cov9 + 9 * (size_t)b);
+            }
+        } else if (COV) {
+            res[5] = iters;
+            if (tid < 9) cov9[9 * (size_t)b + tid] = 0;
         } else res[5] = iters;
         if (tid < 8) out8[8 * (size_t)b + tid] = res[tid];
     }

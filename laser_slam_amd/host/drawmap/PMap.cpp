@@ -45,7 +45,7 @@ void CPMap::initializeMap(int size_x, int size_y, int start_x, int start_y, floa
     if (!t_shared.ctx) {
         lsa_laser_param p;
         must(lsa_param_preset(&p, "LMS211"), "lsa_param_preset");
-        must(lsa_ctx_create(&t_shared.ctx, 0, &p), "lsa_ctx_create");
+        must(lsa_ctx_create(&t_shared.ctx, lsa_default_device(), &p), "lsa_ctx_create");
     }
     m_ctx = t_shared.ctx;
     must(lsa_grid_create(&m_grid, m_ctx, size_x, size_y, start_x, start_y, offset_x, offset_y, resolution), "lsa_grid_create");

@@ -37,7 +37,7 @@ float CICPWarpper::ICPMatch(float* rx, float* ry, int N1, float* ax, float* ay, 
     if (!m_ctx) {
         lsa_laser_param p;                                    // the context only provides device + stream here
         must(lsa_param_preset(&p, "LMS211"), "lsa_param_preset");
-        must(lsa_ctx_create(&m_ctx, 0, &p), "lsa_ctx_create");
+        must(lsa_ctx_create(&m_ctx, lsa_default_device(), &p), "lsa_ctx_create");
     }
     lsa_p2p_options o;
     o.max_iterations = m_maxIterations; o.threshold_dist = m_thresholdDist; o.threshold_ang = m_thresholdAng;

@@ -45,7 +45,9 @@ void must(int rc, const char* what)
 
 } // namespace
 
-CPolarMatch::CPolarMatch(string laser_name) : m_trajectory_path("zhnew.log"), pm_fi(0), pm_si(0), pm_co(0), m_bReady(false), m_ctx(0), m_tableLen(0)
+CPolarMatch::CPolarMatch(string laser_name)
+    : m_trajectory_path("zhnew.log"), pm_fi(0), pm_si(0), pm_co(0), m_bReady(false), m_accuracy_psm_path("err_psm.log"),
+      m_accuracy_icp_path("err_icp.log"), m_failed_psm(0), m_failed_icp(0), m_ctx(0), m_tableLen(0)
 {
     m_pParam = paramByName(laser_name);
     if (m_pParam == NULL) {
@@ -101,7 +103,7 @@ void CPolarMatch::syncParam()
     if (!m_bReady) throw std::runtime_error("CPolarMatch: laser not initialised");
     lsa_laser_param want = toCore(m_pParam);
     if (!m_ctx) {
-        must(lsa_ctx_create(&m_ctx, 0, &want), "lsa_ctx_create");
+        must(lsa_ctx_create(&m_ctx, lsa_default_device(), &want), "lsa_ctx_create");
         return;
     }
     lsa_laser_param have;
@@ -380,7 +382,68 @@ bool CPolarMatch::pm_is_corridor(PMScan* act)
     return st < PM_CORRIDOR_THRESHOLD;
 }
 
-// ---- batched path (addition) -------------------------------------------------------
+
+// ---- device-resident copy of m_SickScans for the batched drivers -------------------------------
+// All arrays are carved from the context's caller arena (lsa_ctx_arena: one grow-only block per context), so the
+// drivers below allocate nothing per call once the arena has reached the log's size.
+namespace {
+struct DevLog {
+    int S, B, n;
+    float* r; uint8_t* bad; uint16_t* seg; int32_t *ri, *ai, *st; float *pose, *init, *exy;
+};
+size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+}
+
+static void uploadLog(lsa_ctx* ctx, const vector<_PMScan*>& scans, int S, int n, DevLog& d, bool write_back)
+{
+    d.S = S; d.B = S - 1; d.n = n;
+    const size_t cells = (size_t)S * n, B = (size_t)(S - 1);
+    size_t off[10], o = 0;
+    const size_t sz[9] = {cells * 4, cells, cells * 2, B * 4, B * 4, B * 4, B * 12, B * 24, B * 8};
+    for (int k = 0; k < 9; ++k) { off[k] = o; o += up256(sz[k]); }
+    off[9] = o;
+    void* base = 0;
+    must(lsa_ctx_arena(ctx, off[9], &base), "lsa_ctx_arena");
+    char* b = (char*)base;
+    d.r = (float*)(b + off[0]); d.bad = (uint8_t*)(b + off[1]); d.seg = (uint16_t*)(b + off[2]);
+    d.ri = (int32_t*)(b + off[3]); d.ai = (int32_t*)(b + off[4]); d.st = (int32_t*)(b + off[5]);
+    d.pose = (float*)(b + off[6]); d.init = (float*)(b + off[7]); d.exy = (float*)(b + off[8]);
+    vector<float> r(cells);
+    vector<uint8_t> bad(cells);
+    vector<int32_t> ri(B), ai(B);
+    for (int k = 0; k < S; ++k) {
+        memcpy(&r[(size_t)k * n], scans[k]->r, sizeof(float) * n);
+        for (int i = 0; i < n; ++i) bad[(size_t)k * n + i] = (uint8_t)scans[k]->bad[i];
+    }
+    for (size_t p = 0; p < B; ++p) { ri[p] = (int32_t)p; ai[p] = (int32_t)p + 1; }
+    must(lsa_memcpy_h2d(ctx, d.r, r.data(), cells * 4), "h2d");
+    must(lsa_memcpy_h2d(ctx, d.bad, bad.data(), cells), "h2d");
+    must(lsa_memcpy_h2d(ctx, d.ri, ri.data(), B * 4), "h2d");
+    must(lsa_memcpy_h2d(ctx, d.ai, ai.data(), B * 4), "h2d");
+    must(lsa_preprocess_batch(ctx, S, d.r, d.bad, d.seg), "lsa_preprocess_batch");
+    if (!write_back) return;
+    // the frames come back preprocessed, as pm_preprocessScan leaves them
+    vector<uint16_t> seg(cells);
+    must(lsa_memcpy_d2h(ctx, r.data(), d.r, cells * 4), "d2h");
+    must(lsa_memcpy_d2h(ctx, bad.data(), d.bad, cells), "d2h");
+    must(lsa_memcpy_d2h(ctx, seg.data(), d.seg, cells * 2), "d2h");
+    for (int k = 0; k < S; ++k) {
+        memcpy(scans[k]->r, &r[(size_t)k * n], sizeof(float) * n);
+        for (int i = 0; i < n; ++i) { scans[k]->bad[i] = bad[(size_t)k * n + i]; scans[k]->seg[i] = seg[(size_t)k * n + i]; }
+    }
+}
+
+// one batched matcher launch over the consecutive pairs; init = NULL for the zero prior
+static void matchLog(lsa_ctx* ctx, int which, const DevLog& d, const vector<float>* init, vector<float>& pose, vector<int>& st)
+{
+    const size_t B = (size_t)d.B;
+    if (init) must(lsa_memcpy_h2d(ctx, d.init, init->data(), B * 24), "h2d");
+    must(lsa_match_batch(ctx, which, d.B, d.r, d.bad, d.seg, d.ri, d.ai, init ? d.init : 0, d.pose, 0, 0, 0, d.st, 0), "lsa_match_batch");
+    pose.resize(B * 3); st.resize(B);
+    must(lsa_memcpy_d2h(ctx, pose.data(), d.pose, B * 12), "d2h");
+    must(lsa_memcpy_d2h(ctx, st.data(), d.st, B * 4), "d2h");
+}
+
 // ---- offline drivers -----------------------------------------------------------------------
 void CPolarMatch::runFlirtFile(string filename, int run_num)           // :332-340
 {
@@ -439,62 +502,26 @@ void CPolarMatch::runlog(int run_num)
     if (S > 1) {
         syncParam();
         const int n = m_pParam->pm_l_points, B = S - 1;
-        vector<float> r((size_t)S * n);
-        vector<uint8_t> bad((size_t)S * n);
-        vector<uint16_t> seg((size_t)S * n);
-        vector<int32_t> ri(B), ai(B);
-        for (int k = 0; k < S; ++k) {
-            memcpy(&r[(size_t)k * n], m_SickScans[k]->r, sizeof(float) * n);
-            for (int i = 0; i < n; ++i) bad[(size_t)k * n + i] = (uint8_t)m_SickScans[k]->bad[i];
-        }
-        for (int b = 0; b < B; ++b) { ri[b] = b; ai[b] = b + 1; }
-        void *d_r = 0, *d_bad = 0, *d_seg = 0, *d_ri = 0, *d_ai = 0, *d_pose = 0, *d_st = 0, *d_init = 0, *d_exy = 0;
-        must(lsa_malloc(&d_r, r.size() * 4), "lsa_malloc"); must(lsa_malloc(&d_bad, bad.size()), "lsa_malloc");
-        must(lsa_malloc(&d_seg, bad.size() * 2), "lsa_malloc");
-        must(lsa_malloc(&d_ri, (size_t)B * 4), "lsa_malloc"); must(lsa_malloc(&d_ai, (size_t)B * 4), "lsa_malloc");
-        must(lsa_malloc(&d_pose, (size_t)B * 12), "lsa_malloc"); must(lsa_malloc(&d_st, (size_t)B * 4), "lsa_malloc");
-        must(lsa_malloc(&d_init, (size_t)B * 24), "lsa_malloc"); must(lsa_malloc(&d_exy, (size_t)B * 8), "lsa_malloc");
-        must(lsa_memcpy_h2d(m_ctx, d_r, r.data(), r.size() * 4), "h2d");
-        must(lsa_memcpy_h2d(m_ctx, d_bad, bad.data(), bad.size()), "h2d");
-        must(lsa_memcpy_h2d(m_ctx, d_ri, ri.data(), (size_t)B * 4), "h2d");
-        must(lsa_memcpy_h2d(m_ctx, d_ai, ai.data(), (size_t)B * 4), "h2d");
-        must(lsa_preprocess_batch(m_ctx, S, (float*)d_r, (uint8_t*)d_bad, (uint16_t*)d_seg), "lsa_preprocess_batch");
-        // the frames come back preprocessed, as pm_preprocessScan leaves them
-        must(lsa_memcpy_d2h(m_ctx, r.data(), d_r, r.size() * 4), "d2h");
-        must(lsa_memcpy_d2h(m_ctx, bad.data(), d_bad, bad.size()), "d2h");
-        must(lsa_memcpy_d2h(m_ctx, seg.data(), d_seg, seg.size() * 2), "d2h");
-        for (int k = 0; k < S; ++k) {
-            memcpy(m_SickScans[k]->r, &r[(size_t)k * n], sizeof(float) * n);
-            for (int i = 0; i < n; ++i) { m_SickScans[k]->bad[i] = bad[(size_t)k * n + i]; m_SickScans[k]->seg[i] = seg[(size_t)k * n + i]; }
-        }
-        vector<float> p_psm((size_t)B * 3), p_icp((size_t)B * 3), init((size_t)B * 6, 0.0f);
-        vector<int> st_psm(B), st_icp(B);
-        must(lsa_match_batch(m_ctx, LSA_MATCH_PSM, B, (float*)d_r, (uint8_t*)d_bad, (uint16_t*)d_seg, (int32_t*)d_ri, (int32_t*)d_ai,
-                             0, (float*)d_pose, 0, 0, 0, (int32_t*)d_st, 0), "lsa_match_batch");
-        must(lsa_memcpy_d2h(m_ctx, p_psm.data(), d_pose, (size_t)B * 12), "d2h");
-        must(lsa_memcpy_d2h(m_ctx, st_psm.data(), d_st, (size_t)B * 4), "d2h");
+        DevLog d;
+        uploadLog(m_ctx, m_SickScans, S, n, d, true);
+        vector<float> p_psm, p_icp, init((size_t)B * 6, 0.0f);
+        vector<int> st_psm, st_icp;
+        matchLog(m_ctx, LSA_MATCH_PSM, d, 0, p_psm, st_psm);
         for (int b = 0; b < B; ++b)
-            if (st_psm[b] == 0) for (int d = 0; d < 3; ++d) init[(size_t)b * 6 + 3 + d] = p_psm[(size_t)b * 3 + d];
-        must(lsa_memcpy_h2d(m_ctx, d_init, init.data(), (size_t)B * 24), "h2d");
-        must(lsa_match_batch(m_ctx, LSA_MATCH_ICP, B, (float*)d_r, (uint8_t*)d_bad, (uint16_t*)d_seg, (int32_t*)d_ri, (int32_t*)d_ai,
-                             (float*)d_init, (float*)d_pose, 0, 0, 0, (int32_t*)d_st, 0), "lsa_match_batch");
-        must(lsa_memcpy_d2h(m_ctx, p_icp.data(), d_pose, (size_t)B * 12), "d2h");
-        must(lsa_memcpy_d2h(m_ctx, st_icp.data(), d_st, (size_t)B * 4), "d2h");
+            if (st_psm[b] == 0) for (int k = 0; k < 3; ++k) init[(size_t)b * 6 + 3 + k] = p_psm[(size_t)b * 3 + k];
+        matchLog(m_ctx, LSA_MATCH_ICP, d, &init, p_icp, st_icp);
         for (int b = 0; b < B; ++b) {
             // pm_icp ok: its pose; pm_icp threw (the retry at :470-476 sees the same state and throws again): the pose
             // pm_psm left, zero if that threw too
             failed_pair[b] = st_icp[b] != 0;
-            for (int d = 0; d < 3; ++d) {
-                rel[(size_t)b * 3 + d] = st_icp[b] == 0 ? p_icp[(size_t)b * 3 + d] : init[(size_t)b * 6 + 3 + d];
-                init[(size_t)b * 6 + 3 + d] = rel[(size_t)b * 3 + d];
+            for (int k = 0; k < 3; ++k) {
+                rel[(size_t)b * 3 + k] = st_icp[b] == 0 ? p_icp[(size_t)b * 3 + k] : init[(size_t)b * 6 + 3 + k];
+                init[(size_t)b * 6 + 3 + k] = rel[(size_t)b * 3 + k];
             }
         }
-        must(lsa_memcpy_h2d(m_ctx, d_init, init.data(), (size_t)B * 24), "h2d");
-        must(lsa_error_index2_batch(m_ctx, B, (float*)d_r, (uint8_t*)d_bad, (uint16_t*)d_seg, (int32_t*)d_ri, (int32_t*)d_ai,
-                                    (float*)d_init, (float*)d_exy, 0), "lsa_error_index2_batch");
-        must(lsa_memcpy_d2h(m_ctx, exy.data(), d_exy, (size_t)B * 8), "d2h");
-        lsa_free(d_r); lsa_free(d_bad); lsa_free(d_seg); lsa_free(d_ri); lsa_free(d_ai); lsa_free(d_pose); lsa_free(d_st);
-        lsa_free(d_init); lsa_free(d_exy);
+        must(lsa_memcpy_h2d(m_ctx, d.init, init.data(), (size_t)B * 24), "h2d");
+        must(lsa_error_index2_batch(m_ctx, B, d.r, d.bad, d.seg, d.ri, d.ai, d.init, d.exy, 0), "lsa_error_index2_batch");
+        must(lsa_memcpy_d2h(m_ctx, exy.data(), d.exy, (size_t)B * 8), "d2h");
     } else if (S == 1) pm_preprocessScan(m_SickScans[0]);
 
     double rx = 0, ry = 0, th = 0;                                      // global pose, cm / rad
@@ -613,30 +640,101 @@ bool CPolarMatch::matchConsecutive(int which, vector<float>& poses, vector<int>&
     syncParam();
     const int S = (int)m_SickScans.size(), n = m_pParam->pm_l_points;
     if (S < 2) return false;
-    vector<float> r((size_t)S * n);
-    vector<uint8_t> bad((size_t)S * n);
-    vector<int32_t> ri(S - 1), ai(S - 1);
-    for (int k = 0; k < S; ++k) {
-        memcpy(&r[(size_t)k * n], m_SickScans[k]->r, sizeof(float) * n);
-        for (int i = 0; i < n; ++i) bad[(size_t)k * n + i] = (uint8_t)m_SickScans[k]->bad[i];
-    }
-    for (int b = 0; b < S - 1; ++b) { ri[b] = b; ai[b] = b + 1; }
-    void *d_r = 0, *d_bad = 0, *d_seg = 0, *d_ri = 0, *d_ai = 0, *d_pose = 0, *d_st = 0;
-    must(lsa_malloc(&d_r, r.size() * 4), "lsa_malloc"); must(lsa_malloc(&d_bad, bad.size()), "lsa_malloc");
-    must(lsa_malloc(&d_seg, bad.size() * 2), "lsa_malloc");
-    must(lsa_malloc(&d_ri, ri.size() * 4), "lsa_malloc"); must(lsa_malloc(&d_ai, ai.size() * 4), "lsa_malloc");
-    must(lsa_malloc(&d_pose, (size_t)(S - 1) * 12), "lsa_malloc"); must(lsa_malloc(&d_st, (size_t)(S - 1) * 4), "lsa_malloc");
-    must(lsa_memcpy_h2d(m_ctx, d_r, r.data(), r.size() * 4), "h2d");
-    must(lsa_memcpy_h2d(m_ctx, d_bad, bad.data(), bad.size()), "h2d");
-    must(lsa_memcpy_h2d(m_ctx, d_ri, ri.data(), ri.size() * 4), "h2d");
-    must(lsa_memcpy_h2d(m_ctx, d_ai, ai.data(), ai.size() * 4), "h2d");
-    must(lsa_preprocess_batch(m_ctx, S, (float*)d_r, (uint8_t*)d_bad, (uint16_t*)d_seg), "lsa_preprocess_batch");
-    must(lsa_match_batch(m_ctx, which, S - 1, (float*)d_r, (uint8_t*)d_bad, (uint16_t*)d_seg, (int32_t*)d_ri,
-                         (int32_t*)d_ai, 0, (float*)d_pose, 0, 0, 0, (int32_t*)d_st, 0), "lsa_match_batch");
-    poses.resize((size_t)(S - 1) * 3);
-    status.resize(S - 1);
-    must(lsa_memcpy_d2h(m_ctx, poses.data(), d_pose, poses.size() * 4), "d2h");
-    must(lsa_memcpy_d2h(m_ctx, status.data(), d_st, status.size() * 4), "d2h");
-    lsa_free(d_r); lsa_free(d_bad); lsa_free(d_seg); lsa_free(d_ri); lsa_free(d_ai); lsa_free(d_pose); lsa_free(d_st);
+    DevLog d;
+    uploadLog(m_ctx, m_SickScans, S, n, d, false);
+    matchLog(m_ctx, which, d, 0, poses, status);
     return true;
+}
+
+// run511Data, :678-734.  Every accepted frame is matched with pm_psm against the last frame that matched (or the
+// first frame), both from a zero prior, and the pose is chained in cm.  A failed frame is dropped and the reference
+// frame stays, so the chain is sequential: single-pair calls, like the reference.
+void CPolarMatch::run511Data(string filename, int run_num)
+{
+    if (!m_bReady) { cout << "Laser is not initialized!" << endl; return; }
+    ofstream trajectory(m_trajectory_path.c_str());
+    if (run_num < 0) run_num = 1000001;
+    double rx = 0, ry = 0, th = 0;                     // robot starts at 0,0,0
+    PMScan ls(m_pParam->pm_l_points), ls_last(m_pParam->pm_l_points);
+    ls.rx = ls.ry = ls.th = 0; ls.t = 0;
+    for (int i = 0; i < ls.np; ++i) { ls.seg[i] = 0; ls.bad[i] = 0; ls.r[i] = ls.x[i] = ls.y[i] = 0; }
+    ifstream inf(filename.c_str());
+    if (!inf.is_open()) { cout << "failed to open file: " << filename << endl; return; }
+    bool first = true;
+    int cnt = 0;
+    string line;
+    while (cnt < run_num && getline(inf, line)) {
+        vector<char> buf(line.begin(), line.end()); buf.push_back(0);
+        if (buf.size() < 2 || !construct511Data(buf.data(), ls)) continue;
+        cnt++;
+        pm_preprocessScan(&ls);
+        if (first) {
+            ls_last = ls;
+            first = false;
+            trajectory << ls.rx << " " << ls.ry << " " << ls.th << endl;
+            continue;
+        }
+        try {
+            ls.rx = ls_last.rx = 0; ls.ry = ls_last.ry = 0; ls.th = ls_last.th = 0;
+            pm_psm(&ls_last, &ls);
+            const double xx = ls.rx * cos(th) - ls.ry * sin(th) + rx;
+            const double yy = ls.rx * sin(th) + ls.ry * cos(th) + ry;
+            const double tth = th + ls.th;
+            rx = xx; ry = yy; th = tth;
+            ls_last = ls;
+            trajectory << rx << " " << ry << " " << th << endl;
+        } catch (int) {
+            cout << "psm failed!" << endl;
+        }
+    }
+}
+
+// testAccuracy, :364-447.  Both matchers start every pair from a zero prior on the previous frame, so all pairs go
+// through two batched launches; the per-pair bookkeeping (ground-truth increment from the log's laser poses, the
+// 1 m / 0.6982 rad gate on what is logged, the failure counters) follows the reference line by line.  As there, a
+// failed match leaves the zero pose in place and its "error" is still tested against the gate.
+void CPolarMatch::testAccuracy(string filename)
+{
+    using zhpsm::OrientedPoint2D;
+    if (!readFlirt(filename)) { cout << "failed to read file: " << filename << endl; return; }
+    ofstream psm_log(m_accuracy_psm_path.c_str()), icp_log(m_accuracy_icp_path.c_str());
+    m_failed_psm = m_failed_icp = 0;
+    const int S = (int)m_SickScans.size(), n = m_pParam->pm_l_points;
+    const double odometry_thre = 0.6982, dis_squre_thre = 1;
+    vector<float> p_psm, p_icp;
+    vector<int> st_psm, st_icp;
+    if (S > 1) {
+        syncParam();
+        DevLog d;
+        uploadLog(m_ctx, m_SickScans, S, n, d, true);
+        matchLog(m_ctx, LSA_MATCH_PSM, d, 0, p_psm, st_psm);
+        matchLog(m_ctx, LSA_MATCH_ICP, d, 0, p_icp, st_icp);
+    } else if (S == 1) pm_preprocessScan(m_SickScans[0]);
+    OrientedPoint2D last_pose;
+    for (int cnt = 0; cnt < S; ++cnt) {
+        PMScan* ls = m_SickScans[cnt];
+        const OrientedPoint2D here(ls->rx, ls->ry, ls->th);
+        if (cnt == 0) { last_pose = here; continue; }
+        const OrientedPoint2D gt_trans(last_pose.ominus(here));
+        last_pose = here;
+        const int b = cnt - 1;
+        for (int which = 0; which < 2; ++which) {
+            const bool failed = (which == 0 ? st_psm[b] : st_icp[b]) != 0;
+            const float* p = which == 0 ? &p_psm[(size_t)b * 3] : &p_icp[(size_t)b * 3];
+            if (failed) {
+                if (which == 0) { m_failed_psm++; cout << "psm failed at " << cnt + 1 << endl; }
+                else { m_failed_icp++; cout << "icp failed at " << cnt + 1 << endl; }
+            }
+            // a throw leaves lsa at the zero prior (:389-391, :412-414)
+            const OrientedPoint2D trans(failed ? 0.0 : p[0] / 100.0, failed ? 0.0 : p[1] / 100.0, failed ? 0.0 : p[2]);
+            const double dis_err = sqrt((trans.x - gt_trans.x) * (trans.x - gt_trans.x) + (trans.y - gt_trans.y) * (trans.y - gt_trans.y));
+            const double angle_err = fabs(trans.theta - gt_trans.theta);
+            if (dis_err < dis_squre_thre && angle_err < odometry_thre) (which == 0 ? psm_log : icp_log) << dis_err << "\t" << angle_err << endl;
+            // the frame keeps the last matcher's pose, as the reference leaves it
+            ls->rx = failed ? 0.0f : p[0]; ls->ry = failed ? 0.0f : p[1]; ls->th = failed ? 0.0f : p[2];
+        }
+        m_SickScans[b]->rx = m_SickScans[b]->ry = m_SickScans[b]->th = 0;
+    }
+    cout << "Number of failed psm : " << m_failed_psm << endl;
+    cout << "Number of failed icp : " << m_failed_icp << endl;
 }

@@ -46,6 +46,9 @@ public:
     void runSICKFile(string filename, int run_num = -1);
     void runFlirtFile(string filename, int run_num = -1);
     void runOurFile(string filename, int run_num = -1);
+    // "timestamp n r_1 .. r_n" lines (construct511Data), every frame against its predecessor with pm_psm from a
+    // zero prior, poses chained in cm (:678-734); trajectory to m_trajectory_path instead of the hard-coded file
+    void run511Data(string filename, int run_num = -1);
     bool construct511Data(char* line, PMScan& scan);        // "timestamp n r_1 .. r_n" [m], :649-667
     void runlog(int run_num);                                // odometry-gated PSM+ICP chain, metres out
     void runlogImproved(int run_num);                        // PSM with reference switching, ICP fallback, cm out
@@ -69,6 +72,13 @@ public:
 
 public:
     void clearRecord();
+    // accuracy harness (:364-447): readFlirt, then pm_psm and pm_icp from a zero prior for every frame against its
+    // predecessor, errors against the log's laser-pose increments.  One "dis_err<TAB>angle_err" line per pair that
+    // passes the reference's 1 m / 0.6982 rad gate goes to m_accuracy_psm_path / m_accuracy_icp_path (the reference
+    // hard-codes /mnt/hgfs/SharedFold/log/err_{psm,icp}.log); the failure counts are printed and kept below.
+    void testAccuracy(string filename);
+    string m_accuracy_psm_path, m_accuracy_icp_path;
+    int m_failed_psm, m_failed_icp;
 
     // ---- additions (not in the reference): the batched path the throughput comes from.
     // Matches scan k against scan k-1 for every k in m_SickScans (zero initial guess,

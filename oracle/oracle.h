@@ -159,6 +159,8 @@ typedef struct orc_plicp_params {
 void orc_plicp_params_default(orc_plicp_params* P);
 void orc_plicp(const float* ref_r_cm, const float* cur_r_cm, int n, float fi_min, float dfi, int min_range_cm,
                int max_range_cm, const orc_plicp_params* P, double out[8]);
+void orc_plicp_cov(const float* ref_r_cm, const float* cur_r_cm, int n, float fi_min, float dfi, int min_range_cm,
+                   int max_range_cm, const orc_plicp_params* P, double sigma, double out[8], double cov9[9], int* corr_out);
 
 /* classic point-to-point ICP with CICPWarpper's options (MRPT absent: PARITY UNPINNED), p2p_oracle.c */
 void orc_p2p_icp(const float* rx, const float* ry, int n1, const float* cx, const float* cy, int n2,

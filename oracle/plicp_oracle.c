@@ -17,7 +17,14 @@
  *   stop: |dt| < 1e-3 m and |dtheta| < 1e-3 rad, at most 10 iterations, or a repeated state;
  *   restart: if the mean error exceeds 0.01 the loop is rerun from six perturbed starts
  *       (+-0.01 m in x, y, +-0.0261799 rad) and the lowest total error wins.
- * ml / sigma weights, alpha test, visibility test and the covariance are switched off there.
+ * ml / sigma weights, alpha test and visibility test are switched off there; the covariance
+ * (do_compute_covariance, CCanonicalMatcher::setCov -> FMatchKeyFrame2, :79-81, :287-298) is restated in
+ * orc_plicp_cov below: A. Censi, "An accurate closed-form estimate of ICP's covariance", ICRA 2007,
+ *       cov(x) = sigma^2 H^-1 (A1 A1^T + A2 A2^T) H^-1,  H = d2J/dx2,  A1 | A2 = d2J/dx d(rho_ref | rho_sens),
+ *       J = sum_i (n_i^T (R p_i + t - p_j1))^2 over the final correspondences (those of the last iteration, or
+ *       recomputed at the result without outlier rejection when the loop was restarted, as sm_icp does), with
+ *       the derivative of the projector n n^T with respect to a reference reading taken as sm_icp takes it:
+ *       a forward difference of 1 mm along the ray.
  */
 #include "oracle.h"
 #include <math.h>
@@ -303,8 +310,101 @@ void orc_plicp_params_default(orc_plicp_params* P)           /* ZHCanonical_Matc
 /* CCanonicalMatcher::FMatch(LDP, LDP) -> sm_icp, first guess 0; ranges in cm as in PMScan.
  * out[0..2] = pose of the current scan in the reference scan's frame (m, m, rad),
  * out[3] = valid, out[4] = total error, out[5] = iterations, out[6] = correspondences kept */
+static void proj_C(double ax, double ay, double bx, double by, double C[3])      /* n n^T of the line a-b: xx, xy, yy */
+{
+    const double dx = bx - ax, dy = by - ay, alpha = 3.14159265358979323846 / 2 + atan2(dy, dx);
+    const double c = cos(alpha), s = sin(alpha);
+    C[0] = c * c; C[1] = c * s; C[2] = s * s;
+}
+
+static void dC_drho(double ax, double ay, double bx, double by, double D[3])    /* d(n n^T) / d|a|, forward difference */
+{
+    const double eps = 0.001, na = sqrt(ax * ax + ay * ay);
+    double C0[3], C1[3];
+    proj_C(ax, ay, bx, by, C0);
+    proj_C(ax + ax / na * eps, ay + ay / na * eps, bx, by, C1);
+    for (int k = 0; k < 3; ++k) D[k] = (C1[k] - C0[k]) / eps;
+}
+
+static double quad(const double u[2], const double C[3], const double v[2])    /* u^T C v */
+{
+    return u[0] * (C[0] * v[0] + C[1] * v[1]) + u[1] * (C[1] * v[0] + C[2] * v[1]);
+}
+
+/* cov9 = sigma^2 H^-1 (A1 A1^T + A2 A2^T) H^-1 at x for the correspondences c; returns 0 if H is singular */
+static int covariance_exact(const scan_t* ref, const scan_t* sens, const corr_t* c, const double x[3], double sigma, double cov9[9])
+{
+    const int n = sens->n;
+    const double th = x[2], cs = cos(th), sn = sin(th);
+    double H[6] = {0, 0, 0, 0, 0, 0};                       /* xx xy xt yy yt tt */
+    double S[6] = {0, 0, 0, 0, 0, 0};                       /* A1 A1^T + A2 A2^T */
+    double* A1 = (double*)calloc((size_t)3 * ref->n, sizeof(double));
+    for (int i = 0; i < n; ++i) {
+        if (!c[i].valid) continue;
+        const int j1 = c[i].j1, j2 = c[i].j2;
+        const double px = sens->px[i], py = sens->py[i];
+        const double Rp[2] = {cs * px - sn * py, sn * px + cs * py};
+        const double v1[2] = {-sn * px - cs * py, cs * px - sn * py};             /* rot(th + pi/2) p */
+        const double v2[2] = {Rp[0] + x[0] - ref->px[j1], Rp[1] + x[1] - ref->py[j1]};
+        const double vn[2] = {-Rp[0], -Rp[1]};                                     /* rot(th + pi) p */
+        const double a = th + sens->theta[i];
+        const double v3[2] = {cos(a), sin(a)}, v4[2] = {-sin(a), cos(a)};
+        double C[3], D1[3], D2[3];
+        proj_C(ref->px[j1], ref->py[j1], ref->px[j2], ref->py[j2], C);
+        dC_drho(ref->px[j1], ref->py[j1], ref->px[j2], ref->py[j2], D1);
+        dC_drho(ref->px[j2], ref->py[j2], ref->px[j1], ref->py[j1], D2);
+        H[0] += 2 * C[0]; H[1] += 2 * C[1]; H[3] += 2 * C[2];
+        H[2] += 2 * (C[0] * v1[0] + C[1] * v1[1]); H[4] += 2 * (C[1] * v1[0] + C[2] * v1[1]);
+        H[5] += 2 * (quad(v2, C, vn) + quad(v1, C, v1));
+        const double a2[3] = {2 * (C[0] * v3[0] + C[1] * v3[1]), 2 * (C[1] * v3[0] + C[2] * v3[1]), 2 * (quad(v2, C, v4) + quad(v3, C, v1))};
+        S[0] += a2[0] * a2[0]; S[1] += a2[0] * a2[1]; S[2] += a2[0] * a2[2]; S[3] += a2[1] * a2[1]; S[4] += a2[1] * a2[2]; S[5] += a2[2] * a2[2];
+        const double vj[2] = {cos(ref->theta[j1]), sin(ref->theta[j1])};
+        A1[3 * j1 + 0] += -2 * (C[0] * vj[0] + C[1] * vj[1]) + 2 * (D1[0] * v2[0] + D1[1] * v2[1]);
+        A1[3 * j1 + 1] += -2 * (C[1] * vj[0] + C[2] * vj[1]) + 2 * (D1[1] * v2[0] + D1[2] * v2[1]);
+        A1[3 * j1 + 2] += -2 * quad(vj, C, v1) + 2 * quad(v2, D1, v1);
+        A1[3 * j2 + 0] += 2 * (D2[0] * v2[0] + D2[1] * v2[1]);
+        A1[3 * j2 + 1] += 2 * (D2[1] * v2[0] + D2[2] * v2[1]);
+        A1[3 * j2 + 2] += 2 * quad(v2, D2, v1);
+    }
+    for (int j = 0; j < ref->n; ++j) {
+        const double* a = A1 + 3 * j;
+        S[0] += a[0] * a[0]; S[1] += a[0] * a[1]; S[2] += a[0] * a[2]; S[3] += a[1] * a[1]; S[4] += a[1] * a[2]; S[5] += a[2] * a[2];
+    }
+    free(A1);
+    /* H^-1 (symmetric 3x3, adjugate) */
+    const double h00 = H[0], h01 = H[1], h02 = H[2], h11 = H[3], h12 = H[4], h22 = H[5];
+    const double c00 = h11 * h22 - h12 * h12, c01 = h02 * h12 - h01 * h22, c02 = h01 * h12 - h02 * h11;
+    const double c11 = h00 * h22 - h02 * h02, c12 = h01 * h02 - h00 * h12, c22 = h00 * h11 - h01 * h01;
+    const double det = h00 * c00 + h01 * c01 + h02 * c02;
+    memset(cov9, 0, sizeof(double) * 9);
+    if (!(fabs(det) > 1e-300)) return 0;
+    const double I[3][3] = {{c00 / det, c01 / det, c02 / det}, {c01 / det, c11 / det, c12 / det}, {c02 / det, c12 / det, c22 / det}};
+    const double Sm[3][3] = {{S[0], S[1], S[2]}, {S[1], S[3], S[4]}, {S[2], S[4], S[5]}};
+    double T[3][3];
+    for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) { T[r][k] = 0; for (int m = 0; m < 3; ++m) T[r][k] += I[r][m] * Sm[m][k]; }
+    for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) { double v = 0; for (int m = 0; m < 3; ++m) v += T[r][m] * I[m][k]; cov9[3 * r + k] = sigma * sigma * v; }
+    return 1;
+}
+
+static void plicp_run(const float* ref_r_cm, const float* cur_r_cm, int n, float fi_min, float dfi, int min_range_cm,
+                      int max_range_cm, const orc_plicp_params* P, double out[8], double sigma, double* cov9, int* corr_out);
+
 void orc_plicp(const float* ref_r_cm, const float* cur_r_cm, int n, float fi_min, float dfi, int min_range_cm,
                int max_range_cm, const orc_plicp_params* P, double out[8])
+{
+    plicp_run(ref_r_cm, cur_r_cm, n, fi_min, dfi, min_range_cm, max_range_cm, P, out, 0.0, 0, 0);
+}
+
+/* orc_plicp + sm_icp's covariance (sigma = sm_params.sigma, 0.04 in the reference, :104); corr_out (2 n ints, may be
+ * NULL) receives the correspondences the covariance was formed over: j1, j2 per current ray, -1 = none */
+void orc_plicp_cov(const float* ref_r_cm, const float* cur_r_cm, int n, float fi_min, float dfi, int min_range_cm,
+                   int max_range_cm, const orc_plicp_params* P, double sigma, double out[8], double cov9[9], int* corr_out)
+{
+    plicp_run(ref_r_cm, cur_r_cm, n, fi_min, dfi, min_range_cm, max_range_cm, P, out, sigma, cov9, corr_out);
+}
+
+static void plicp_run(const float* ref_r_cm, const float* cur_r_cm, int n, float fi_min, float dfi, int min_range_cm,
+                      int max_range_cm, const orc_plicp_params* P, double out[8], double sigma, double* cov9, int* corr_out)
 {
     scan_t ref, sens;
     scan_init(&ref, ref_r_cm, n, fi_min, dfi, min_range_cm, max_range_cm);
@@ -314,9 +414,13 @@ void orc_plicp(const float* ref_r_cm, const float* cur_r_cm, int n, float fi_min
     double x[3] = {0, 0, 0}, error = 0;
     int nvalid = 0, iters = 0;
     memset(out, 0, sizeof(double) * 8);
+    if (cov9) memset(cov9, 0, sizeof(double) * 9);
+    if (corr_out) for (int i = 0; i < 2 * n; ++i) corr_out[i] = -1;
     if (icp_loop(P, &ref, &sens, c, q0, x, &error, &nvalid, &iters)) {
         double best_error = error, best[3] = {x[0], x[1], x[2]};
+        int restarted = 0;
         if (P->restart && error / nvalid > P->restart_threshold_mean_error) {
+            restarted = 1;
             const double dt = P->restart_dt, dth = P->restart_dtheta;
             const double perturb[6][3] = {{dt, 0, 0}, {-dt, 0, 0}, {0, dt, 0}, {0, -dt, 0}, {0, 0, dth}, {0, 0, -dth}};
             for (int a = 0; a < 6; ++a) {
@@ -329,6 +433,18 @@ void orc_plicp(const float* ref_r_cm, const float* cur_r_cm, int n, float fi_min
             }
         }
         out[0] = best[0]; out[1] = best[1]; out[2] = best[2]; out[3] = 1; out[4] = best_error; out[5] = iters; out[6] = nvalid;
+        if (cov9) {
+            if (restarted) {                     /* sm_icp recomputes the correspondences at the result after restarts */
+                const double cs = cos(best[2]), sn = sin(best[2]);
+                for (int i = 0; i < sens.n; ++i) {
+                    sens.wx[i] = cs * sens.px[i] - sn * sens.py[i] + best[0];
+                    sens.wy[i] = sn * sens.px[i] + cs * sens.py[i] + best[1];
+                }
+                find_correspondences(P, &ref, &sens, c);
+            }
+            covariance_exact(&ref, &sens, c, best, sigma, cov9);
+            if (corr_out) for (int i = 0; i < n; ++i) if (c[i].valid) { corr_out[2 * i] = c[i].j1; corr_out[2 * i + 1] = c[i].j2; }
+        }
     } else { out[5] = iters; }
     free(c); scan_free(&ref); scan_free(&sens);
 }

@@ -213,8 +213,57 @@ static int run_corridor(const char* laser, const char* fi_min, const char* fi_ma
     return 0;
 }
 
+// csmx <laser> <log> <tag>: CCanonicalMatcher's laser_data-typed overloads and FMatchKeyFrame2 with sm_icp's covariance
+static int run_csmx(const char* laser, const char* log, const char* tag)
+{
+    CPolarMatch pm(laser);
+    if (!pm.m_bReady || !pm.readCarmon(log, tag)) return 2;
+    CCanonicalMatcher csm(pm.m_pParam);
+    // 1. LDP overload == PMScan overload (the PMScan one is median filter + conversion + the LDP one)
+    PMScan a(*pm.m_SickScans[0]), b(*pm.m_SickScans[1]);
+    float r_pm = csm.FMatch(&a, &b, true);
+    printf("pm %g %a %a %a\n", r_pm, b.rx, b.ry, b.th);
+    LDP la = 0, lb = 0;
+    csm.fromPMScan2LDP(&a, &la, csm.m_pParam);        // a, b are median filtered by now
+    csm.fromPMScan2LDP(&b, &lb, csm.m_pParam);
+    float r_ld = csm.FMatch(la, lb);
+    printf("ld %g %a %a %a %d %d\n", r_ld, lb->true_pose[0], lb->true_pose[1], lb->true_pose[2], la->nrays, csm.output->valid);
+    ld_free(la); ld_free(lb);
+    // 2. key frames with the covariance
+    csm.setCov(true);
+    struct Mat { double m[3][3]; double& operator()(int i, int j) { return m[i][j]; } } cov;
+    for (int k = 0; k < 4; ++k) {
+        PMScan s(*pm.m_SickScans[k]);
+        memset(&cov, 0, sizeof cov);
+        float r = csm.FMatchKeyFrame2(&s, cov);
+        printf("kf %d %g %a %a %a", k, r, s.rx, s.ry, s.th);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) printf(" %a", cov(i, j));
+        printf("\n");
+    }
+    csm.resetKeyFrame(pm.m_SickScans[0]);
+    csm.setThreshold(0.5f, 0.2f);
+    double p1[3] = {0.1, 0.1, 0.1}, p2[3] = {0.6, 0.0, 0.0}, p3[3] = {0.0, 0.0, 0.3};
+    printf("thr %d %d %d %g %g\n", (int)csm.newKeyframeNeeded(p1), (int)csm.newKeyframeNeeded(p2), (int)csm.newKeyframeNeeded(p3),
+           csm.threshold_dist_sq_, csm.threshold_angular_);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc >= 5 && !strcmp(argv[1], "csmx")) return run_csmx(argv[2], argv[3], argv[4]);
+    if (argc >= 6 && !strcmp(argv[1], "accuracy")) {     // accuracy <laser> <log> <psm_out> <icp_out>
+        CPolarMatch m(argv[2]);
+        m.m_accuracy_psm_path = argv[4]; m.m_accuracy_icp_path = argv[5];
+        m.testAccuracy(argv[3]);
+        printf("failed %d %d\n", m.m_failed_psm, m.m_failed_icp);
+        return 0;
+    }
+    if (argc >= 6 && !strcmp(argv[1], "run511")) {       // run511 <laser> <file> <traj_out> <n>
+        CPolarMatch m(argv[2]);
+        m.m_trajectory_path = argv[4];
+        m.run511Data(argv[3], atoi(argv[5]));
+        return 0;
+    }
     if (argc >= 7 && !strcmp(argv[1], "corridor")) return run_corridor(argv[2], argv[3], argv[4], argv[5], argv[6]);
     if (argc >= 6 && !strcmp(argv[1], "readers")) return run_readers(argv[2], argv[3], argv[4], argv[5]);
     if (argc >= 6 && !strcmp(argv[1], "match")) return run_match(argv[2], argv[3], argv[4], atoi(argv[5]));

@@ -568,3 +568,14 @@ def plicp(ref_r_cm, cur_r_cm, fi_min, dfi, min_range_cm, max_range_cm):
     _orc().orc_plicp(_p(a), _p(b), len(a), C.c_float(fi_min), C.c_float(dfi), int(min_range_cm), int(max_range_cm),
                      C.byref(P), _p(out))
     return out
+
+
+def plicp_cov(ref_r_cm, cur_r_cm, fi_min, dfi, min_range_cm, max_range_cm, sigma=0.04):
+    """orc_plicp_cov: result record, sm_icp-style covariance (3x3) and the correspondences it was formed over."""
+    P = _PlicpParams()
+    _orc().orc_plicp_params_default(C.byref(P))
+    a = np.ascontiguousarray(ref_r_cm, f32); b = np.ascontiguousarray(cur_r_cm, f32)
+    out = np.zeros(8, np.float64); cov = np.zeros(9, np.float64); corr = np.zeros(2 * len(a), np.int32)
+    _orc().orc_plicp_cov(_p(a), _p(b), len(a), C.c_float(fi_min), C.c_float(dfi), int(min_range_cm), int(max_range_cm),
+                         C.byref(P), C.c_double(sigma), _p(out), _p(cov), _p(corr))
+    return out, cov.reshape(3, 3), corr.reshape(-1, 2)

@@ -272,3 +272,109 @@ def test_offline_driver_runlog_flirt(exe, tmp_path):
     assert got.shape == want.shape == (min(n, len(r_all)), 3)
     assert np.allclose(got, want, rtol=2e-5, atol=2e-5)          # the file holds 6 significant digits
     assert bridged < len(want) // 2                                # most frames are matched, not bridged
+
+
+def test_accuracy_harness(exe, tmp_path):
+    """CPolarMatch::testAccuracy (ZHPolar_Match.cpp:364-447) on the head of mit-cscail.log: the two error logs against
+    the harness's bookkeeping replayed with the golden poses of pm_psm / pm_icp (reference-made, zero prior)."""
+    from oracle_lib import Oracle
+    name = "mit"
+    g = load(name)
+    laser, fn, tag = SETS[name]
+    fp, fi = str(tmp_path / "err_psm.log"), str(tmp_path / "err_icp.log")
+    res = subprocess.run([exe, "accuracy", laser, os.path.join(GOLDEN, fn), fp, fi], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    failed = [l.split() for l in res.stdout.splitlines() if l.startswith("failed")][0]
+    o = Oracle(laser)
+    _, _, _, _, pose_all = o.read_carmen(os.path.join(GOLDEN, fn), tag)
+    S = len(pose_all)
+    assert int(failed[1]) == int((g["psm_status"][:S - 1] != 0).sum()) and int(failed[2]) == int((g["icp_status"][:S - 1] != 0).sum())
+    for which, path in (("psm", fp), ("icp", fi)):
+        want = []
+        for b in range(S - 1):
+            a, c = pose_all[b].astype(np.float64), pose_all[b + 1].astype(np.float64)
+            cs, sn = np.cos(a[2]), np.sin(a[2])
+            gt = np.array([(c[0] - a[0]) * cs + (c[1] - a[1]) * sn, -(c[0] - a[0]) * sn + (c[1] - a[1]) * cs, c[2] - a[2]])
+            p = g[which + "_pose"][b].astype(np.float64) if g[which + "_status"][b] == 0 else np.zeros(3)
+            dis = np.hypot(p[0] / 100.0 - gt[0], p[1] / 100.0 - gt[1]); ang = abs(p[2] - gt[2])
+            if dis < 1 and ang < 0.6982:
+                want.append((dis, ang))
+        got = np.loadtxt(path).reshape(-1, 2)
+        want = np.array(want)
+        assert got.shape == want.shape and len(want) > (S - 1) // 2
+        assert np.allclose(got, want, rtol=2e-5, atol=1e-9)          # the file holds 6 significant digits
+
+
+def test_run511_driver(exe, tmp_path):
+    """CPolarMatch::run511Data (ZHPolar_Match.cpp:678-734, what the reference's own src/zhpsm/test.cpp runs): a file of
+    "timestamp n r_1 .. r_n" lines made from the head of fr079.log, chained pm_psm against the oracle's replay."""
+    from oracle_lib import Oracle
+    laser, fn, tag = SETS["fr079"]
+    o = Oracle(laser)
+    r_all, _, _, _, _ = o.read_carmen(os.path.join(GOLDEN, fn), tag)
+    n = 25
+    src = tmp_path / "lms511.txt"
+    with open(src, "w") as f:
+        for k in range(n):
+            f.write("%d.5 %d %s\n" % (1000 + k, r_all.shape[1], " ".join(repr(float(np.float32(v)) / 100.0) for v in r_all[k])))
+        f.write("7 12 1.0 2.0\n")                                    # a record of the wrong size is skipped
+    out = str(tmp_path / "traj511.log")
+    res = subprocess.run([exe, "run511", laser, str(src), out, "-1"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    got = np.loadtxt(out).reshape(-1, 3)
+    o = Oracle(laser)                 # run511Data reads no CARMEN header: the preset's bearings (0 .. 180 deg) stay
+    P = o.param_dict()
+    rx = ry = th = 0.0
+    want = [(0.0, 0.0, 0.0)]
+    last = None
+    for k in range(n):
+        r = (np.array([float(np.float32(v)) / 100.0 for v in r_all[k]]) * 100.).astype(np.float32)
+        r = np.where(r < P["min_range"], np.float32(P["max_range"] + 1), r).astype(np.float32)
+        ls = o.preprocess(r)
+        if last is None:
+            last = ls
+            continue
+        st, pose, _, _ = o.match(0, last, ls)
+        if st != 0:
+            continue
+        xx = float(pose[0]) * np.cos(th) - float(pose[1]) * np.sin(th) + rx
+        yy = float(pose[0]) * np.sin(th) + float(pose[1]) * np.cos(th) + ry
+        rx, ry, th = xx, yy, th + float(pose[2])
+        last = ls
+        want.append((rx, ry, th))
+    want = np.array(want)
+    assert got.shape == want.shape and len(want) >= n - 3
+    assert np.allclose(got, want, rtol=2e-5, atol=2e-5)
+
+
+def test_ccanonicalmatcher_ldp_and_covariance(exe):
+    """laser_data-typed FMatch == PMScan-typed FMatch; FMatchKeyFrame2's covariance == the oracle's closed form on the
+    median-filtered frames (parity unpinned: CSM absent); setThreshold(dist, angle) in the reference's argument order."""
+    from oracle_lib import Oracle, plicp_cov
+    from helpers import golden_param
+    laser, fn, tag = SETS["mit"]
+    res = subprocess.run([exe, "csmx", laser, os.path.join(GOLDEN, fn), tag], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    rows = {r.split()[0] + (r.split()[1] if r.startswith("kf") else ""): r.split() for r in res.stdout.splitlines() if r.strip()}
+    pm, ld = rows["pm"], rows["ld"]
+    assert float(pm[1]) == 0.0 and float(ld[1]) == 0.0 and int(ld[6]) == 1
+    assert np.array_equal([hexf(pm[2]), hexf(pm[3]), hexf(pm[4])],
+                          [np.float32(float.fromhex(ld[2]) * 100.), np.float32(float.fromhex(ld[3]) * 100.), np.float32(float.fromhex(ld[4]))])
+    g = load("mit")
+    o = Oracle(laser)
+    gp = golden_param(g)
+    r_all, _, _, _, _ = o.read_carmen(os.path.join(GOLDEN, fn), tag)
+    o.set_fimin_maxrange(np.float32(gp["fi_min"]), int(gp["max_range"]))
+    P = o.param_dict()
+    med = [o.median(r_all[k]) for k in range(4)]
+    assert float(rows["kf0"][2]) == 2.0                              # first frame stored
+    for k in range(1, 4):
+        row = rows["kf%d" % k]
+        want, wcov, _ = plicp_cov(med[k - 1], med[k], P["fi_min"], P["dfi"], P["min_range"], P["max_range"], 0.04)
+        assert float(row[2]) == 0.0 and want[3] == 1.0
+        got = np.array([float.fromhex(t) for t in row[3:6]])
+        assert np.allclose(got, [want[0] * 100, want[1] * 100, want[2]], rtol=0, atol=2e-4)
+        cov = np.array([float.fromhex(t) for t in row[6:15]]).reshape(3, 3)
+        assert np.allclose(cov, wcov, rtol=1e-5, atol=1e-9 * np.abs(wcov).max()), (cov, wcov)
+    thr = rows["thr"]
+    assert [int(t) for t in thr[1:4]] == [0, 1, 1] and abs(float(thr[4]) - 0.25) < 1e-6 and abs(float(thr[5]) - 0.2) < 1e-6

@@ -139,3 +139,43 @@ def test_plicp_follows_parameter_changes():
     assert b[3] == wb[3] == 1.0 and np.allclose(b[:3], wb[:3], atol=5e-6)
     assert np.abs(wb[:2] - wa[:2]).max() > 1e-3                                # the rotation of the frame is visible in the translation
     ctx.close()
+
+
+@pytest.mark.parametrize("n_beams", [361, 1081])
+def test_plicp_covariance_matches_oracle(n_beams):
+    """sm_icp's covariance (Censi's closed form) of the device against oracle/plicp_oracle.c's - which
+    tests/test_oracle_plicp.py holds to a finite-difference Hessian - incl. pairs that go through the restart path
+    (correspondences recomputed at the result) and a failing pair (zeros)."""
+    import torch
+    from laser_slam_amd import capi, synth
+    from oracle_lib import plicp_cov
+    kw = dict(points=n_beams, fov_deg=270, max_range=3000, min_valid=n_beams // 4, window=n_beams // 6,
+              fi_min_deg=-135, fi_max_deg=135)
+    p = capi.param_make(**kw)
+    ctx = capi.Context(p)
+    raw, _ = synth.make_scans(12, n_beams=n_beams)
+    raw = np.concatenate([raw, np.full((1, n_beams), 3001.0, np.float32)], 0)          # a blind scan: the match fails
+    ri = np.array([0, 1, 2, 0, 3, 5, 0], np.int32); ai = np.array([1, 2, 3, 4, 9, 11, 12], np.int32)
+    B = len(ri)
+    d_r = torch.from_numpy(raw).cuda()
+    d_out = torch.zeros(B, 8, dtype=torch.float64, device="cuda"); d_cov = torch.full((B, 9), 7.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    capi.plicp_batch_cov(ctx, B, d_r, torch.from_numpy(ri).cuda(), torch.from_numpy(ai).cuda(), 0.04, d_out, d_cov)
+    ctx.sync()
+    got, cov = d_out.cpu().numpy(), d_cov.cpu().numpy().reshape(B, 3, 3)
+    restarted = 0
+    for b in range(B):
+        want, wcov, _ = plicp_cov(raw[ri[b]], raw[ai[b]], p.fi_min, p.dfi, p.min_range, p.max_range, 0.04)
+        assert got[b, 3] == want[3]
+        if want[3] == 0:
+            assert np.all(cov[b] == 0)
+            continue
+        assert np.allclose(got[b, :3], want[:3], atol=2e-6)
+        restarted += want[5] > 10
+        # same correspondences, same formulas; sums in another order and ocml against libm in the trigonometry
+        assert np.allclose(cov[b], wcov, rtol=1e-6, atol=1e-9 * np.abs(wcov).max()), (b, cov[b], wcov)
+        assert np.all(np.linalg.eigvalsh(0.5 * (cov[b] + cov[b].T)) > 0)
+    assert got[B - 1, 3] == 0
+    one, c1 = capi.plicp_host_cov(ctx, raw[0], raw[1], 0.04)
+    assert np.array_equal(one, got[0]) and np.allclose(c1, cov[0], rtol=1e-9, atol=0)
+    ctx.close()
