@@ -1,20 +1,20 @@
 // pm_icp (src/zhpsm/ZHPolar_Match.cpp:1653-2021) on gfx950, included from
 // match_kernels.hip inside namespace lsa.
 //
-// One 256-thread workgroup (4 waves) per scan pair, 4 workgroups per CU:
+// One 256-thread workgroup (4 waves) per scan pair, 6 workgroups per CU at 1081 beams:
 //  - order-free phases (projection, scatter-min, nearest neighbour, interpolation,
 //    products) use all 256 lanes;
-//  - order-bound phases (list compaction, the partial bubble sort, the ordered FP32
-//    sums of the rigid fit) run in wave 0 while the other waves of the pair wait at
-//    a barrier and the CU's other pairs fill the SIMDs.
+//  - order-bound phases (list compaction, the ordered FP32 sums of the rigid fit) run in wave 0 while
+//    the other waves of the pair wait at a barrier and the CU's other pairs fill the SIMDs.
 //
-// LDS (bytes, Np = N rounded up to 64; 31.1 KiB at N = 1081 -> 5 pairs per CU):
+// LDS (bytes, Np = N rounded up to 64; 26 656 B at N = 1081 -> 6 pairs per CU):
 //   [ 0   , 8Np)  ref_xy   float2 (reference scan, Cartesian; ranges for the error index)
 //   [ 8Np ,16Np)  K        u64 scatter-min keys -> per-beam NN record -> match list (in place)
-//   [16Np ,16Np+VB) D      pr,pf of the projection (NN reads them as search centre)
-//                          -> V: ordered (nx,ny,ix,iy) float4 list -> W: the four products
-//                          (the trim pools and scratch also live here, between NN and V)
-//                          -> owner (u32 per reference beam) between the trim and the value lists
+//                          -> the ordered lists nx | ny of the rigid fit (Np floats each), later two product lists
+//   [16Np ,16Np+DB) D      pr,pf of the projection (NN reads them as search centre)
+//                          -> trim pools and scratch -> owner (u32 per reference beam)
+//                          -> the ordered lists ix | iy, later two product lists, + the first `drop` pairs' beams
+//                             (what :2015-2020 needs after the lists have replaced the match list)
 //   [.. , +256)   broadcast slots
 //   [.. , +Np/8)  good: one bit per reference ray (ref_bad == 0)
 //   [.. , +Np/8)  pair_mask: one bit per beam (beams i-1,i form a valid pair)
@@ -44,22 +44,23 @@ constexpr float NN_CAP = 10001.0f;     // matches with d^2 >= 100^2 are rejected
 
 constexpr int TRIM_CHUNK = 256;        // records consumed per step of the partial bubble sort
 
-// D region: max of { pr,pf of the projection | the ordered value lists | trim pools + scratch }
-__host__ __device__ inline int icp_v_bytes(int n)
+// floats per ordered list in the D region (ix | iy): the kept pairs, a multiple of 4 (ordered_sum reads 128 bits at a
+// time and runs a few quads ahead: whatever lies behind a list inside the workgroup's LDS may be read, never used)
+__host__ __device__ inline int icp_list_floats(int n) { return (n - (int)((double)n * 0.2) + 2 + 3) & ~3; }
+// A thread takes the match records and owners of its (at most 4) pairs to registers before the lists replace the
+// match list and the owner array.  Longer lists (more than 1278 beams) get arrays of their own instead.
+__host__ __device__ inline bool icp_lists_separate(int n) { return n - (int)((double)n * 0.2) + 2 > 4 * ICP_THREADS; }
+// D region: max of { pr,pf of the projection | ix,iy lists + the first `drop` pairs' beams | trim pools + scratch }
+__host__ __device__ inline int icp_d_bytes(int n)
 {
     int Np = (n + 63) & ~63;
-    int keep_max = n - (int)((double)n * 0.2) + 2;
-    int vb = 16 * ((keep_max + 3) & ~3);
-    if (vb < 8 * Np) vb = 8 * Np;
     int kmax = (int)((double)n * 0.2) + 1;
+    int vb = 8 * icp_list_floats(n) + 4 * kmax;
+    if (vb < 8 * Np) vb = 8 * Np;
     int tb = 2 * kmax * 8 + TRIM_CHUNK * (8 + 3 * 4);   // two pools, eviction slots, three float rows
     if (vb < tb) vb = tb;
     return (vb + 63) & ~63;
 }
-// The owner array (u32 per reference beam) is needed only between the trim and the value lists,
-// so it aliases the D region; each thread then holds the owners of its (at most 4) pairs in
-// registers while the lists overwrite it.  Longer lists get an array of their own.
-__host__ __device__ inline bool icp_owner_separate(int n) { return n - (int)((double)n * 0.2) + 2 > 4 * ICP_THREADS; }
 __host__ __device__ inline int icp_mask_bytes(int n)
 {
     int Np = (n + 63) & ~63;
@@ -68,7 +69,7 @@ __host__ __device__ inline int icp_mask_bytes(int n)
 __host__ __device__ inline int icp_lds_bytes(int n)
 {
     int Np = (n + 63) & ~63;
-    return 16 * Np + icp_v_bytes(n) + (icp_owner_separate(n) ? 4 * Np : 0) + 256 + 2 * icp_mask_bytes(n);
+    return 16 * Np + icp_d_bytes(n) + (icp_lists_separate(n) ? 12 * Np : 0) + 256 + 2 * icp_mask_bytes(n);
 }
 
 __device__ __forceinline__ Lds carve_icp(char* base, int n)
@@ -81,15 +82,17 @@ __device__ __forceinline__ Lds carve_icp(char* base, int n)
     char* d = base + 16 * Np;
     L.pr = (float*)d;
     L.pf = (float*)(d + 4 * Np);
-    L.V = (float4*)d;
     const int kmax = (int)((double)n * 0.2) + 1;
     L.poolA = (unsigned long long*)d;               // trim pools + scratch alias the D region
     L.poolB = L.poolA + kmax;
     L.evict = L.poolB + kmax;                       // TRIM_CHUNK records, then 3 x TRIM_CHUNK floats
     L.pool_d = (float*)(L.evict + TRIM_CHUNK);
-    char* f = d + icp_v_bytes(n);
+    L.vd = (float*)d;                               // ix | iy
+    L.first_ij = (uint32_t*)(d + 8 * icp_list_floats(n));
+    char* f = d + icp_d_bytes(n);
     L.owner = (uint32_t*)d;
-    if (icp_owner_separate(n)) { L.owner = (uint32_t*)f; f += 4 * Np; }
+    L.vk = (float*)L.key;                           // nx | ny (Np floats each)
+    if (icp_lists_separate(n)) { L.owner = (uint32_t*)f; L.vk = (float*)(f + 4 * Np); f += 12 * Np; }
     L.misc = (float*)f;
     L.good = (uint32_t*)(f + 256);
     L.pair_mask = (uint32_t*)(f + 256 + icp_mask_bytes(n));
@@ -570,7 +573,7 @@ __device__ __forceinline__ float ordered_sum(const float* arr, int cnt)
 
 // ---------------------------------------------------------------------------
 #ifndef LSA_ICP_WG_PER_CU
-#define LSA_ICP_WG_PER_CU 5
+#define LSA_ICP_WG_PER_CU 6
 #endif
 // NC > 0: the beam count as a compile-time constant (the sensors' usual sizes), so that the LDS
 // layout and the trip counts are immediates instead of scalar registers; NC = 0: any size.
@@ -593,9 +596,10 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
     Lds L = carve_icp(smem, N);
     int* imisc = (int*)L.misc;              // [0] n
     float* fmisc = L.misc + 8;      // [0..3] means  [4..7] covariances
-    // ordered value lists (SoA, padded): nx | ny | ix | iy, later the four product lists
-    const int VS = icp_v_bytes(N) / 16;                       // floats per list (multiple of 4, + slack)
-    float* const V0 = (float*)L.V;
+    // ordered value lists (SoA): nx | ny in the K region, ix | iy in the D region, later the four product lists
+    const int Np = (N + 63) & ~63, VD = icp_list_floats(N);
+    float* const Lnx = L.vk; float* const Lny = L.vk + Np; float* const Lix = L.vd; float* const Liy = L.vd + VD;
+    const float* const my_list = lane == 0 ? Lnx : lane == 1 ? Lny : lane == 2 ? Lix : Liy;    // the list lane 0..3 of the serial wave sums
 
     const int sw = 0;                       // the wave that runs the order-bound single-wave phases
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
@@ -708,25 +712,31 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
                 atomicMax(&L.owner[(uint32_t)(L.key[k] >> 32) >> 16], (uint32_t)(k + 1));
             __syncthreads();
             for (int k0 = 0; k0 < keep; k0 += 4 * ICP_THREADS) {
-                // the owners of this thread's pairs go to registers before the value lists overwrite the array
-                int ko[4];
+                // this thread's pairs (beams i -> j) and the beams of the pairs that own their reference beams go to
+                // registers before the value lists replace the match list and the owner array
+                uint32_t ijs[4];
+                int ios[4];
                 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int k = k0 + u * ICP_THREADS + tid;
-                    ko[u] = k < keep ? (int)L.owner[(uint32_t)(L.key[k] >> 32) >> 16] - 1 : -1;
+                    ijs[u] = 0; ios[u] = 0;
+                    if (k < keep) {
+                        ijs[u] = (uint32_t)(L.key[k] >> 32);
+                        const int ko = (int)L.owner[ijs[u] >> 16] - 1;
+                        ios[u] = ko == k ? (int)(ijs[u] & 0xffff) : (int)((uint32_t)(L.key[ko] >> 32) & 0xffff);
+                    }
                 }
                 __syncthreads();
                 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int k = k0 + u * ICP_THREADS + tid;
                     if (k < keep) {
-                        const uint32_t ij = (uint32_t)(L.key[k] >> 32);
-                        const int i = ij & 0xffff, j = ij >> 16;
-                        const int io = ko[u] == k ? i : (int)((uint32_t)(L.key[ko[u]] >> 32) & 0xffff);
+                        const int i = ijs[u] & 0xffff, j = ijs[u] >> 16, io = ios[u];
                         const float2 p = cur_point(P, L.g_act_r, i, co, si, ax, ay);
                         const float2 po = io == i ? p : cur_point(P, L.g_act_r, io, co, si, ax, ay);
                         const float2 q = interp_candidate(P, L, N, po, j);
-                        V0[k] = p.x; V0[VS + k] = p.y; V0[2 * VS + k] = q.x; V0[3 * VS + k] = q.y;
+                        Lnx[k] = p.x; Lny[k] = p.y; Lix[k] = q.x; Liy[k] = q.y;
+                        if (k < drop) L.first_ij[k] = ijs[u];
                     }
                 }
             }
@@ -734,19 +744,19 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
             STAMP(4);
 
             // ---- closed-form rigid fit, :1936-1986: ordered sums, one lane per sum -------
-            if (wave == sw && lane < 4) fmisc[lane] = ordered_sum(V0 + lane * VS, keep) / (float)keep;
+            if (wave == sw && lane < 4) fmisc[lane] = ordered_sum(my_list, keep) / (float)keep;
             __syncthreads();
             STAMP(5);
             const float mpx = fmisc[0], mpy = fmisc[1], mqx = fmisc[2], mqy = fmisc[3];
             for (int k = tid; k < keep; k += ICP_THREADS) {
-                const float a = V0[k] - mpx, c = V0[VS + k] - mpy, e = V0[2 * VS + k] - mqx, f = V0[3 * VS + k] - mqy;
-                V0[k] = a * e; V0[VS + k] = a * f; V0[2 * VS + k] = c * e; V0[3 * VS + k] = c * f;   // sxx sxy syx syy
+                const float a = Lnx[k] - mpx, c = Lny[k] - mpy, e = Lix[k] - mqx, f = Liy[k] - mqy;
+                Lnx[k] = a * e; Lny[k] = a * f; Lix[k] = c * e; Liy[k] = c * f;   // sxx sxy syx syy
             }
             __syncthreads();
             // the covariance sums, then the pose update (:1984-1999) and next iteration's cos/sin
             // (:1753-1754), by the one wave that holds the sums: the other waves only read the result
             if (wave == sw) {
-                const float sum = lane < 4 ? ordered_sum(V0 + lane * VS, keep) : 0.0f;
+                const float sum = lane < 4 ? ordered_sum(my_list, keep) : 0.0f;
                 const float sxx = bcast_f(sum, 0), sxy = bcast_f(sum, 1), syx = bcast_f(sum, 2), syy = bcast_f(sum, 3);
                 const float ndth = atan2f_(sxy - syx, sxx + syy);                // :1984
                 const float cd = cosf_(ndth), sd = sinf_(ndth);
@@ -775,9 +785,9 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
         // :2012-2020.  The returned value averages the residuals of the first `drop`
         // kept pairs of the last iteration, each against its own candidate point.
         if (status == LSA_ST_OK) {
-            float* resid = V0;
+            float* resid = Lnx;                 // (the lists are dead by now)
             for (int k = tid; k < drop; k += ICP_THREADS) {
-                const uint32_t ij = (uint32_t)(L.key[k] >> 32);
+                const uint32_t ij = L.first_ij[k];
                 const float2 p = cur_point(P, L.g_act_r, ij & 0xffff, co, si, pax, pay);
                 const float2 c = interp_candidate(P, L, N, p, ij >> 16);
                 resid[k] = sqrtf((p.x - c.x) * (p.x - c.x) + (p.y - c.y) * (p.y - c.y));

@@ -55,7 +55,9 @@ struct Lds {
     uint32_t* pool_ij;
     const float* g_act_r;      // ICP reads the current scan's ranges from HBM/L2 (act_r == nullptr)
     const float* g_ref_r;      // ICP: the reference scan's ranges (unusable rays carry a far sentinel in ref_xy)
-    float4* V;                 // ICP v2: ordered value list (nx, ny, ix, iy) -> products
+    float* vk;                 // ICP: ordered value lists nx | ny (in place of the match list), later products
+    float* vd;                 // ICP: ordered value lists ix | iy (D region), later products
+    uint32_t* first_ij;        // ICP: beams (i | j << 16) of the first `drop` kept pairs
     unsigned long long* poolA; // ICP v2 trim pool (double buffered) + eviction scratch
     unsigned long long* poolB;
     unsigned long long* evict;
