@@ -203,6 +203,7 @@ constexpr int NN_FLAT = 8;             // candidate counts up to this are evalua
 struct NnBeam {
     float2 p;
     int lo, hi;          // the reference's window [lo, hi)
+    int n_beams;
     float x, B;          // real-valued index of the bearing, half width in rays (B < 0: the whole window)
     int s0, e0;          // main range, clipped to the window
     bool live, flat;     // flat: the candidates are NN_FLAT consecutive rays of the window starting at s0
@@ -240,7 +241,7 @@ __device__ __forceinline__ void nn_plan(const DevParam& P, const Lds& L, int i, 
 {
     const int N = P.n, W = P.window;
     const int ic = i < N ? i : N - 1;
-    b.p = p; b.live = live;
+    b.p = p; b.live = live; b.n_beams = N;
     b.lo = ic - W < 0 ? 0 : ic - W;
     b.hi = ic + W > N ? N : ic + W;
     const float rho = L.pr[ic] * 0.999f - 0.01f;
@@ -281,10 +282,14 @@ __device__ __forceinline__ void nn_plan(const DevParam& P, const Lds& L, int i, 
     // (without any seed the radius is that of NN_CAP: a match farther than 100 cm is rejected anyway, :1811)
     const bool bounded = rho > NN_RHO_MIN && t < 1.0f;
     b.B = bounded ? (t + 0.5708f * t * t * t) * inv_dfi + NN_SLACK : -1.0f;
+    // The images one turn away can reach the scan only if the half width exceeds (T - N) / 2 rays (x lies within half a
+    // turn of the scan's centre): for the usual sensors that is a search radius of tens of degrees, so a wave almost
+    // never has such a lane and skips their ranges.
     int done = b.lo - 1, s, e, len = 0;
-    nn_range(b, T, -1, done, s, e); len += e >= s ? e - s + 1 : 0;
+    const bool images = __ballot(b.B > 0.5f * (T - (float)N) - 2.0f) != 0;
+    if (images) { nn_range(b, T, -1, done, s, e); len += e >= s ? e - s + 1 : 0; }
     nn_range(b, T, 0, done, b.s0, b.e0); const int l0 = b.e0 >= b.s0 ? b.e0 - b.s0 + 1 : 0; len += l0;
-    nn_range(b, T, 1, done, s, e); len += e >= s ? e - s + 1 : 0;
+    if (images) { nn_range(b, T, 1, done, s, e); len += e >= s ? e - s + 1 : 0; }
     // straight-line path: one range of at most NN_FLAT rays, and the NN_FLAT rays from its start lie inside the window
     // and the scan (any ray of the window may be evaluated on top of the candidates)
     b.flat = live && len == l0 && l0 <= NN_FLAT && b.s0 >= b.lo && b.s0 + NN_FLAT <= b.hi;
@@ -320,8 +325,10 @@ __device__ __forceinline__ void nn_general(const Lds& L, float T, NnBeam& b)
 {
     if (b.live && !b.flat) {
         int done = b.lo - 1, s, e;
+        const bool images = b.B > 0.5f * (T - (float)b.n_beams) - 2.0f;      // (as in nn_plan, per lane)
         #pragma unroll
         for (int im = -1; im <= 1; ++im) {
+            if (im != 0 && !images) continue;
             nn_range(b, T, im, done, s, e);
             int j = s;
             const int eq = e + 3 < b.hi - 1 ? e + 3 : b.hi - 1;         // quads may run past e inside the window

@@ -214,9 +214,12 @@ __device__ __forceinline__ float seg_foot(float x1, float y1, float x2, float y2
                                           float& fx, float& fy)
 {
     float ax = x2 - x1, ay = y2 - y1;
-    float len = sqrtf(ax * ax + ay * ay);
-    if ((double)len < 0.0001) return -1.0f;
-    float t = -(-ax * x3 + ay * y1 + ax * x1 - ay * y3) / (ax * ax + ay * ay);
+    // `(double)sqrtf(l2) < 0.0001` (:2043-2044) without the square root: sqrtf is correctly rounded and monotone, and
+    // 0x1.5798f0p-27 is the smallest float whose root reaches 0x1.a36e30p-14, the smallest float >= 0.0001
+    // (tests/native/math_bits_check.cpp walks the floats either side of it)
+    const float l2 = ax * ax + ay * ay;
+    if (l2 < 0x1.5798f0p-27f) return -1.0f;
+    float t = -(-ax * x3 + ay * y1 + ax * x1 - ay * y3) / l2;
     if (t < 0 || t > 1) return -1.0f;
     fx = x1 + t * ax;
     fy = y1 + t * ay;

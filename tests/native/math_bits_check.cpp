@@ -63,6 +63,16 @@ int main(int argc, char** argv)
         });
     }
     for (auto& t : th) t.join();
+    // seg_foot's degenerate-segment test (match_kernels.hip): (double)sqrtf(s) < 0.0001  <=>  s < 0x1.5798f0p-27f.
+    // A million floats either side of the threshold, then every float strided: the two predicates must agree.
+    unsigned long long bad_seg = 0;
+    {
+        const float thr = 0x1.5798f0p-27f;
+        const uint32_t ut = lsa::f2u(thr);
+        for (uint32_t u = ut - 1000000u; u <= ut + 1000000u; ++u) { const float v = lsa::u2f(u); bad_seg += ((double)sqrtf(v) < 0.0001) != (v < thr); }
+        for (uint64_t u = 0; u < 0x7f800000ull; u += 997) { const float v = lsa::u2f((uint32_t)u); bad_seg += ((double)sqrtf(v) < 0.0001) != (v < thr); }
+    }
+    if (bad_seg) { fprintf(stderr, "segment-length threshold: %llu mismatches\n", bad_seg); bad_sin += bad_seg; }
     printf("{\"stride\": %u, \"sin\": %llu, \"cos\": %llu, \"atan\": %llu, \"atan2\": %llu}\n", stride,
            (unsigned long long)bad_sin, (unsigned long long)bad_cos, (unsigned long long)bad_atan,
            (unsigned long long)bad_atan2);
