@@ -347,6 +347,53 @@ int lsa_icp_goodness_scores(lsa_field* f, const float* d_prob, const float* d_po
                             float max_range, const lsa_p2p_options* opt, float* d_weight, float* d_rel_pose);
 
 
+/* ---- multi-GPU: one process per GPU, an RCCL communicator per context ------------------------
+ * The scan-pair batches need no exchange (ranks take disjoint pair lists).  The path has two exchange steps:
+ * the count grids of ranks that inserted different scans are summed (config 5), and the particle filter's step
+ * runs over particles sharded across the ranks (config 4).  RCCL is bound at run time (librccl.so.1); a communicator
+ * of one rank never loads it.  All ranks of a communicator must make the same calls in the same order. */
+typedef struct lsa_comm lsa_comm;
+#define LSA_COMM_ID_BYTES 128
+/* rank 0 makes the id (ncclGetUniqueId) and hands it to the other ranks by whatever channel the host has (file, socket,
+ * MPI, environment); every rank then creates its end.  world = 1: id may be NULL. */
+int lsa_comm_unique_id(uint8_t id[LSA_COMM_ID_BYTES]);
+int lsa_comm_create(lsa_comm** out, lsa_ctx* c, int rank, int world, const uint8_t id[LSA_COMM_ID_BYTES]);
+void lsa_comm_destroy(lsa_comm* m);
+int lsa_comm_rank(const lsa_comm* m);
+int lsa_comm_world(const lsa_comm* m);
+uint64_t lsa_comm_bytes_sent(const lsa_comm* m);       /* payload handed to other ranks so far */
+/* block [first, first + count) of rank among n_total items (blocks differ by at most one) */
+int lsa_shard_bounds(int64_t n_total, int rank, int world, int64_t* first, int64_t* count);
+/* CPMap layers of all ranks summed in place (hit and visit counts are additive integers: the result is the map one
+ * process would have built from all scans, PMap.cpp:74-87).  Call before lsa_grid_compute_prob. */
+int lsa_grid_allreduce(lsa_grid* g, lsa_comm* m);
+/* best particle over all shards: the larger score, equal scores to the smaller global index (particles.cpp:339-343);
+ * first_index = global index of the shard's first particle; h_pose (may be NULL) = that particle's pose */
+int lsa_pf_global_best(lsa_comm* m, const float* d_score, const float* d_poses, int n_local, int64_t first_index,
+                       float* h_score, int64_t* h_index, float h_pose[3]);
+/* lsa_pf_weights on the shard with the global maximum; the two sums are those of all shards (CParticles::neff) */
+int lsa_pf_global_weights(lsa_comm* m, const float* d_score, int n_local, float max_score, float* d_w, double* h_sum, double* h_sumsq);
+/* Systematic_resampler (src/sensorFusion/SIRFlt.cpp:118-191) over sharded particles, in fixed point so that the result
+ * does not depend on how the particles are split (csrc/shard_kernels.hip): an all-gather of one 8-byte weight sum per
+ * rank, local resolution of the rank's own strata, and an exchange of the offspring that belong to another rank's
+ * block (12 B each).  d_poses_out = this rank's block of the new particle array (n_local poses, no aliasing). */
+int lsa_pf_resample_sharded(lsa_comm* m, const float* d_w, const float* d_poses, int n_local, int64_t n_total, double u0,
+                            float* d_poses_out);
+/* roughen_minmax (SIRFlt.cpp:359-413) with the extremes and the size of the whole particle set */
+int lsa_pf_roughen_sharded(lsa_comm* m, int n_local, int64_t n_total, double K, const float* d_normals, float* d_poses);
+/* the pieces of lsa_pf_resample_sharded, for hosts that bring their own transport (MPI, torch.distributed):
+ *   lsa_pf_fixed_sum        sum of floor(w * 2^32) over the shard (exact)
+ *   lsa_pf_plan             host only: from all shards' sums -> total, U0 = floor(u0 * total) and bounds[world + 1]:
+ *                           shard r's particles are the parents of offspring [bounds[r], bounds[r + 1])
+ *   lsa_pf_offspring_bounds d_e[i] = offspring of the global particles 0 .. (this shard's i); offset = sum of the
+ *                           earlier shards' sums
+ *   lsa_pf_parents          local parent index of offspring m_first .. m_first + m_count - 1 (inside this shard's range) */
+int lsa_pf_fixed_sum(lsa_ctx* c, const float* d_w, int n, uint64_t* h_sum);
+int lsa_pf_plan(int world, int64_t n_total, const uint64_t* shard_sum, double u0, uint64_t* total, uint64_t* u0_fixed, int64_t* bounds);
+int lsa_pf_offspring_bounds(lsa_ctx* c, const float* d_w, int n, uint64_t offset, int64_t n_total, uint64_t u0_fixed, uint64_t total,
+                            int32_t* d_e);
+int lsa_pf_parents(lsa_ctx* c, const int32_t* d_e, int n, int64_t m_first, int m_count, int32_t* d_parent);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,24 @@ def lib():
     L.lsa_plicp_batch_cov.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_double, vp, vp]
     L.lsa_plicp_host_cov.argtypes = [vp, vp, vp, vp, C.c_double, vp, vp]
     L.lsa_ctx_arena.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.lsa_comm_unique_id.argtypes = [vp]
+    L.lsa_comm_create.argtypes = [C.POINTER(vp), vp, C.c_int, C.c_int, vp]
+    L.lsa_comm_destroy.argtypes = [vp]
+    L.lsa_comm_destroy.restype = None
+    L.lsa_comm_rank.argtypes = [vp]
+    L.lsa_comm_world.argtypes = [vp]
+    L.lsa_comm_bytes_sent.argtypes = [vp]
+    L.lsa_comm_bytes_sent.restype = C.c_uint64
+    L.lsa_shard_bounds.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.lsa_grid_allreduce.argtypes = [vp, vp]
+    L.lsa_pf_global_best.argtypes = [vp, vp, vp, C.c_int, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_int64), vp]
+    L.lsa_pf_global_weights.argtypes = [vp, vp, C.c_int, C.c_float, vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.lsa_pf_resample_sharded.argtypes = [vp, vp, vp, C.c_int, C.c_int64, C.c_double, vp]
+    L.lsa_pf_roughen_sharded.argtypes = [vp, C.c_int, C.c_int64, C.c_double, vp, vp]
+    L.lsa_pf_fixed_sum.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_uint64)]
+    L.lsa_pf_plan.argtypes = [C.c_int, C.c_int64, vp, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp]
+    L.lsa_pf_offspring_bounds.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_int64, C.c_uint64, C.c_uint64, vp]
+    L.lsa_pf_parents.argtypes = [vp, vp, C.c_int, C.c_int64, C.c_int, vp]
     L.lsa_icp_goodness_scores.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp, vp]
     L.lsa_gather_poses.argtypes = [vp, vp, vp, C.c_int, vp]
     L.lsa_p2p_icp_host.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp]
@@ -519,3 +537,82 @@ def p2p_icp_host(ctx, ref_x, ref_y, cur_x, cur_y, init_pose):
     check(lib().lsa_p2p_icp_host(ctx.h, _hp(rx), _hp(ry), len(rx), _hp(cx), _hp(cy), len(cx), _hp(init), None, _hp(out)),
           "lsa_p2p_icp_host")
     return out
+
+
+# ---- multi-GPU entry points (include/lsa_core.h, "multi-GPU") -------------------------------------------------
+def shard_bounds(n_total, rank, world):
+    f, c = C.c_int64(0), C.c_int64(0)
+    check(lib().lsa_shard_bounds(int(n_total), int(rank), int(world), C.byref(f), C.byref(c)), "lsa_shard_bounds")
+    return f.value, c.value
+
+
+def pf_plan(shard_sums, n_total, u0):
+    """lsa_pf_plan (host only, needs no GPU): total, U0 and bounds[world + 1] of the sharded systematic resampling."""
+    sums = np.ascontiguousarray(shard_sums, np.uint64)
+    world = len(sums)
+    W, U0 = C.c_uint64(0), C.c_uint64(0)
+    bounds = np.zeros(world + 1, np.int64)
+    check(lib().lsa_pf_plan(world, int(n_total), _hp(sums), float(u0), C.byref(W), C.byref(U0), _hp(bounds)), "lsa_pf_plan")
+    return W.value, U0.value, bounds
+
+
+def pf_fixed_sum(ctx, d_w, n):
+    s = C.c_uint64(0)
+    check(lib().lsa_pf_fixed_sum(ctx.h, _dp(d_w), n, C.byref(s)), "lsa_pf_fixed_sum")
+    return s.value
+
+
+def pf_offspring_bounds(ctx, d_w, n, offset, n_total, U0, W, d_e):
+    check(lib().lsa_pf_offspring_bounds(ctx.h, _dp(d_w), n, int(offset), int(n_total), int(U0), int(W), _dp(d_e)), "lsa_pf_offspring_bounds")
+
+
+def pf_parents(ctx, d_e, n, m_first, m_count, d_parent):
+    check(lib().lsa_pf_parents(ctx.h, _dp(d_e), n, int(m_first), int(m_count), _dp(d_parent)), "lsa_pf_parents")
+
+
+def comm_unique_id():
+    buf = np.zeros(128, np.uint8)
+    check(lib().lsa_comm_unique_id(_hp(buf)), "lsa_comm_unique_id")
+    return buf
+
+
+class Comm:
+    """lsa_comm: an RCCL communicator bound to a context (one rank per GPU); world 1 needs no id and no RCCL."""
+
+    def __init__(self, ctx, rank=0, world=1, unique_id=None):
+        self.h = vp()
+        self.ctx = ctx
+        idp = None if unique_id is None else _hp(np.ascontiguousarray(unique_id, np.uint8))
+        check(lib().lsa_comm_create(C.byref(self.h), ctx.h, rank, world, idp), "lsa_comm_create")
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if self.h:
+            lib().lsa_comm_destroy(self.h)
+            self.h = vp()
+
+    def bytes_sent(self):
+        return int(lib().lsa_comm_bytes_sent(self.h))
+
+    def grid_allreduce(self, grid):
+        check(lib().lsa_grid_allreduce(grid.h, self.h), "lsa_grid_allreduce")
+
+    def pf_global_best(self, d_score, d_poses, n_local, first_index):
+        sc, idx = C.c_float(0), C.c_int64(0)
+        pose = np.zeros(3, np.float32)
+        check(lib().lsa_pf_global_best(self.h, _dp(d_score), _dp(d_poses), n_local, int(first_index), C.byref(sc), C.byref(idx),
+                                       _hp(pose)), "lsa_pf_global_best")
+        return sc.value, idx.value, pose
+
+    def pf_global_weights(self, d_score, n_local, max_score, d_w):
+        s, s2 = C.c_double(0), C.c_double(0)
+        check(lib().lsa_pf_global_weights(self.h, _dp(d_score), n_local, max_score, _dp(d_w), C.byref(s), C.byref(s2)),
+              "lsa_pf_global_weights")
+        return s.value, s2.value
+
+    def pf_resample_sharded(self, d_w, d_poses, n_local, n_total, u0, d_poses_out):
+        check(lib().lsa_pf_resample_sharded(self.h, _dp(d_w), _dp(d_poses), n_local, int(n_total), float(u0), _dp(d_poses_out)),
+              "lsa_pf_resample_sharded")
+
+    def pf_roughen_sharded(self, n_local, n_total, K, d_normals, d_poses):
+        check(lib().lsa_pf_roughen_sharded(self.h, n_local, int(n_total), float(K), _dp(d_normals), _dp(d_poses)), "lsa_pf_roughen_sharded")

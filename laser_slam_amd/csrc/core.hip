@@ -19,6 +19,9 @@
 #include "sim_kernels.hip"
 #include "p2p_kernels.hip"
 #include "plicp_kernels.hip"
+namespace lsa {
+#include "shard_kernels.hip"
+}
 
 static thread_local std::string g_err;
 
@@ -1582,5 +1585,7 @@ int lsa_p2p_icp_host(lsa_ctx* c, const float* ref_x, const float* ref_y, int n_r
     hipFree(d);
     return rc;
 }
+
+#include "shard_host.inc"
 
 } // extern "C"

@@ -1,20 +1,23 @@
-"""Sharded pose scoring / particle-filter step: one process per GPU,
-particles split evenly over the ranks, map + scan replicated.
+"""Sharded particle-filter step: one process per GPU, the particles split into contiguous
+blocks over the ranks, map and scan replicated.  This module is the exchange logic over torch.distributed (RCCL over
+xGMI on GPUs, gloo in the CPU tests); the same steps are available to C++ hosts through the C ABI's `lsa_comm`
+entry points (include/lsa_core.h, csrc/shard_host.inc), which use RCCL directly.
 
-Exchange steps (torch.distributed; RCCL over xGMI on GPUs, gloo in the CPU tests):
-  * best pose: all-gather of one (score, global index) record per rank -> exact arg-max
-  * weights:   all-reduce(SUM) of {sum w, sum w^2} (w = exp(score - global max)) -> N_eff
-  * resample:  all-gather of the weights and poses; every rank draws its own contiguous
-    block of the systematic grid (src/sensorFusion/SIRFlt.cpp:118-191) from the same
-    cumulative weights, so the result equals single-process systematic resampling.  The reference's
-    default Standard_resampler (SIRFlt.cpp:39-115, one uniform per offspring) shards the same way:
-    pass the shared uniforms as `u0` and a `local_resample` built on lsa_pf_resample_standard, whose
-    (first, M) block of the parent-ascending list is this rank's share.
+Exchange steps of one step (messages are tiny except the last one):
+  * best pose   all-gather of one (score, global index) record per rank -> exact arg-max (ties: smaller index)
+  * weights     all-reduce(SUM) of {sum w, sum w^2}, w = exp(score - global max) -> N_eff
+  * resampling  (only when N_eff is low) systematic resampling (src/sensorFusion/SIRFlt.cpp:118-191) in fixed point:
+      - all-gather of ONE 8-byte weight sum per rank -> every rank knows the total, the stratum offset U0 and
+        which offspring [E_r, E_{r+1}) each shard's particles are the parents of (`capi.pf_plan`, host arithmetic);
+      - every rank resolves its own strata from its LOCAL cumulative sum (no weights, no cumulative sums and no
+        particle array cross ranks);
+      - one all-to-all moves the offspring that belong to another rank's block of the new particle array
+        (12 B each).  Smooth weights leave almost everything where it is; bytes sent per rank <= 12 x the number of
+        offspring the rank produced.
+    Fixed point (q = floor(w 2^32), exact 64-bit sums) makes every number of the scheme independent of how the
+    particles are split, so the sharded step reproduces the single-process step exactly (csrc/shard_kernels.hip).
 
-The collectives carry a few bytes (records) or 16 B per particle (resampling); the
-scoring itself never leaves the GPU.  Compute = HIP kernels behind the C ABI
-(`local_*` callables); this module is the host-side exchange logic only, so it can be
-exercised on CPU ranks with stand-in local results.
+Compute = HIP kernels behind the C ABI, handed in as `prims` (see `DevicePrims`); the CPU tests pass numpy stand-ins.
 """
 import numpy as np
 import torch
@@ -28,7 +31,7 @@ def _world():
 
 
 def shard_bounds(n_total, rank, world):
-    """Contiguous block [first, first+count) of rank; blocks differ by at most one."""
+    """Contiguous block [first, first+count) of rank; blocks differ by at most one (== lsa_shard_bounds)."""
     base, rem = divmod(n_total, world)
     first = rank * base + min(rank, rem)
     return first, base + (1 if rank < rem else 0)
@@ -44,8 +47,9 @@ def global_best(local_max, local_index, first, device="cpu"):
         return float(rec[0]), int(rec[1])
     out = [torch.zeros_like(rec) for _ in range(world)]
     dist.all_gather(out, rec)
-    best = max(out, key=lambda r: (float(r[0]), -float(r[1])))
-    return float(best[0]), int(best[1])
+    out = torch.stack(out).cpu()
+    best = max(range(world), key=lambda r: (float(out[r, 0]), -float(out[r, 1])))
+    return float(out[best, 0]), int(out[best, 1])
 
 
 def global_weight_sums(local_sum, local_sumsq, device="cpu"):
@@ -60,7 +64,8 @@ def global_weight_sums(local_sum, local_sumsq, device="cpu"):
 
 
 def gather_concat(t):
-    """all-gather of equally- or unequally-sized shards along dim 0 (pads to the largest)."""
+    """all-gather of equally- or unequally-sized shards along dim 0 (pads to the largest).  Used by tests and result
+    collection only - the filter step itself never gathers particle arrays."""
     rank, world = _world()
     if world == 1:
         return t
@@ -76,38 +81,114 @@ def gather_concat(t):
     return torch.cat([o[:k] for o, k in zip(outs, ns)], 0)
 
 
+def exchange_plan(bounds, n_total, rank, world):
+    """From the offspring ranges [bounds[r], bounds[r+1]) the shards produce and the destination blocks of the new
+    particle array: how many offspring this rank sends to / receives from every rank (in rank order, which is also
+    ascending offspring order on both sides)."""
+    my_first, my_count = shard_bounds(n_total, rank, world)
+    p_lo, p_hi = int(bounds[rank]), int(bounds[rank + 1])
+    send, recv = [], []
+    for q in range(world):
+        qf, qc = shard_bounds(n_total, q, world)
+        send.append(max(0, min(p_hi, qf + qc) - max(p_lo, qf)))
+        recv.append(max(0, min(int(bounds[q + 1]), my_first + my_count) - max(int(bounds[q]), my_first)))
+    return send, recv
+
+
+class DevicePrims:
+    """The per-rank compute of the step on the GPU: thin calls into the C ABI (laser_slam_amd.capi)."""
+
+    def __init__(self, ctx, field, d_scan_x, d_scan_y, n_points, decimation=3):
+        from . import capi
+        self.capi, self.ctx, self.field = capi, ctx, field
+        self.sx, self.sy, self.n_points, self.decim = d_scan_x, d_scan_y, n_points, decimation
+
+    def score(self, poses):
+        s = torch.empty(poses.shape[0], device=poses.device)
+        self.field.score_poses(self.sx, self.sy, self.n_points, self.decim, poses, poses.shape[0], s)
+        return s
+
+    def argmax(self, s):
+        return self.capi.pose_argmax(self.ctx, s, s.shape[0])
+
+    def weights(self, s, gmax):
+        w = torch.empty_like(s)
+        a, b = self.capi.pf_weights(self.ctx, s, s.shape[0], gmax, w)
+        return w, a, b
+
+    def fixed_sum(self, w):
+        return self.capi.pf_fixed_sum(self.ctx, w, w.shape[0])
+
+    def offspring_bounds(self, w, offset, n_total, U0, W):
+        e = torch.empty(w.shape[0], dtype=torch.int32, device=w.device)
+        self.capi.pf_offspring_bounds(self.ctx, w, w.shape[0], offset, n_total, U0, W, e)
+        return e
+
+    def parents(self, e, m_first, m_count):
+        p = torch.empty(m_count, dtype=torch.int32, device=e.device)
+        self.capi.pf_parents(self.ctx, e, e.shape[0], m_first, m_count, p)
+        return p
+
+    def gather(self, poses, parent):
+        out = torch.empty(parent.shape[0], 3, device=poses.device)
+        self.capi.gather_poses(self.ctx, poses, parent, parent.shape[0], out)
+        self.ctx.sync()
+        return out
+
+
 class ShardedParticleFilter:
-    """One localisation step over this rank's particle shard.
+    """One localisation step over this rank's particle shard; `prims` supplies score / argmax / weights /
+    fixed_sum / offspring_bounds / parents / gather (DevicePrims, or stand-ins in the CPU tests)."""
 
-    local_score(poses[M,3]) -> scores[M]      (lsa_score_poses)
-    local_argmax(scores) -> (max, index)      (lsa_pose_argmax)
-    local_weights(scores, gmax) -> (w[M], sum, sumsq)     (lsa_pf_weights)
-    local_resample(all_w[N], u0, first, M) -> parent[M]   (lsa_pf_resample)
-    local_gather(all_poses[N,3], parent[M]) -> poses[M,3] (lsa_gather_poses)
-    """
-
-    def __init__(self, n_total, local_score, local_argmax, local_weights, local_resample, local_gather,
-                 resample_threshold=0.5, device="cpu"):
+    def __init__(self, n_total, prims, resample_threshold=0.5, device="cpu"):
         self.rank, self.world = _world()
         self.n_total = n_total
         self.first, self.count = shard_bounds(n_total, self.rank, self.world)
-        self.fn = (local_score, local_argmax, local_weights, local_resample, local_gather)
+        self.prims = prims
         self.resample_threshold = resample_threshold          # g_resample_threshold, globaldef.cpp:22
         self.device = device
+        self.bytes_sent = 0                                   # payload handed to other ranks (all steps so far)
+
+    def resample(self, w, poses, u0):
+        """Systematic resampling of the sharded set; returns this rank's block of the new particle array."""
+        from . import capi
+        P, rank, world = self.prims, self.rank, self.world
+        mine = torch.tensor([P.fixed_sum(w)], dtype=torch.int64, device=self.device)     # < 2^63
+        if world > 1:
+            outs = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(outs, mine)
+            sums = [int(v) for v in outs]
+            self.bytes_sent += 8 * (world - 1)
+        else:
+            sums = [int(mine)]
+        W, U0, bounds = capi.pf_plan(sums, self.n_total, u0)
+        offset = sum(sums[:rank])
+        p_lo, p_cnt = int(bounds[rank]), int(bounds[rank + 1] - bounds[rank])
+        if p_cnt > 0:
+            e = P.offspring_bounds(w, offset, self.n_total, U0, W)
+            prod = P.gather(poses, P.parents(e, p_lo, p_cnt))                                # offspring p_lo .. p_lo + p_cnt - 1
+        else:
+            prod = poses[:0]
+        if world == 1:
+            return prod.contiguous()
+        send, recv = exchange_plan(bounds, self.n_total, rank, world)
+        out = torch.empty(self.count, 3, dtype=poses.dtype, device=poses.device)
+        dist.all_to_all_single(out, prod.contiguous(), output_split_sizes=recv, input_split_sizes=send)
+        self.bytes_sent += 12 * (sum(send) - send[rank])
+        return out
 
     def step(self, poses, u0):
         """poses: this rank's [count,3] tensor.  Returns (new poses, info dict)."""
-        score, argmax, weights, resample, gather = self.fn
-        s = score(poses)
-        lmax, lidx = argmax(s)
+        P = self.prims
+        s = P.score(poses)
+        lmax, lidx = P.argmax(s)
         gmax, gidx = global_best(lmax, lidx, self.first, self.device)
-        w, lsum, lsumsq = weights(s, gmax)
+        w, lsum, lsumsq = P.weights(s, gmax)
         tot, tot2, neff = global_weight_sums(lsum, lsumsq, self.device)
+        if self.world > 1:
+            self.bytes_sent += (16 + 16) * (self.world - 1)
         info = dict(best_score=gmax, best_index=gidx, weight_sum=tot, n_eff=neff, resampled=False)
         if neff < self.resample_threshold * self.n_total:      # particles.cpp:350
-            all_w = gather_concat(w)
-            all_p = gather_concat(poses)
-            parent = resample(all_w, u0, self.first, self.count)
-            poses = gather(all_p, parent)
+            poses = self.resample(w, poses, u0)
             info["resampled"] = True
         return poses, info

@@ -1,6 +1,6 @@
-"""CPU, world_size 2 (gloo): the exchange logic of the sharded pose-scoring / particle-filter
-step (laser_slam_amd/pf.py) and of the sharded scan-pair batches, with numpy stand-ins for the
-per-rank HIP results.  The sharded result must equal the single-process result exactly."""
+"""CPU, world_size 2 and 3 (gloo): the exchange logic of the sharded particle-filter step (laser_slam_amd/pf.py,
+SURVEY.md 8e) and of the sharded grid mapping, with numpy / oracle stand-ins for the per-rank HIP results, and the
+N-rank launch path of bench.py.  The sharded result must equal the single-process result exactly."""
 import os
 import sys
 
@@ -20,35 +20,59 @@ def _scores(poses):
     return -((poses[:, 0] - 3.0) ** 2 + (poses[:, 1] + 1.0) ** 2) * 4.0 - torch.abs(poses[:, 2]) * 0.5
 
 
-def _make_fns():
-    from oracle_lib import Oracle  # systematic resampler restated in oracle/pose_oracle.c
-    import ctypes as C
-    L = Oracle("LMS211").L
+class NumpyPrims:
+    """Stand-ins for the HIP kernels behind laser_slam_amd.pf.DevicePrims, in exact integer arithmetic (Python ints):
+    the definitions csrc/shard_kernels.hip implements."""
 
-    def score(p):
+    def score(self, p):
         return _scores(p)
 
-    def argmax(s):
+    def argmax(self, s):
         m = float(s.max())
         return m, int(torch.nonzero(s == m)[0])
 
-    def weights(s, gmax):
+    def weights(self, s, gmax):
         w = torch.exp(s - gmax).float()
         wd = w.double()
         return w, float(wd.sum()), float((wd * wd).sum())
 
-    def resample(all_w, u0, first, M):
-        w = np.ascontiguousarray(all_w.numpy(), np.float32)
-        n_total = len(w)
-        parent = np.zeros(n_total, np.int32)
-        L.orc_systematic_resample(w.ctypes.data_as(C.c_void_p), n_total, C.c_double(u0), n_total,
-                                  parent.ctypes.data_as(C.c_void_p))
-        return torch.from_numpy(parent[first:first + M].copy())
+    @staticmethod
+    def quantise(w):
+        wd = np.clip(w.numpy().astype(np.float64), 0.0, 1.0)
+        return [int(v) for v in np.floor(wd * 4294967296.0)]
 
-    def gather(all_p, parent):
-        return all_p[parent.long()]
+    def fixed_sum(self, w):
+        return sum(self.quantise(w))
 
-    return score, argmax, weights, resample, gather
+    def offspring_bounds(self, w, offset, n_total, U0, W):
+        e, c = [], offset
+        for q in self.quantise(w):
+            c += q
+            x = c * n_total - U0
+            e.append(0 if x <= 0 else min(n_total, -(-x // W)))
+        return torch.tensor(e, dtype=torch.int32)
+
+    def parents(self, e, m_first, m_count):
+        m = np.arange(m_first, m_first + m_count)
+        return torch.from_numpy(np.searchsorted(e.numpy(), m, side="right").astype(np.int32))
+
+    def gather(self, poses, parent):
+        return poses[parent.long()]
+
+
+def _reference_resample(w_all, n_total, u0):
+    """Systematic resampling of the whole set straight from the definition: offspring m sits at m W + U0 on the axis of
+    N-fold cumulative fixed-point weights; its parent is the first particle whose N-fold cumulative weight exceeds it."""
+    q = NumpyPrims.quantise(w_all)
+    W = sum(q)
+    U0 = (int(np.ldexp(u0, 53)) * W) >> 53
+    parent, i, c = [], 0, q[0]
+    for m in range(n_total):
+        while c * n_total <= m * W + U0:
+            i += 1
+            c += q[i]
+        parent.append(i)
+    return np.array(parent)
 
 
 def _worker(rank, world, port, n_total, out_dir):
@@ -58,35 +82,76 @@ def _worker(rank, world, port, n_total, out_dir):
     from laser_slam_amd import pf
     rng = np.random.default_rng(5)
     poses_all = torch.from_numpy(rng.normal(0, 2, (n_total, 3)).astype(np.float32))
-    f = pf.ShardedParticleFilter(n_total, *_make_fns(), resample_threshold=0.9)
+    f = pf.ShardedParticleFilter(n_total, NumpyPrims(), resample_threshold=0.9)
     mine = poses_all[f.first:f.first + f.count]
     new, info = f.step(mine, 0.37)
+    assert new.shape[0] == f.count
     allnew = pf.gather_concat(new)
+    sent = pf.gather_concat(torch.tensor([f.bytes_sent], dtype=torch.int64))
     if rank == 0:
         np.save(os.path.join(out_dir, "poses.npy"), allnew.numpy())
+        np.save(os.path.join(out_dir, "sent.npy"), sent.numpy())
         np.save(os.path.join(out_dir, "info.npy"), np.array([info["best_score"], info["best_index"], info["weight_sum"],
                                                              info["n_eff"], float(info["resampled"])]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [1000, 1001])
-def test_sharded_pf_step_equals_single_process(n_total, tmp_path):
+@pytest.mark.parametrize("world,n_total", [(2, 1000), (2, 1001), (3, 1000), (3, 4099)])
+def test_sharded_pf_step_equals_single_process(world, n_total, tmp_path):
+    """SURVEY 8(e)'s scheme: one 8-byte weight sum per rank is gathered, every rank resolves its own strata locally,
+    only offspring that belong to another rank's block travel (12 B each).  The sharded step must give exactly the
+    single-process step, and a rank must hand over O(N / world) bytes - the r1 scheme gathered 16 N bytes to every rank."""
     from laser_slam_amd import pf
-    port = 29500 + (os.getpid() % 400) + (n_total % 7)
-    mp.spawn(_worker, args=(2, port, n_total, str(tmp_path)), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 300) + 17 * world + (n_total % 7)
+    mp.spawn(_worker, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "poses.npy")
     info = np.load(tmp_path / "info.npy")
-    # single-process reference of the same step
+    sent = np.load(tmp_path / "sent.npy")
+    # single-process run of the same step (world 1: no collective at all)
     rng = np.random.default_rng(5)
     poses_all = torch.from_numpy(rng.normal(0, 2, (n_total, 3)).astype(np.float32))
-    f = pf.ShardedParticleFilter(n_total, *_make_fns(), resample_threshold=0.9)
+    f = pf.ShardedParticleFilter(n_total, NumpyPrims(), resample_threshold=0.9)
     ref, ref_info = f.step(poses_all, 0.37)
     assert ref_info["resampled"] and info[4] == 1.0
-    assert np.array_equal(got, ref.numpy())
+    assert got.shape == (n_total, 3) and np.array_equal(got, ref.numpy())
     assert info[1] == ref_info["best_index"] and info[0] == ref_info["best_score"]
     assert abs(info[2] - ref_info["weight_sum"]) < 1e-9 * ref_info["weight_sum"]
     assert abs(info[3] - ref_info["n_eff"]) < 1e-9 * ref_info["n_eff"]
+    # ... which is systematic resampling by its definition
+    w_all = NumpyPrims().weights(_scores(poses_all), ref_info["best_score"])[0]
+    parent = _reference_resample(w_all, n_total, 0.37)
+    assert np.array_equal(ref.numpy(), poses_all.numpy()[parent])
+    # bytes handed to other ranks: the offspring outside the rank's own block + the records, not the particle set
+    per_rank = -(-n_total // world)
+    assert sent.max() <= 12 * per_rank + 64 * world, sent
+    assert sent.max() < 16 * n_total / 4                      # (r1: 16 N per rank)
+    assert sent.sum() > 0
+
+
+def test_pf_plan_host_arithmetic():
+    """lsa_pf_plan (host side of the C ABI, no GPU): total, U0 = floor(u0 W) and the offspring ranges of the shards
+    against Python integers, incl. totals beyond 2^53 where doubles would no longer be exact."""
+    from laser_slam_amd import capi
+    rng = np.random.default_rng(11)
+    for world in (1, 2, 3, 8):
+        for scale in (1 << 20, 1 << 40, (1 << 59) // world):
+            sums = [int(v) for v in rng.integers(1, scale, world)]
+            n_total = int(rng.integers(world, 1 << 23))
+            u0 = float(rng.random())
+            W, U0, bounds = capi.pf_plan(sums, n_total, u0)
+            assert W == sum(sums) and U0 == (int(np.ldexp(u0, 53)) * W) >> 53 and U0 < W
+            off, want = 0, []
+            for r in range(world + 1):
+                x = off * n_total - U0
+                want.append(0 if x <= 0 else min(n_total, -(-x // W)))
+                if r < world:
+                    off += sums[r]
+            assert list(bounds) == want and bounds[0] == 0 and bounds[-1] == n_total
+    with pytest.raises(capi.LsaError):
+        capi.pf_plan([0, 0], 10, 0.5)                        # "total likelihood zero", SIRFlt.cpp:150-152
+    with pytest.raises(capi.LsaError):
+        capi.pf_plan([5, 5], 10, 1.0)
 
 
 def test_shard_bounds_cover_everything():
