@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: scan-matches/s on synthetic 1081-beam scans (BASELINE.json).
 
-A "step" = one batch of `--pairs` scan-pair matches (pm_icp, the matcher behind the
-reference's FMatch front door) over a device-resident, already preprocessed scan set.
-Inputs are in HBM before the timed region.  With N ranks (torch.distributed / RCCL)
-each rank matches its own batch (independent pairs -> no data-path collective, weak
-scaling); value = all pairs of all ranks / max-over-ranks time.
+A "step" = one batch of `--pairs` scan-pair matches (pm_icp, the matcher behind the reference's FMatch front door)
+over a device-resident, already preprocessed scan set.  Inputs are in HBM before the timed region.
 
-Prints ONE JSON line (rank 0) with the contract's fields plus `roofline`
-(dominant kernel = icp_kernel, algorithmic bytes per SURVEY.md §8d) and
-`cpu_baseline` (the reference built in place when oracle/_ref travelled, else the
-oracle port; bounded sample on the host cores).
+`--gpus N`: one process per GPU.  Under torchrun (WORLD_SIZE set) this process is one rank; started plainly with
+N > 1 it launches the N ranks itself (child processes, before anything touches the GPU) and rank 0 prints the line.
+Each rank matches its own batch (independent pairs -> no data-path collective, weak scaling); value = all pairs of all
+ranks / max-over-ranks time.  The particle-filter step, the one part of the path with an exchange, is timed as a
+secondary entry over `torch.distributed` (RCCL) with 2^20 particles per rank.
+
+Prints ONE JSON line (rank 0): the contract's fields, `roofline` for the dominant kernel (icp_kernel is bound by
+vector-instruction issue: instructions per pair from the committed PMC pass x pairs/s against 256 CUs x 4 SIMDs x
+2.4 GHz / 4; the HBM figure of SURVEY.md 8d beside it), `secondary` (the other kernels of the path, each with its own
+roofline) and `cpu_baseline` (the reference built in place when oracle/_ref travelled, else the oracle port: single
+thread and all host cores, bounded samples, timed before the GPU is touched).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -23,46 +30,204 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BYTES_PER_PAIR = 2 * 1081 * 4 + 12 + 20      # SURVEY.md §8d: 8 680 B per 1081-beam pair
+BYTES_PER_PAIR = 2 * 1081 * 4 + 12 + 20      # SURVEY.md 8d: 8 680 B per 1081-beam pair
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4.0       # wave64 instructions/s: 256 CUs x 4 SIMDs, one per 4 cycles at 2.4 GHz
 FP32_PEAK_TFLOPS = 157.3
+PROFILE_ROUND = "r02"
+N_BASE, SEEDS = 200, 8
 
 
-def build_scan_set(n_scans, seeds):
+def build_scan_set():
     from laser_slam_amd import synth
-    sets = [synth.make_scans(n_scans, noise_seed=synth.WORLD_SEED + j)[0] for j in range(seeds)]
+    sets = [synth.make_scans(N_BASE, noise_seed=synth.WORLD_SEED + j)[0] for j in range(SEEDS)]
     return np.concatenate(sets, 0)
 
 
-def cpu_baseline(raw, n_pairs, which, gpu_match=None):
-    """Time the CPU path on a bounded sample of the same workload (rank 0 only).  With `gpu_match` the device's
-    poses for the very same pairs are set against the CPU's: BASELINE.json's "pose RMSE vs CPU ref"."""
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline: worker processes (started before this process touches the GPU), one matcher object per process
+def cpu_worker(raw_path, start, count, which, out_path):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     from laser_slam_amd import synth
+    raw = np.load(raw_path)
     use_ref = oracle_lib.have_ref()
     eng = oracle_lib.Ref(**synth.SYN1081) if use_ref else oracle_lib.Oracle(**synth.SYN1081)
-    pre = [eng.preprocess(raw[k]) for k in range(n_pairs + 1)]
+    pre = [eng.preprocess(raw[k]) for k in range(start, start + count + 1)]
+    pose = np.zeros((count, 3), np.float32); st = np.zeros(count, np.int32)
     t0 = time.perf_counter()
-    cpu_pose = np.zeros((n_pairs, 3), np.float32); cpu_st = np.zeros(n_pairs, np.int32)
-    for b in range(n_pairs):
+    for b in range(count):
         res = eng.match(which, pre[b], pre[b + 1])
-        cpu_st[b] = res[0]; cpu_pose[b] = res[1]
+        st[b] = res[0]; pose[b] = res[1]
     dt = time.perf_counter() - t0
-    out = {"value": n_pairs / dt, "unit": "scan-matches/s", "cores": 1,
-           "kind": "reference" if use_ref else "port",
-           "sample": "%d consecutive synthetic 1081-beam pairs, pm_icp, single thread, preprocessing excluded (%.1f s)"
-                     % (n_pairs, dt)}
-    if gpu_match is not None:
-        g_pose, g_st = gpu_match(n_pairs)
-        ok = (cpu_st == 0) & (g_st == 0)
-        d = (g_pose[ok].astype(np.float64) - cpu_pose[ok].astype(np.float64))
-        out["pose_rmse_vs_cpu"] = {
-            "pairs": int(n_pairs), "matched_by_both": int(ok.sum()), "status_mismatches": int(((cpu_st == 0) != (g_st == 0)).sum()),
-            "xy_m": float(np.sqrt(np.mean(d[:, 0] ** 2 + d[:, 1] ** 2)) * 0.01) if ok.any() else None,
-            "theta_rad": float(np.sqrt(np.mean(d[:, 2] ** 2))) if ok.any() else None,
-            "bit_identical": bool(np.array_equal(g_pose[ok].view(np.uint32), cpu_pose[ok].view(np.uint32)))}
+    np.savez(out_path, dt=dt, pose=pose, st=st, ref=int(use_ref))
+
+
+def host_cores():
+    """Cores this job may use: the affinity mask, cut to the cgroup's CPU quota where one is set (a GPU box hands a
+    one-GPU job a share of its cores; starting a process per visible core would only queue them up)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                cores = max(1, min(cores, int(float(quota) / period + 0.5)))
+            break
+        except Exception:
+            continue
+    cap = os.environ.get("LSA_BENCH_CORES")
+    if cap:
+        cores = max(1, min(cores, int(cap)))
+    return min(cores, 64)
+
+
+def cpu_baseline(raw, n_pairs, which):
+    """Single thread, then all host cores (one process each over disjoint pair ranges, as BASELINE.md 2 timed the
+    reference), on bounded samples of the bench workload; preprocessing excluded from the timer."""
+    cores = host_cores()
+    tmp = tempfile.mkdtemp(prefix="lsa_bench_")
+    raw_path = os.path.join(tmp, "raw.npy")
+    np.save(raw_path, raw)
+
+    def run(jobs, tag):
+        procs = []
+        for k, (start, count) in enumerate(jobs):
+            out = os.path.join(tmp, "%s%d.npz" % (tag, k))
+            procs.append((out, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", raw_path, str(start),
+                                                 str(count), str(which), out], stderr=subprocess.DEVNULL)))
+        res = []
+        for out, p in procs:
+            if p.wait() != 0:
+                raise RuntimeError("CPU baseline worker failed")
+            with np.load(out) as z:
+                res.append({k: z[k] for k in z.files})
+        return res
+
+    one = run([(0, n_pairs)], "one")[0]
+    per = n_pairs
+    jobs = [((k * 97) % (raw.shape[0] - per - 1), per) for k in range(cores)]     # disjoint-ish ranges of the same scan set
+    many = run(jobs, "all")
+    wall = max(float(r["dt"]) for r in many)
+    kind = "reference" if int(one["ref"]) else "port"
+    out = {"value": cores * per / wall, "unit": "scan-matches/s", "cores": cores, "kind": kind,
+           "sample": "%d processes x %d consecutive synthetic 1081-beam pairs each, pm_icp, one matcher object per process, "
+                     "preprocessing excluded (%.1f s)" % (cores, per, wall),
+           "single_thread": {"value": n_pairs / float(one["dt"]), "unit": "scan-matches/s", "cores": 1, "kind": kind,
+                             "sample": "%d consecutive synthetic 1081-beam pairs, pm_icp, preprocessing excluded (%.1f s)"
+                                       % (n_pairs, float(one["dt"]))}}
+    return out, one["pose"], one["st"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """--gpus N without torchrun: start the N ranks as child processes (this process never touches the GPU)."""
+    import torch
+    backend = os.environ.get("LSA_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()                      # (counting devices does not initialise the GPU)
+    if backend == "nccl" and ndev < n and "--rehearse-launch" not in argv:
+        sys.stderr.write("bench.py: --gpus %d needs %d devices, %d visible (LSA_DIST_BACKEND=gloo lets ranks share devices "
+                         "for a rehearsal)\n" % (n, n, ndev))
+        return 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+            if rc:
+                break
+    finally:
+        for p in procs:                                   # a failed rank must not leave the others at a barrier
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def rehearse_launch(rank, world, args):
+    """The N-rank launch path without a GPU: rendezvous, barrier, max-over-ranks reduction, one line from rank 0."""
+    import torch
+    t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "scan-matches/sec (1081-beam)", "rehearsal": True, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "max_over_ranks_s": float(t.item())}), flush=True)
+    return 0
+
+
+def load_profile(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "%s_%s.json" % (PROFILE_ROUND, name))))
+    except Exception:
+        return None
+
+
+def pmc_per_unit(kernel):
+    """Counters of the committed rocprofv3 PMC passes (profiles/r02_pmc_*.json, tools/collect_profiles.py), per
+    launch and per unit (pair / scan): VALU wave-instructions, busy share of the issue slots at the clock the chip
+    held, HBM bytes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE)."""
+    out = {}
+    sq, hbm = load_profile("pmc_sq_counters"), load_profile("pmc_hbm_traffic")
+    key = "lsa::" + kernel
+    if sq and key in sq:
+        rec = sq[key]
+        units = rec.get("units_per_launch")
+        if units:
+            out["valu_instr_per_unit"] = rec["SQ_INSTS_VALU"] / units
+        out["valu_busy_frac"] = rec["SQ_ACTIVE_INST_VALU"] / (rec["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0)
+    if hbm and key in hbm:
+        rec = hbm[key]
+        units = rec.get("units_per_launch") or rec.get("pairs_per_launch")
+        if units:
+            out["hbm_bytes_per_unit"] = (2.0 * rec["FETCH_SIZE_KB_per_launch"] + rec["WRITE_SIZE_KB_per_launch"]) * 1024.0 / units
     return out
+
+
+def valu_roofline(kernel, units_per_s, kernel_ms, units_per_launch, alg_bytes_per_unit, extra=None):
+    """Roofline of an instruction-issue-bound matcher kernel: VALU wave-instructions/s against the issue peak, the
+    HBM figure (algorithmic bytes of SURVEY.md 8d) beside it."""
+    pm = pmc_per_unit(kernel)
+    ipu = pm.get("valu_instr_per_unit")
+    hbm_gbs = alg_bytes_per_unit * units_per_launch / (kernel_ms * 1e-3) / 1e9
+    r = {"bound": "valu", "achieved": ipu * units_per_s / 1e9 if ipu else None, "peak": VALU_PEAK_GINSTR, "unit": "Ginstr/s",
+         "frac": ipu * units_per_s / 1e9 / VALU_PEAK_GINSTR if ipu else None,
+         "traffic": pm["hbm_bytes_per_unit"] * units_per_launch if "hbm_bytes_per_unit" in pm else None,
+         "kernel": kernel, "kernel_ms": kernel_ms, "valu_instr_per_unit": ipu, "valu_busy_frac": pm.get("valu_busy_frac"),
+         "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
+                 "bytes_per_unit": alg_bytes_per_unit},
+         "note": "vector-instruction-issue bound (DESIGN.md 4.1): achieved = wave64 VALU instructions per unit (rocprofv3 "
+                 "SQ_INSTS_VALU, profiles/%s_pmc_sq_counters.json) x units/s measured here; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4; "
+                 "valu_busy_frac = share of issue slots busy at the clock the chip held; hbm = algorithmic bytes of SURVEY 8d" % PROFILE_ROUND}
+    if extra:
+        r.update(extra)
+    return r
+
+
+def hbm_roofline(kernel, alg_bytes, ms, units_per_launch=None, label=None):
+    pm = pmc_per_unit(kernel)
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+         "traffic": pm["hbm_bytes_per_unit"] * units_per_launch if units_per_launch and "hbm_bytes_per_unit" in pm else None,
+         "kernel": kernel, "kernel_ms": ms}
+    if label:
+        r["note"] = label
+    return r
 
 
 def main():
@@ -74,15 +239,36 @@ def main():
     ap.add_argument("--matcher", default="icp", choices=["icp", "psm"])
     ap.add_argument("--cpu-pairs", type=int, default=400)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--extras", action="store_true", help="also time PSM, preprocess and grid update")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary kernels (profiling passes of the headline alone)")
+    ap.add_argument("--cpu-worker", nargs=5, metavar=("RAW", "START", "COUNT", "WHICH", "OUT"), help=argparse.SUPPRESS)
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="launcher plumbing only, no GPU: the ranks meet over gloo and rank 0 prints a line with n_gpus (tests/test_dist_cpu.py)")
     args = ap.parse_args()
+    if args.cpu_worker:
+        raw_path, start, count, which, out = args.cpu_worker
+        cpu_worker(raw_path, int(start), int(count), int(which), out)
+        return 0
 
-    import torch
-    from laser_slam_amd import capi, synth
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is used\n" % (args.gpus, world))
+    if args.rehearse_launch:
+        return rehearse_launch(rank, world, args)
+
+    raw = build_scan_set()                                    # [1600][1081]
+    which_i = 1 if args.matcher == "icp" else 0
+    cpu = cpu_pose = cpu_st = None
+    if rank == 0 and world == 1 and not args.no_cpu:          # before the GPU is touched (worker processes are started)
+        cpu, cpu_pose, cpu_st = cpu_baseline(raw, args.cpu_pairs, which_i)
+
+    import torch
+    from laser_slam_amd import capi, synth
+
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -100,10 +286,9 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev_index = torch.cuda.current_device()
+    coll_dev = "cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu"
 
     # ---- workload: synthetic 1081-beam scans, consecutive pairs, zero initial guess ----
-    n_base, seeds = 200, 8
-    raw = build_scan_set(n_base, seeds)                       # [1600][1081]
     S, n = raw.shape
     p = capi.param_make(**synth.SYN1081)
     ctx = capi.Context(p, dev_index)
@@ -117,7 +302,7 @@ def main():
     ctx.preprocess_batch(S, d_r, d_bad, d_seg)
     # pairs (k-1, k) inside each seed's run, tiled up to the batch size; each rank takes a
     # different rotation so ranks do not match identical pairs
-    base_pairs = np.array([(s * n_base + k - 1, s * n_base + k) for s in range(seeds) for k in range(1, n_base)], np.int32)
+    base_pairs = np.array([(s * N_BASE + k - 1, s * N_BASE + k) for s in range(SEEDS) for k in range(1, N_BASE)], np.int32)
     B = args.pairs
     sel = (np.arange(B) + rank * 7919) % len(base_pairs)
     d_ri = torch.from_numpy(np.ascontiguousarray(base_pairs[sel, 0])).cuda()
@@ -149,7 +334,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -159,8 +344,8 @@ def main():
     value = total_pairs / elapsed
 
     out = None
+    kern = "%s_kernel" % args.matcher
     if rank == 0:
-        achieved = BYTES_PER_PAIR * B / (kernel_ms * 1e-3) / 1e9
         W = p.window
         flops_pair = mean_iters * (n * 2 * W * 6 + 60 * n) if which == capi.MATCH_ICP else \
             mean_iters / 2 * ((2 * W + 1) * n * 3) + mean_iters * 60 * n
@@ -173,114 +358,91 @@ def main():
                                    "pm_%s batched, one 256-thread workgroup per pair" % args.matcher,
                        "pairs_per_step_per_gpu": B, "beams": n, "matcher": "pm_" + args.matcher,
                        "mean_iterations": mean_iters, "failed_fraction": fail_frac, "parallelism": "pairs sharded x%d" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "%s_kernel" % args.matcher, "kernel_ms": kernel_ms,
-                         "bytes_per_pair": BYTES_PER_PAIR,
-                         "note": "the matcher is vector-instruction-issue bound, not HBM bound (DESIGN.md 4.1; valu_busy_frac); "
-                                 "effective_fp32_frac prices the REFERENCE algorithm's arithmetic (brute-force window "
-                                 "search) at this rate against the fp32 vector peak - the kernel prunes that search "
-                                 "exactly, so these are not executed flops",
-                         "effective_fp32_frac": flops_pair * B / (kernel_ms * 1e-3) / (FP32_PEAK_TFLOPS * 1e12),
-                         "reference_flops_per_pair": flops_pair},
+            "roofline": valu_roofline(kern, B / (kernel_ms * 1e-3), kernel_ms, B, BYTES_PER_PAIR,
+                                      {"reference_flops_per_pair": flops_pair,
+                                       "effective_fp32_frac": flops_pair * B / (kernel_ms * 1e-3) / (FP32_PEAK_TFLOPS * 1e12)}),
         }
-        out["secondary"] = secondary(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, which)
-        out["roofline"]["traffic"] = pmc_traffic(args.matcher, B)
-        out["roofline"]["valu_busy_frac"] = pmc_valu_busy(args.matcher)
-        if args.extras:
-            out["extras"] = extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p)
-        if not args.no_cpu and world == 1:                   # (rank 0 at N = 1 only: the other ranks would wait for it)
-            def gpu_match(m):                              # the CPU sample's pairs (k, k + 1) on the device
-                ri = torch.arange(0, m, dtype=torch.int32, device="cuda"); ai = ri + 1
-                gp = torch.zeros(m, 3, device="cuda"); gs = torch.zeros(m, dtype=torch.int32, device="cuda")
-                torch.cuda.synchronize()
-                ctx.match_batch(which, m, d_r, d_bad, d_seg, ri, ai, gp, d_status=gs); ctx.sync()
-                return gp.cpu().numpy(), gs.cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(raw, args.cpu_pairs, 1 if which == capi.MATCH_ICP else 0, gpu_match)
+    # ---- secondary kernels of the path -------------------------------------------------------------------------
+    sec = {}
+    if not args.no_extras:
+        if rank == 0:
+            sec.update(secondary_matchers(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, which, raw, n))
+        sec_pf = secondary_pf(torch, capi, ctx, dist, rank, world, raw, p, coll_dev)     # (all ranks: it has collectives)
+        if rank == 0:
+            sec.update(sec_pf)
+            if world == 1:
+                sec.update(secondary_grid(torch, capi, ctx, raw, p))
+    if rank == 0:
+        out["secondary"] = sec
+        if cpu is not None:
+            m = len(cpu_st)
+            ri = torch.arange(0, m, dtype=torch.int32, device="cuda"); ai = ri + 1
+            gp = torch.zeros(m, 3, device="cuda"); gs = torch.zeros(m, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            ctx.match_batch(which, m, d_r, d_bad, d_seg, ri, ai, gp, d_status=gs); ctx.sync()
+            g_pose, g_st = gp.cpu().numpy(), gs.cpu().numpy()
+            ok = (cpu_st == 0) & (g_st == 0)
+            d = (g_pose[ok].astype(np.float64) - cpu_pose[ok].astype(np.float64))
+            cpu["pose_rmse_vs_cpu"] = {
+                "pairs": int(m), "matched_by_both": int(ok.sum()), "status_mismatches": int(((cpu_st == 0) != (g_st == 0)).sum()),
+                "xy_m": float(np.sqrt(np.mean(d[:, 0] ** 2 + d[:, 1] ** 2)) * 0.01) if ok.any() else None,
+                "theta_rad": float(np.sqrt(np.mean(d[:, 2] ** 2))) if ok.any() else None,
+                "bit_identical": bool(np.array_equal(g_pose[ok].view(np.uint32), cpu_pose[ok].view(np.uint32)))}
+            out["cpu_baseline"] = cpu
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
-def secondary(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, which):
-    """The other matcher of the path on the same batch (one timed launch), for the record."""
-    other = capi.MATCH_PSM if which == capi.MATCH_ICP else capi.MATCH_ICP
-    pose = torch.zeros(B, 3, device="cuda")
-    ctx.match_batch(other, B, d_r, d_bad, d_seg, d_ri, d_ai, pose)
-    torch.cuda.synchronize()
+def timed(torch, fn, reps=3):
+    fn(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record(); ctx.match_batch(other, B, d_r, d_bad, d_seg, d_ri, d_ai, pose); b.record()
-    torch.cuda.synchronize()
-    return {("pm_psm" if other == capi.MATCH_PSM else "pm_icp") + "_matches_per_s": B / (a.elapsed_time(b) * 1e-3)}
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
 
 
-def pmc_traffic(matcher, B):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs at
-    32768 pairs per launch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled to
-    this batch size.  None when the profile file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    try:
-        rec = json.load(open(path))["lsa::%s_kernel" % matcher]
-        per_pair = (2.0 * rec["FETCH_SIZE_KB_per_launch"] + rec["WRITE_SIZE_KB_per_launch"]) * 1024.0 / rec.get("pairs_per_launch", 32768)
-        return per_pair * B
-    except Exception:
-        return None
-
-
-def pmc_valu_busy(matcher):
-    """Share of the SIMDs' issue slots the dominant kernel keeps busy with vector instructions, from the
-    committed SQ counter pass (profiles/r01_pmc_sq_counters.json): SQ_ACTIVE_INST_VALU (quad-cycles) over
-    GRBM_GUI_ACTIVE / 8 XCDs / 4 cycles x 1024 SIMDs.  This, not HBM, is the resource the matcher runs
-    against.  None when the profile file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_sq_counters.json")
-    try:
-        rec = json.load(open(path))["lsa::%s_kernel" % matcher]
-        return rec["SQ_ACTIVE_INST_VALU"] / (rec["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0)
-    except Exception:
-        return None
-
-
-def extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p):
-    """Secondary kernels of the path, timed the same way (not the headline)."""
-    from laser_slam_amd import synth
+def secondary_matchers(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, which, raw, n):
+    """The other matcher of zhpsm, the point-to-line ICP of zhcsm and the batched preprocessing, each on its own."""
     res = {}
+    other = capi.MATCH_PSM if which == capi.MATCH_ICP else capi.MATCH_ICP
+    oname = "psm" if other == capi.MATCH_PSM else "icp"
+    pose = torch.zeros(B, 3, device="cuda")
+    ms = timed(torch, lambda: ctx.match_batch(other, B, d_r, d_bad, d_seg, d_ri, d_ai, pose), reps=1)
+    res["pm_%s" % oname] = {"value": B / (ms * 1e-3), "unit": "scan-matches/s", "pairs": B,
+                            "roofline": valu_roofline("%s_kernel" % oname, B / (ms * 1e-3), ms, B, BYTES_PER_PAIR)}
     # point-to-line ICP (CCanonicalMatcher / zhcsm's matcher), raw scans, 8192 pairs
     Bp = 8192
     d_raw = torch.from_numpy(raw).cuda()
     d_o8 = torch.zeros(Bp, 8, dtype=torch.float64, device="cuda")
-    torch.cuda.synchronize()
-    capi.plicp_batch(ctx, Bp, d_raw, d_ri[:Bp].contiguous(), d_ai[:Bp].contiguous(), d_o8); ctx.sync()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record(); capi.plicp_batch(ctx, Bp, d_raw, d_ri[:Bp].contiguous(), d_ai[:Bp].contiguous(), d_o8); b.record()
-    torch.cuda.synchronize()
-    res["plicp_matches_per_s"] = Bp / (a.elapsed_time(b) * 1e-3)
-    res["plicp_mean_iterations"] = float(d_o8[:, 5].mean().item())
-    pose = torch.zeros(B, 3, device="cuda")
-
-    def timed(fn, reps=3):
-        fn(); torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(reps):
-            fn()
-        b.record(); torch.cuda.synchronize()
-        return a.elapsed_time(b) / reps
-
-    ms = timed(lambda: ctx.match_batch(capi.MATCH_PSM, B, d_r, d_bad, d_seg, d_ri, d_ai, pose))
-    res["pm_psm_matches_per_s"] = B / (ms * 1e-3)
-    S, n = raw.shape
+    ri, ai = d_ri[:Bp].contiguous(), d_ai[:Bp].contiguous()
+    ms = timed(torch, lambda: capi.plicp_batch(ctx, Bp, d_raw, ri, ai, d_o8), reps=1)
+    res["plicp"] = {"value": Bp / (ms * 1e-3), "unit": "scan-matches/s", "pairs": Bp, "mean_iterations": float(d_o8[:, 5].mean().item()),
+                    "roofline": valu_roofline("plicp_kernel", Bp / (ms * 1e-3), ms, Bp, BYTES_PER_PAIR,
+                                              {"note": "double-precision point-to-line ICP (parity unpinned: CSM absent); "
+                                                       "instruction-issue and latency bound, DESIGN.md 4.7"})}
+    S = raw.shape[0]
     Sp = 16384                                              # batched preprocessing (one lane per scan from 4096 scans on)
     big = np.tile(raw, ((Sp + S - 1) // S, 1))[:Sp]
     r2 = torch.from_numpy(big).cuda(); b2 = torch.zeros(Sp, n, dtype=torch.uint8, device="cuda"); s2 = torch.zeros(Sp, n, dtype=torch.int16, device="cuda")
-    ms = timed(lambda: ctx.preprocess_batch(Sp, r2, b2, s2), reps=1)
-    res["preprocess_scans_per_s"] = Sp / (ms * 1e-3)
-    # grid update: 4096^2 @ 5 cm, scans inserted at their true poses
+    ms = timed(torch, lambda: ctx.preprocess_batch(Sp, r2, b2, s2), reps=1)
+    res["preprocess"] = {"value": Sp / (ms * 1e-3), "unit": "scans/s", "scans": Sp,
+                         "roofline": hbm_roofline("preprocess_lanes_kernel", Sp * n * 12.0, ms, Sp,
+                                                  "12 B per beam: ranges read and written, flags read and written, segments written")}
+    return res
+
+
+def secondary_grid(torch, capi, ctx, raw, p):
+    """CPMap: binned batch insertion into 4096^2 @ 5 cm and the probability pass."""
+    from laser_slam_amd import synth
+    res = {}
+    n = raw.shape[1]
     fi = capi.param_tables(p)[0]
     nb = 2048
-    _, poses = synth.make_scans(1)
     poses = synth.path_pose(np.arange(nb))
     rr = np.concatenate([raw, raw])[:nb] / 100.0
     gx = (poses[:, 0:1] + rr * np.cos(poses[:, 2:3] + fi[None])).astype(np.float32)
@@ -288,88 +450,109 @@ def extras(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, raw, p):
     grid = capi.Grid(ctx, 4096, 4096, 1024, 1024, 0.0, 0.0, 0.05)
     dgx, dgy = torch.from_numpy(gx).cuda(), torch.from_numpy(gy).cuda()
     drob = torch.from_numpy(poses[:, :2].astype(np.float32)).cuda()
-    ms = timed(lambda: grid.update_batch(nb, n, dgx, dgy, drob), reps=2)
+    ms = timed(torch, lambda: grid.update_batch(nb, n, dgx, dgy, drob), reps=2)
     cells = float(np.mean(np.maximum(np.abs(gx - poses[:, 0:1]), np.abs(gy - poses[:, 1:2])) / 0.05)) + 1
-    res["grid_update_scans_per_s"] = nb / (ms * 1e-3)
-    res["grid_update_cells_per_s"] = nb * n * cells / (ms * 1e-3)
-    res["grid_update_GBps_algorithmic"] = nb * n * (cells * 8 + 16) / (ms * 1e-3) / 1e9
-    ms = timed(lambda: grid.compute_prob(), reps=3)
-    res["grid_prob_GBps"] = 12 * 4096 * 4096 / (ms * 1e-3) / 1e9
-    # pose scoring (likelihood field of the map just built): 1 M poses around the path, 1081-beam scan / 3
-    fld = capi.Field(ctx, 4096, 4096, 1024, 1024, 0.0, 0.0, 0.05)
+    res["grid_update"] = {"value": nb / (ms * 1e-3), "unit": "scans/s", "scans": nb, "cells_per_s": nb * n * cells / (ms * 1e-3),
+                          "mean_ray_cells": cells,
+                          "roofline": hbm_roofline("grid_binned_kernel", nb * n * (cells * 8 + 16), ms, nb,
+                                                   "EFFECTIVE: SURVEY 8d's algorithmic read-modify-write bytes N (L 8 + 16) per scan over the "
+                                                   "whole batch update (prep + binning + walk); the walk accumulates in LDS tiles, so the bytes "
+                                                   "that reach HBM (`traffic`, PMC) are far fewer")}
+    ms = timed(torch, lambda: grid.compute_prob(), reps=3)
+    res["grid_prob"] = {"value": 4096 * 4096 / (ms * 1e-3), "unit": "cells/s",
+                        "roofline": hbm_roofline("grid_prob_kernel", 12.0 * 4096 * 4096, ms, 1,
+                                                 "12 B per cell; the 201 MB working set is Infinity-Cache resident between launches")}
+    grid.close()
+    return res
+
+
+def secondary_pf(torch, capi, ctx, dist, rank, world, raw, p, coll_dev):
+    """Particle-filter localisation step (config 4), 2^20 particles PER RANK sharded over the ranks (pf.py over
+    torch.distributed; at one rank no collective runs): predict, likelihood-field scores, best pose, weights / N_eff,
+    fixed-point systematic resampling with the surplus exchange, roughening.  Also the scorer alone."""
+    from laser_slam_amd import pf, synth
+    res = {}
+    n = raw.shape[1]
+    fi = capi.param_tables(p)[0]
+    # a map of the synthetic world: 256 scans inserted at their true poses, then the likelihood field
+    nb = 256
+    poses = synth.path_pose(np.arange(nb) * 6)
+    rr = raw[(np.arange(nb) * 6) % N_BASE] / 100.0
+    gx = (poses[:, 0:1] + rr * np.cos(poses[:, 2:3] + fi[None])).astype(np.float32)
+    gy = (poses[:, 1:2] + rr * np.sin(poses[:, 2:3] + fi[None])).astype(np.float32)
+    G = 4096
+    grid = capi.Grid(ctx, G, G, 1024, 1024, 0.0, 0.0, 0.05)
+    grid.update_batch(nb, n, torch.from_numpy(gx).cuda(), torch.from_numpy(gy).cuda(), torch.from_numpy(poses[:, :2].astype(np.float32)).cuda())
+    grid.compute_prob()
+    fld = capi.Field(ctx, G, G, 1024, 1024, 0.0, 0.0, 0.05)
     t0 = time.perf_counter()
     fld.build_from_grid(grid); ctx.sync()
-    res["field_build_ms_4096sq"] = (time.perf_counter() - t0) * 1e3
+    res["field_build"] = {"value": (time.perf_counter() - t0) * 1e3, "unit": "ms", "grid": "%dx%d" % (G, G)}
     P = 1 << 20
-    rng = np.random.default_rng(1)
+    n_total = P * world
+    rng = np.random.default_rng(1 + rank)
     pp = np.stack([10 + rng.normal(0, 1.0, P), 7.5 + rng.normal(0, 1.0, P), rng.normal(0, 0.3, P)], 1).astype(np.float32)
     d_p = torch.from_numpy(pp).cuda()
     sxy = (rr[0][:, None] * np.stack([np.cos(fi), np.sin(fi)], 1)).astype(np.float32)
     d_sx, d_sy = torch.from_numpy(np.ascontiguousarray(sxy[:, 0])).cuda(), torch.from_numpy(np.ascontiguousarray(sxy[:, 1])).cuda()
     d_sc = torch.zeros(P, device="cuda")
     torch.cuda.synchronize()
-    ms = timed(lambda: fld.score_poses(d_sx, d_sy, n, 3, d_p, P, d_sc), reps=3)
-    res["score_poses_per_s"] = P / (ms * 1e-3)
-    res["score_gather_GBps"] = P * ((n + 2) // 3) * 4 / (ms * 1e-3) / 1e9
-    # beam model (ray-cast 541-beam virtual scans in the map just built, 16384 poses) and top-60 of 1 M scores
-    P2, nb2 = 16384, 541
-    d_prob = torch.from_numpy(grid.download(2)).cuda()
-    d_or = torch.full((nb2,), 4.0, device="cuda"); d_ob = torch.zeros(nb2, dtype=torch.uint8, device="cuda")
-    d_s2 = torch.zeros(P2, device="cuda")
-    torch.cuda.synchronize()
-    ms = timed(lambda: capi.beam_model_scores(fld, d_prob, d_p, P2, d_or, d_ob, nb2, d_s2), reps=2)
-    res["beam_model_poses_per_s"] = P2 / (ms * 1e-3)
-    res["beam_model_rays_per_s"] = P2 * nb2 / (ms * 1e-3)
-    # ICP-goodness scorer (obsLikelyhood): virtual 541-beam scan + point-to-point ICP per pose, 16384 poses
-    P3 = 16384
-    ang = (-3.141592654 / 4.0 + np.arange(nb2) * (4.712388981 / (nb2 - 1))).astype(np.float32)
-    d_r1 = torch.zeros(1, nb2, device="cuda"); d_b1 = torch.zeros(1, nb2, dtype=torch.uint8, device="cuda")
-    d_c = torch.tensor([[10.0, 7.5, 0.0]], device="cuda")
-    torch.cuda.synchronize()
-    capi.simulate_scans(fld, d_prob, d_c, 1, nb2, d_r1, d_b1); ctx.sync()
-    r1 = d_r1.cpu().numpy()[0]                      # the scan seen from the centre of the pose cloud
-    d_ox = torch.from_numpy((r1 * np.cos(ang)).astype(np.float32)).cuda(); d_oy = torch.from_numpy((r1 * np.sin(ang)).astype(np.float32)).cuda()
-    d_w3 = torch.zeros(P3, device="cuda")
-    torch.cuda.synchronize()
-    ms = timed(lambda: capi.icp_goodness_scores(fld, d_prob, d_p, P3, d_ox, d_oy, nb2, d_w3), reps=1)
-    res["icp_goodness_poses_per_s"] = P3 / (ms * 1e-3)
-    t0 = time.perf_counter()
-    capi.pose_topk(ctx, d_sc, P, 60)
-    res["topk60_of_1M_ms"] = (time.perf_counter() - t0) * 1e3
-    # the particle filter's resampling step at 1 M particles (weights, the reference's standard resampler, gather)
-    m, _ = capi.pose_argmax(ctx, d_sc, P)
-    d_w = torch.zeros(P, device="cuda"); d_par = torch.zeros(P, dtype=torch.int32, device="cuda"); d_new = torch.zeros(P, 3, device="cuda")
-    d_u = torch.rand(P, dtype=torch.float64, device="cuda")
-    torch.cuda.synchronize()
-
-    def resample_step():
-        capi.pf_weights(ctx, d_sc, P, m, d_w)
-        capi.pf_resample_standard(ctx, d_w, P, d_u, P, d_par)
-        capi.gather_poses(ctx, d_p, d_par, P, d_new)
-    resample_step(); ctx.sync()
-    t0 = time.perf_counter(); resample_step(); ctx.sync()
-    res["pf_resample_1M_ms"] = (time.perf_counter() - t0) * 1e3
-    # one whole localisation step at 1 M particles as CParticles runs it (particles.cpp:119-153, 321-387): predict,
-    # likelihood-field scores, best pose, weights / N_eff, standard resampling, gather, roughening, estimate of the 8 best
+    ms = timed(torch, lambda: fld.score_poses(d_sx, d_sy, n, 3, d_p, P, d_sc), reps=3)
+    nbm = (n + 2) // 3
+    res["score_poses"] = {"value": P / (ms * 1e-3), "unit": "poses/s", "poses": P, "beams_per_pose": nbm,
+                          "roofline": {"bound": "cache-gather", "achieved": P * nbm * 4 / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": P * nbm * 4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "score_poses_kernel",
+                                       "kernel_ms": ms,
+                                       "note": "gathered bytes (P x beams x 4) of the 64 MiB likelihood field, served by L2 / Infinity "
+                                               "Cache; peak = the HBM figure for scale, the gather itself is not an HBM stream"}}
+    prims = pf.DevicePrims(ctx, fld, d_sx, d_sy, n, 3)
+    filt = pf.ShardedParticleFilter(n_total, prims, resample_threshold=2.0, device=coll_dev)     # (threshold 2: every step resamples)
     d_nrm = torch.randn(P, 3, device="cuda"); d_cur = d_p.clone()
+    comm_ranks = world
 
     def pf_step():
         capi.pf_predict(ctx, P, [10.0, 7.5, 0.0], [0.25, 0.25, 0.27], d_nrm, d_cur)
-        fld.score_poses(d_sx, d_sy, n, 3, d_cur, P, d_sc)
-        mm, _ = capi.pose_argmax(ctx, d_sc, P)
-        s1, s2 = capi.pf_weights(ctx, d_sc, P, mm, d_w)
-        if 1.0 / (1.0 + s2 / (s1 * s1)) < 0.5 * P:
-            capi.pf_resample_standard(ctx, d_w, P, d_u, P, d_par)
-            capi.gather_poses(ctx, d_cur, d_par, P, d_new)
-            capi.pf_roughen(ctx, P, 0.2, d_nrm, d_new)
-        return capi.pf_estimate(ctx, d_cur, d_sc, P, 8)
-    pf_step(); ctx.sync()
-    t0 = time.perf_counter(); pf_step(); ctx.sync()
-    res["pf_step_1M_ms"] = (time.perf_counter() - t0) * 1e3
-    fld.close()
-    grid.close()
+        new, info = filt.step(d_cur, 0.37)
+        if world == 1:
+            capi.pf_roughen(ctx, P, 0.2, d_nrm, new)
+        else:                                                # extremes of the whole set: two tiny all-reduces
+            lo = new.min(0).values; hi = new.max(0).values
+            lo_c, hi_c = lo.to(coll_dev), hi.to(coll_dev)
+            dist.all_reduce(lo_c, op=dist.ReduceOp.MIN); dist.all_reduce(hi_c, op=dist.ReduceOp.MAX)
+            scale = 0.2 * float(n_total) ** (-1.0 / 3.0)
+            new += d_nrm * ((hi_c - lo_c).to(new.device) * scale)
+        ctx.sync()
+        return info
+
+    pf_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        info = pf_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = (time.perf_counter() - t0) / reps
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    bytes_pp = 140.0                                         # predict 12 w, score 12 r + 4 w, weights 4 r + 4 w, scan 4 r + 8 w + 8 r,
+    res["pf_step"] = {"value": n_total / dt, "unit": "particles/s", "ms_per_step": dt * 1e3, "particles_total": n_total,
+                      "particles_per_gpu": P, "n_gpus": comm_ranks, "scaling": "weak", "resampled_every_step": bool(info["resampled"]),
+                      "bytes_sent_per_step_rank0": filt.bytes_sent / (reps + 1),
+                      "roofline": {"bound": "hbm", "achieved": n_total * bytes_pp / dt / 1e9, "peak": HBM_PEAK_GBS * comm_ranks, "unit": "GB/s",
+                                   "frac": n_total * bytes_pp / dt / 1e9 / (HBM_PEAK_GBS * comm_ranks), "traffic": None, "kernel": "pf step (10 launches)",
+                                   "kernel_ms": dt * 1e3,
+                                   "note": "about 140 B of particle arrays per particle and step (predict, score, weights, fixed-point scan, "
+                                           "bounds, parents, gather, roughen) + the field gather; a host-synchronised sequence of short "
+                                           "launches and three small collectives, i.e. latency bound at this size"}}
+    fld.close(); grid.close()
     return res
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

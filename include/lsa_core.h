@@ -16,7 +16,10 @@
  *    `throw int` sites of the reference (ZHPolar_Match.cpp:1095,1106,1239,1831).
  *  - a context owns one HIP stream + scratch; contexts are independent, so one
  *    context per host thread is re-entrant (the reference's matchers are used
- *    one-instance-per-thread, src/slam/threadLocal1.cpp:144).
+ *    one-instance-per-thread, src/slam/threadLocal1.cpp:144).  The context's own stream is
+ *    a blocking one (hipStreamDefault): it is ordered against the legacy default stream, so
+ *    buffers prepared there are safe to pass in; a caller-owned stream handed to
+ *    lsa_ctx_set_stream keeps whatever ordering the caller gave it.
  *  - there is NO CPU fallback: without a HIP device every call fails with
  *    LSA_E_NODEVICE.
  *
@@ -382,15 +385,16 @@ int lsa_pf_resample_sharded(lsa_comm* m, const float* d_w, const float* d_poses,
 /* roughen_minmax (SIRFlt.cpp:359-413) with the extremes and the size of the whole particle set */
 int lsa_pf_roughen_sharded(lsa_comm* m, int n_local, int64_t n_total, double K, const float* d_normals, float* d_poses);
 /* the pieces of lsa_pf_resample_sharded, for hosts that bring their own transport (MPI, torch.distributed):
- *   lsa_pf_fixed_sum        sum of floor(w * 2^32) over the shard (exact)
+ *   lsa_pf_fixed_scan       d_cum[i] = sum of floor(w_j * 2^32) over the shard's particles j <= i (exact, 64 bit);
+ *                           h_sum = the shard's total
  *   lsa_pf_plan             host only: from all shards' sums -> total, U0 = floor(u0 * total) and bounds[world + 1]:
  *                           shard r's particles are the parents of offspring [bounds[r], bounds[r + 1])
- *   lsa_pf_offspring_bounds d_e[i] = offspring of the global particles 0 .. (this shard's i); offset = sum of the
- *                           earlier shards' sums
+ *   lsa_pf_offspring_bounds d_e[i] = offspring of the global particles 0 .. (this shard's i), from the shard's cumulative
+ *                           weights; offset = sum of the earlier shards' totals
  *   lsa_pf_parents          local parent index of offspring m_first .. m_first + m_count - 1 (inside this shard's range) */
-int lsa_pf_fixed_sum(lsa_ctx* c, const float* d_w, int n, uint64_t* h_sum);
+int lsa_pf_fixed_scan(lsa_ctx* c, const float* d_w, int n, uint64_t* d_cum, uint64_t* h_sum);
 int lsa_pf_plan(int world, int64_t n_total, const uint64_t* shard_sum, double u0, uint64_t* total, uint64_t* u0_fixed, int64_t* bounds);
-int lsa_pf_offspring_bounds(lsa_ctx* c, const float* d_w, int n, uint64_t offset, int64_t n_total, uint64_t u0_fixed, uint64_t total,
+int lsa_pf_offspring_bounds(lsa_ctx* c, const uint64_t* d_cum, int n, uint64_t offset, int64_t n_total, uint64_t u0_fixed, uint64_t total,
                             int32_t* d_e);
 int lsa_pf_parents(lsa_ctx* c, const int32_t* d_e, int n, int64_t m_first, int m_count, int32_t* d_parent);
 

@@ -6,6 +6,7 @@ or no GPU is present, calls raise.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -126,7 +127,7 @@ def lib():
     L.lsa_pf_global_weights.argtypes = [vp, vp, C.c_int, C.c_float, vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.lsa_pf_resample_sharded.argtypes = [vp, vp, vp, C.c_int, C.c_int64, C.c_double, vp]
     L.lsa_pf_roughen_sharded.argtypes = [vp, C.c_int, C.c_int64, C.c_double, vp, vp]
-    L.lsa_pf_fixed_sum.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_uint64)]
+    L.lsa_pf_fixed_scan.argtypes = [vp, vp, C.c_int, vp, C.POINTER(C.c_uint64)]
     L.lsa_pf_plan.argtypes = [C.c_int, C.c_int64, vp, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp]
     L.lsa_pf_offspring_bounds.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_int64, C.c_uint64, C.c_uint64, vp]
     L.lsa_pf_parents.argtypes = [vp, vp, C.c_int, C.c_int64, C.c_int, vp]
@@ -207,6 +208,9 @@ class Context:
             self.h = vp()
 
     def __del__(self):
+        # (not at interpreter shutdown: the HIP runtime may already be gone, and calling into it then aborts the process)
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -335,6 +339,9 @@ class Grid:
             self.h = vp()
 
     def __del__(self):
+        # (not at interpreter shutdown: the HIP runtime may already be gone, and calling into it then aborts the process)
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -397,6 +404,9 @@ class Field:
             self.h = vp()
 
     def __del__(self):
+        # (not at interpreter shutdown: the HIP runtime may already be gone, and calling into it then aborts the process)
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -556,14 +566,15 @@ def pf_plan(shard_sums, n_total, u0):
     return W.value, U0.value, bounds
 
 
-def pf_fixed_sum(ctx, d_w, n):
+def pf_fixed_scan(ctx, d_w, n, d_cum):
+    """d_cum: int64 / uint64 [n] device tensor; returns the shard's total."""
     s = C.c_uint64(0)
-    check(lib().lsa_pf_fixed_sum(ctx.h, _dp(d_w), n, C.byref(s)), "lsa_pf_fixed_sum")
+    check(lib().lsa_pf_fixed_scan(ctx.h, _dp(d_w), n, _dp(d_cum), C.byref(s)), "lsa_pf_fixed_scan")
     return s.value
 
 
-def pf_offspring_bounds(ctx, d_w, n, offset, n_total, U0, W, d_e):
-    check(lib().lsa_pf_offspring_bounds(ctx.h, _dp(d_w), n, int(offset), int(n_total), int(U0), int(W), _dp(d_e)), "lsa_pf_offspring_bounds")
+def pf_offspring_bounds(ctx, d_cum, n, offset, n_total, U0, W, d_e):
+    check(lib().lsa_pf_offspring_bounds(ctx.h, _dp(d_cum), n, int(offset), int(n_total), int(U0), int(W), _dp(d_e)), "lsa_pf_offspring_bounds")
 
 
 def pf_parents(ctx, d_e, n, m_first, m_count, d_parent):

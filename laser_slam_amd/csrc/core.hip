@@ -300,7 +300,10 @@ int lsa_ctx_create(lsa_ctx** out, int device, const lsa_laser_param* p)
     lsa_ctx* c = new lsa_ctx;
     c->device = device;
     c->p = *p;
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // A blocking stream (hipStreamDefault), not hipStreamNonBlocking: it is ordered against the legacy default stream in
+    // both directions, so a host that prepares buffers on the default stream (hipMemset, a framework's tensor ops)
+    // and then calls in here needs no extra synchronisation.  Contexts remain independent of each other.
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamDefault);
     if (e != hipSuccess) { delete c; return fail(LSA_E_HIP, "hipStreamCreate", e); }
     rc = upload_tables(c);
     if (rc) { hipStreamDestroy(c->stream); delete c; return rc; }
@@ -333,7 +336,7 @@ int lsa_ctx_set_stream(lsa_ctx* c, void* s)
     if (c->own_stream && c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
     if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
     else {
-        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamDefault));
         c->own_stream = true;
     }
     return LSA_OK;

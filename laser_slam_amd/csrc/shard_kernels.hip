@@ -59,6 +59,16 @@ __global__ void shard_scan_sums_kernel(unsigned long long* __restrict__ block_su
     }
 }
 
+// in-block cumulative sums -> cumulative sums of the whole shard
+__global__ __launch_bounds__(SCAN_BLOCK) void shard_scan_apply_kernel(unsigned long long* __restrict__ cum, int P,
+                                                                      const unsigned long long* __restrict__ block_off)
+{
+    const int base = (blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
+    const unsigned long long o = block_off[blockIdx.x];
+    #pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < P) cum[base + k] += o;
+}
+
 // ceil((c * n - u0) / w) clamped to [0, n]: the quotient is at most n < 2^31, so a double estimate is within one of it
 // and the 128-bit remainder settles the rest
 __device__ __forceinline__ int shard_offspring_bound(unsigned long long c, unsigned long long n, unsigned long long u0,
@@ -80,15 +90,13 @@ __device__ __forceinline__ int shard_offspring_bound(unsigned long long c, unsig
     return e > (long long)n ? (int)n : (int)e;
 }
 
-// e_i for the shard's particles: global cumulative weight = offset + block offset + in-block cumulative sum
-__global__ __launch_bounds__(256) void shard_bounds_kernel(const unsigned long long* __restrict__ cum,
-                                                           const unsigned long long* __restrict__ block_off, int P,
+// e_i for the shard's particles: global cumulative weight = offset of the shard + cumulative sum inside it
+__global__ __launch_bounds__(256) void shard_bounds_kernel(const unsigned long long* __restrict__ cum, int P,
                                                            unsigned long long offset, unsigned long long n_total,
                                                            unsigned long long u0, unsigned long long w_total, int* __restrict__ e)
 {
-    const int per = SCAN_BLOCK * SCAN_ITEMS;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x)
-        e[i] = shard_offspring_bound(offset + block_off[i / per] + cum[i], n_total, u0, w_total);
+        e[i] = shard_offspring_bound(offset + cum[i], n_total, u0, w_total);
 }
 
 // parent (local index) of offspring m_first .. m_first + M - 1: the first particle with e > m

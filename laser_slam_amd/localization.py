@@ -40,6 +40,10 @@ def global_search(field, d_prob, d_poses, scan, scorer="likelihood", k=N_KEEP, f
     d_cand = d_poses[keep].contiguous()
     M = d_cand.shape[0]
     d_score = torch.zeros(M, dtype=torch.float32, device=d_poses.device)
+    # the gather and the fill above run on torch's current stream, the scorer on the context's: order them explicitly
+    # (the context's own stream is a blocking one and would wait for the default stream anyway; a caller-owned stream
+    # set with ctx.set_stream might not)
+    torch.cuda.current_stream().synchronize()
     if scorer == "likelihood":
         field.score_poses(scan["x"], scan["y"], scan["x"].numel(), scan.get("decimation", 3), d_cand, M, d_score)
     elif scorer == "beam":

@@ -116,12 +116,13 @@ class DevicePrims:
         a, b = self.capi.pf_weights(self.ctx, s, s.shape[0], gmax, w)
         return w, a, b
 
-    def fixed_sum(self, w):
-        return self.capi.pf_fixed_sum(self.ctx, w, w.shape[0])
+    def fixed_scan(self, w):
+        cum = torch.empty(w.shape[0], dtype=torch.int64, device=w.device)
+        return cum, self.capi.pf_fixed_scan(self.ctx, w, w.shape[0], cum)
 
-    def offspring_bounds(self, w, offset, n_total, U0, W):
-        e = torch.empty(w.shape[0], dtype=torch.int32, device=w.device)
-        self.capi.pf_offspring_bounds(self.ctx, w, w.shape[0], offset, n_total, U0, W, e)
+    def offspring_bounds(self, cum, offset, n_total, U0, W):
+        e = torch.empty(cum.shape[0], dtype=torch.int32, device=cum.device)
+        self.capi.pf_offspring_bounds(self.ctx, cum, cum.shape[0], offset, n_total, U0, W, e)
         return e
 
     def parents(self, e, m_first, m_count):
@@ -138,7 +139,7 @@ class DevicePrims:
 
 class ShardedParticleFilter:
     """One localisation step over this rank's particle shard; `prims` supplies score / argmax / weights /
-    fixed_sum / offspring_bounds / parents / gather (DevicePrims, or stand-ins in the CPU tests)."""
+    fixed_scan / offspring_bounds / parents / gather (DevicePrims, or stand-ins in the CPU tests)."""
 
     def __init__(self, n_total, prims, resample_threshold=0.5, device="cpu"):
         self.rank, self.world = _world()
@@ -153,7 +154,8 @@ class ShardedParticleFilter:
         """Systematic resampling of the sharded set; returns this rank's block of the new particle array."""
         from . import capi
         P, rank, world = self.prims, self.rank, self.world
-        mine = torch.tensor([P.fixed_sum(w)], dtype=torch.int64, device=self.device)     # < 2^63
+        cum, total = P.fixed_scan(w)                         # exact cumulative fixed-point weights of the shard
+        mine = torch.tensor([total], dtype=torch.int64, device=self.device)               # < 2^63
         if world > 1:
             outs = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(outs, mine)
@@ -165,7 +167,7 @@ class ShardedParticleFilter:
         offset = sum(sums[:rank])
         p_lo, p_cnt = int(bounds[rank]), int(bounds[rank + 1] - bounds[rank])
         if p_cnt > 0:
-            e = P.offspring_bounds(w, offset, self.n_total, U0, W)
+            e = P.offspring_bounds(cum, offset, self.n_total, U0, W)
             prod = P.gather(poses, P.parents(e, p_lo, p_cnt))                                # offspring p_lo .. p_lo + p_cnt - 1
         else:
             prod = poses[:0]
@@ -173,7 +175,12 @@ class ShardedParticleFilter:
             return prod.contiguous()
         send, recv = exchange_plan(bounds, self.n_total, rank, world)
         out = torch.empty(self.count, 3, dtype=poses.dtype, device=poses.device)
-        dist.all_to_all_single(out, prod.contiguous(), output_split_sizes=recv, input_split_sizes=send)
+        if dist.get_backend() == "gloo" and prod.is_cuda:    # (rehearsals with ranks sharing a GPU: gloo moves host memory)
+            out_h = torch.empty(self.count, 3, dtype=poses.dtype)
+            dist.all_to_all_single(out_h, prod.cpu().contiguous(), output_split_sizes=recv, input_split_sizes=send)
+            out.copy_(out_h)
+        else:
+            dist.all_to_all_single(out, prod.contiguous(), output_split_sizes=recv, input_split_sizes=send)
         self.bytes_sent += 12 * (sum(send) - send[rank])
         return out
 

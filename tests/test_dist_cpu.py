@@ -41,14 +41,17 @@ class NumpyPrims:
         wd = np.clip(w.numpy().astype(np.float64), 0.0, 1.0)
         return [int(v) for v in np.floor(wd * 4294967296.0)]
 
-    def fixed_sum(self, w):
-        return sum(self.quantise(w))
-
-    def offspring_bounds(self, w, offset, n_total, U0, W):
-        e, c = [], offset
+    def fixed_scan(self, w):
+        cum, c = [], 0
         for q in self.quantise(w):
             c += q
-            x = c * n_total - U0
+            cum.append(c)
+        return cum, c
+
+    def offspring_bounds(self, cum, offset, n_total, U0, W):
+        e = []
+        for c in cum:
+            x = (offset + c) * n_total - U0
             e.append(0 if x <= 0 else min(n_total, -(-x // W)))
         return torch.tensor(e, dtype=torch.int32)
 
@@ -210,3 +213,25 @@ def test_sharded_grid_mapping_equals_single_process(tmp_path):
     assert np.array_equal(np.load(tmp_path / "hit.npy"), hit.numpy())
     assert np.array_equal(np.load(tmp_path / "sum.npy"), visits.numpy())
     assert int(hit.sum()) == 2 * S * 181 or int(hit.sum()) > 0
+
+
+def test_bench_launches_n_ranks_itself():
+    """`python bench.py --gpus N` without torchrun starts N ranks (child processes, before anything touches the GPU),
+    they rendezvous, and rank 0 alone prints the line with n_gpus = N.  --rehearse-launch keeps the GPU out of it."""
+    import json
+    import subprocess
+    for n in (1, 2, 3):
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+                              "--rehearse-launch"], capture_output=True, text=True, timeout=300,
+                             env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")})
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == n and rec["steps"] == 2 and abs(rec["max_over_ranks_s"] - 0.001 * n) < 1e-12
+    # under a launcher that sets the environment (torchrun), the process is one rank and does not spawn
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rehearse-launch"], capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert res.returncode == 0 and json.loads(res.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    assert "WORLD_SIZE=1" in res.stderr

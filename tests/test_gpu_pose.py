@@ -145,31 +145,27 @@ def test_sharded_filter_single_gpu(world):
     P = 20000
     poses = torch.from_numpy(np.stack([rng.uniform(1, 12, P), rng.uniform(1, 9, P), rng.uniform(-3, 3, P)], 1).astype(np.float32)).cuda()
 
-    # the context launches on its own HIP stream: hand results back to torch only after a sync
-    def score(p):
-        s = torch.zeros(p.shape[0], device="cuda"); torch.cuda.synchronize()
-        fld.score_poses(d_x, d_y, n, 3, p, p.shape[0], s); ctx.sync(); return s
-
-    def argmax(s):
-        return capi.pose_argmax(ctx, s, s.shape[0])
-
-    def weights(s, gmax):
-        w = torch.zeros_like(s); torch.cuda.synchronize(); a, b = capi.pf_weights(ctx, s, s.shape[0], gmax, w); return w, a, b
-
-    def resample(all_w, u0, first, M):
-        par = torch.zeros(M, dtype=torch.int32, device="cuda"); torch.cuda.synchronize()
-        capi.pf_resample(ctx, all_w, all_w.shape[0], u0, all_w.shape[0], first, M, par); return par
-
-    def gather(all_p, par):
-        out = torch.zeros(par.shape[0], 3, device="cuda"); torch.cuda.synchronize()
-        capi.gather_poses(ctx, all_p, par, par.shape[0], out); ctx.sync(); return out
-
-    f = pf.ShardedParticleFilter(P, score, argmax, weights, resample, gather, device="cuda")
+    prims = pf.DevicePrims(ctx, fld, d_x, d_y, n, 3)
+    f = pf.ShardedParticleFilter(P, prims, device="cuda")
     new, info = f.step(poses, 0.25)
     ctx.sync()
-    assert info["resampled"] and new.shape == (P, 3)
+    assert info["resampled"] and new.shape == (P, 3) and f.bytes_sent == 0
     # resampling concentrates the particles on high-score poses
-    assert float(score(new).mean()) > float(score(poses).mean())
+    assert float(prims.score(new).mean()) > float(prims.score(poses).mean())
+    # ... and is systematic resampling of the fixed-point weights by its definition
+    s = prims.score(poses); ctx.sync()
+    w = np.exp(s.cpu().numpy() - np.float32(info["best_score"])).astype(np.float32)
+    wd, _, _ = prims.weights(s, info["best_score"]); ctx.sync()
+    q = [int(v) for v in np.floor(np.clip(wd.cpu().numpy().astype(np.float64), 0, 1) * 4294967296.0)]
+    W = sum(q); U0 = (int(np.ldexp(0.25, 53)) * W) >> 53
+    c, e = 0, []
+    for v in q:
+        c += v
+        x = c * P - U0
+        e.append(0 if x <= 0 else min(P, -(-x // W)))
+    par = np.searchsorted(np.array(e), np.arange(P), side="right")
+    assert np.array_equal(new.cpu().numpy(), poses.cpu().numpy()[par])
+    assert np.allclose(wd.cpu().numpy(), w, rtol=2e-6)
 
 
 def test_scan_simulator_and_beam_model(world):

@@ -41,10 +41,12 @@ def test_fixed_point_resampling_is_split_independent(n_total, sharp):
     d_w, d_p = torch.from_numpy(w).cuda(), torch.from_numpy(poses).cuda()
     torch.cuda.synchronize()
     # the whole set as one shard
-    assert capi.pf_fixed_sum(ctx, d_w, n_total) == sum(q)
+    d_cum = torch.zeros(n_total, dtype=torch.int64, device="cuda")
+    assert capi.pf_fixed_scan(ctx, d_w, n_total, d_cum) == sum(q)
+    assert np.array_equal(d_cum.cpu().numpy(), np.cumsum(np.array(q, np.int64)))
     W, U0, bounds = capi.pf_plan([sum(q)], n_total, u0)
     d_e = torch.zeros(n_total, dtype=torch.int32, device="cuda")
-    capi.pf_offspring_bounds(ctx, d_w, n_total, 0, n_total, U0, W, d_e); ctx.sync()
+    capi.pf_offspring_bounds(ctx, d_cum, n_total, 0, n_total, U0, W, d_e); ctx.sync()
     e_one = d_e.cpu().numpy()
     if n_total <= 200000:
         assert np.array_equal(e_one, _py_bounds(q, 0, n_total, U0, W))
@@ -60,12 +62,13 @@ def test_fixed_point_resampling_is_split_independent(n_total, sharp):
     assert np.all(np.abs(cnt - expect) < 1.0 + 1e-9)
     # the same set as 3 and as 7 virtual shards: stitched offspring == the one-shard result
     for world in (3, 7):
-        sums, blocks = [], []
+        sums, blocks, cums = [], [], []
         for r in range(world):
             f, c = pf.shard_bounds(n_total, r, world)
             assert (f, c) == capi.shard_bounds(n_total, r, world)
             blocks.append((f, c))
-            sums.append(capi.pf_fixed_sum(ctx, d_w[f:f + c], c))
+            cums.append(torch.zeros(c, dtype=torch.int64, device="cuda"))
+            sums.append(capi.pf_fixed_scan(ctx, d_w[f:f + c], c, cums[r]))
         assert sums == [sum(q[f:f + c]) for f, c in blocks]
         W2, U02, b2 = capi.pf_plan(sums, n_total, u0)
         assert (W2, U02) == (W, U0) and b2[0] == 0 and b2[-1] == n_total
@@ -78,7 +81,7 @@ def test_fixed_point_resampling_is_split_independent(n_total, sharp):
                 sent.append(0)
                 continue
             d_er = torch.zeros(c, dtype=torch.int32, device="cuda")
-            capi.pf_offspring_bounds(ctx, d_w[f:f + c], c, sum(sums[:r]), n_total, U0, W, d_er)
+            capi.pf_offspring_bounds(ctx, cums[r], c, sum(sums[:r]), n_total, U0, W, d_er)
             d_pr = torch.zeros(cnt_r, dtype=torch.int32, device="cuda")
             capi.pf_parents(ctx, d_er, c, lo, cnt_r, d_pr)
             d_out = torch.zeros(cnt_r, 3, device="cuda")
