@@ -1,0 +1,106 @@
+"""GPU: every scan pair of the three CARMEN logs the reference ships (BASELINE.json configs 1, 2, 5), bit for bit.
+
+tests/golden/full_<name>.npz hold what the reference's own code (compiled in place in the build container,
+tests/golden/make_full_logs.py) returns for all 1463 + 2671 + 1050 consecutive pairs: pm_psm and pm_icp from a zero
+prior, and the FMatch chain of the front-ends.  For mit-cscail the chained poses then feed all 1051 scans into a
+4096 x 4096 CPMap whose layers must hash to the reference CPMap's (config 5 at full length)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, chain_poses, same_bits, scan_endpoints
+
+pytestmark = pytest.mark.gpu
+
+LASER = {"fr079": "LMS511", "intel": "LMS211", "mit": "LMS511"}
+
+
+def _load(name):
+    z = np.load(os.path.join(GOLDEN, "full_%s.npz" % name))
+    g = {k: z[k] for k in z.files}
+    g["r"] = g["raw_r_u16"].astype(np.float32) if "raw_r_u16" in g else g["raw_r"]
+    g["bad"] = g["raw_bad"] if "raw_bad" in g else np.zeros(g["r"].shape, np.uint8)
+    g["P"] = dict(zip([str(k) for k in g["param_keys"]], g["param"]))
+    return g
+
+
+def _context(capi, name, g):
+    p = capi.param_preset(LASER[name])
+    p.fi_min = np.float32(g["P"]["fi_min"]); p.fi_max = np.float32(g["P"]["fi_max"]); p.max_range = int(g["P"]["max_range"])
+    return capi.Context(p), p
+
+
+@pytest.mark.parametrize("name", ["fr079", "intel", "mit"])
+def test_whole_log_every_pair_bit_identical(name):
+    import torch
+    from laser_slam_amd import capi
+    g = _load(name)
+    ctx, p = _context(capi, name, g)
+    S, n = g["r"].shape
+    B = S - 1
+    assert B == {"fr079": 1463, "intel": 2671, "mit": 1050}[name]
+    d_r = torch.from_numpy(g["r"]).cuda(); d_bad = torch.from_numpy(g["bad"].astype(np.uint8)).cuda()
+    d_seg = torch.zeros(S, n, dtype=torch.int16, device="cuda")
+    ri = torch.arange(0, B, dtype=torch.int32, device="cuda"); ai = ri + 1
+    torch.cuda.synchronize()
+    ctx.preprocess_batch(S, d_r, d_bad, d_seg)
+    for which, nm in ((capi.MATCH_PSM, "psm"), (capi.MATCH_ICP, "icp")):
+        pose = torch.zeros(B, 3, device="cuda"); st = torch.zeros(B, dtype=torch.int32, device="cuda")
+        exy = torch.zeros(B, 2, device="cuda")
+        torch.cuda.synchronize()
+        ctx.match_batch(which, B, d_r, d_bad, d_seg, ri, ai, pose, d_err_xy=exy, d_status=st); ctx.sync()
+        got, gst = pose.cpu().numpy(), st.cpu().numpy()
+        want_st = g[nm + "_status"].astype(np.int32)
+        assert np.array_equal(gst != 0, want_st != 0), (nm, np.nonzero((gst != 0) != (want_st != 0))[0][:10])
+        ok = want_st == 0
+        bad_pairs = np.nonzero(ok & (got.view(np.uint32) != g[nm + "_pose"].view(np.uint32)).any(1))[0]
+        assert len(bad_pairs) == 0, (nm, bad_pairs[:10], got[bad_pairs[:3]], g[nm + "_pose"][bad_pairs[:3]])
+        assert np.all(got[~ok] == 0)                      # lsa untouched where the reference throws
+        if which == capi.MATCH_ICP:
+            # FMatch = preprocess the current scan once + pm_icp from zero + pm_error_index2 (ZHPolar_Match.cpp:81-121)
+            fm_ok = ~((g["fmatch_pair"][:, 0] < 0) & (g["fmatch_pair"][:, 1] < 0))
+            assert np.array_equal(fm_ok, ok)
+            assert same_bits(got[fm_ok], g["fmatch_pose"][fm_ok])
+            e = exy.cpu().numpy()
+            assert same_bits(e[fm_ok], g["fmatch_pair"][fm_ok])
+            assert np.all(e[~fm_ok] == -1)
+    ctx.close()
+
+
+def test_mit_cscail_full_chain_into_4096_grid():
+    import torch
+    from laser_slam_amd import capi
+    g = _load("mit")
+    ctx, p = _context(capi, "mit", g)
+    S, n = g["r"].shape
+    B = S - 1
+    d_r = torch.from_numpy(g["r"]).cuda(); d_bad = torch.from_numpy(g["bad"].astype(np.uint8)).cuda()
+    d_seg = torch.zeros(S, n, dtype=torch.int16, device="cuda")
+    ri = torch.arange(0, B, dtype=torch.int32, device="cuda"); ai = ri + 1
+    torch.cuda.synchronize()
+    ctx.preprocess_batch(S, d_r, d_bad, d_seg)
+    pose = torch.zeros(B, 3, device="cuda"); st = torch.zeros(B, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.match_batch(capi.MATCH_ICP, B, d_r, d_bad, d_seg, ri, ai, pose, d_status=st); ctx.sync()
+    rel, failed = pose.cpu().numpy(), st.cpu().numpy() != 0
+    gp = chain_poses(rel, failed)
+    assert np.array_equal(gp, g["chain_pose"])             # same relative poses, same double arithmetic
+    pre_r, pre_bad = d_r.cpu().numpy(), d_bad.cpu().numpy()
+    fi = capi.param_tables(p)[0]
+    gx = np.zeros((S, n), np.float32); gy = np.zeros((S, n), np.float32); nv = np.zeros(S, np.int32)
+    for k in range(S):
+        gx[k], gy[k], nv[k] = scan_endpoints(pre_r[k], pre_bad[k], fi, gp[k], p.max_range)
+    assert np.array_equal(nv, g["map_n_valid"])
+    G = [int(v) for v in g["map_geom"][:4]]
+    grid = capi.Grid(ctx, G[0], G[1], G[2], G[3], float(g["map_geom"][4]), float(g["map_geom"][5]), float(g["map_geom"][6]))
+    rob = gp[:, :2].astype(np.float32)
+    grid.update_batch(S, n, torch.from_numpy(gx).cuda(), torch.from_numpy(gy).cuda(), torch.from_numpy(rob).cuda(),
+                      torch.from_numpy(nv).cuda())
+    grid.compute_prob(); ctx.sync()
+    hit, sm, prob = grid.layers()
+    assert int(hit.astype(np.int64).sum()) == int(g["map_hit_total"][0]) and int(sm.astype(np.int64).sum()) == int(g["map_sum_total"][0])
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert [sha(hit.astype(np.int32)), sha(sm.astype(np.int32)), sha(prob.astype(np.float32))] == [str(s) for s in g["map_sha"]]
+    grid.close(); ctx.close()

@@ -147,3 +147,25 @@ def test_grid_line_quirks():
     assert b[0].tolist() == [2, 1] and len(a) == len(b) == 9
     c = grid_line(0, 9, 1, 0)
     assert c[0].tolist() == [1, 0] and c[-1].tolist() == [0, 9] and len(c) == 10
+
+
+@pytest.mark.parametrize("name,laser", [("fr079", "LMS511"), ("intel", "LMS211"), ("mit", "LMS511")])
+def test_oracle_on_whole_log_goldens(name, laser):
+    """tests/golden/full_<name>.npz (every pair of the shipped logs, reference-made): the CPU oracle on every 40th
+    pair and on every pair the reference failed - pins the file the GPU test of the whole logs relies on."""
+    from oracle_lib import Oracle
+    z = np.load(os.path.join(GOLDEN, "full_%s.npz" % name))
+    r = z["raw_r_u16"].astype(np.float32) if "raw_r_u16" in z.files else z["raw_r"]
+    bad = z["raw_bad"].astype(np.int32) if "raw_bad" in z.files else np.zeros(r.shape, np.int32)
+    P = dict(zip([str(k) for k in z["param_keys"]], z["param"]))
+    o = Oracle(laser)
+    o.set_fimin_maxrange(np.float32(P["fi_min"]), int(P["max_range"]))
+    B = r.shape[0] - 1
+    picks = sorted(set(range(0, B, 40)) | set(np.nonzero(z["icp_status"])[0].tolist()) | set(np.nonzero(z["psm_status"])[0].tolist()))
+    for b in picks:
+        a, c = o.preprocess(r[b], bad[b]), o.preprocess(r[b + 1], bad[b + 1])
+        for which, nm in ((0, "psm"), (1, "icp")):
+            st, pose, _, _ = o.match(which, a, c)
+            assert (st != 0) == (z[nm + "_status"][b] != 0), (name, nm, b)
+            if st == 0:
+                assert same_bits(pose, z[nm + "_pose"][b]), (name, nm, b)
