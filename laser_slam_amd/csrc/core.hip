@@ -1475,12 +1475,15 @@ int lsa_plicp_batch_cov(lsa_ctx* c, int B, const float* d_r, const int32_t* d_re
         HIP_TRY(hipMalloc((void**)&c->d_trig, sizeof(double) * t.size()));
         HIP_TRY(hipMemcpy(c->d_trig, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
     }
-    // four workgroups per CU fit while 4 x LDS <= 160 KB; larger scans get the instance budgeted for three
+    // four workgroups per CU fit while 4 x LDS <= 160 KB; larger scans get the instance budgeted for fewer
+#ifndef LSA_PLICP_WG_BIG
+#define LSA_PLICP_WG_BIG 3
+#endif
     const bool four = 4 * (size_t)lsa::plicp_lds_bytes(P.n) <= 160 * 1024;
     if (d_cov9) return four ? plicp_launch<4, true>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9)
-                            : plicp_launch<3, true>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9);
+                            : plicp_launch<LSA_PLICP_WG_BIG, true>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9);
     return four ? plicp_launch<4, false>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, 0.0, nullptr)
-                : plicp_launch<3, false>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, 0.0, nullptr);
+                : plicp_launch<LSA_PLICP_WG_BIG, false>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, 0.0, nullptr);
 }
 
 int lsa_plicp_batch(lsa_ctx* c, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,

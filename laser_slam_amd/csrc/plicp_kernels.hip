@@ -673,26 +673,33 @@ __global__ __launch_bounds__(PLICP_THREADS, WG) void plicp_kernel(PlicpParam P, 
         }
         for (int i = tid; i < n; i += PLICP_THREADS) L.corr[i] = -1;      // no previous match to seed the search with
         __syncthreads();
-        const double q0[3] = {0, 0, 0};
-        double x[3] = {0, 0, 0}, error = 0, res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int nvalid = 0, iters = 0;
-        if (plicp_loop(P, L, q0, x, error, nvalid, iters)) {
-            double best_error = error, best[3] = {x[0], x[1], x[2]};
-            bool restarted = false;
-            if (P.restart && error / nvalid > P.restart_threshold_mean_error) {
-                restarted = true;
-                const double dt = P.restart_dt, dth = P.restart_dtheta;
-                for (int a = 0; a < 6; ++a) {
-                    const double start[3] = {x[0] + (a == 0 ? dt : a == 1 ? -dt : 0.0), x[1] + (a == 2 ? dt : a == 3 ? -dt : 0.0),
-                                             x[2] + (a == 4 ? dth : a == 5 ? -dth : 0.0)};
-                    double xa[3] = {0, 0, 0}, my_error = 0;
-                    int my_valid = 0, my_iters = 0;
-                    __syncthreads();
-                    if (!plicp_loop(P, L, start, xa, my_error, my_valid, my_iters)) continue;
-                    iters += my_iters;
-                    if (my_error < best_error) { best_error = my_error; best[0] = xa[0]; best[1] = xa[1]; best[2] = xa[2]; }
-                }
+        // sm_icp: one icp_loop from the first guess (0); if its mean error exceeds the threshold, six more from poses
+        // perturbed around its result, the lowest total error wins.  One call site for all seven runs (a = -1: the first),
+        // so that the loop body exists once in the binary.
+        double x[3] = {0, 0, 0}, best[3] = {0, 0, 0}, best_error = 0, res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int nvalid = 0, iters = 0, runs = 1;
+        bool ok_first = false, restarted = false;
+        for (int a = -1; a < runs - 1; ++a) {
+            const double dt = P.restart_dt, dth = P.restart_dtheta;
+            const double start[3] = {x[0] + (a == 0 ? dt : a == 1 ? -dt : 0.0), x[1] + (a == 2 ? dt : a == 3 ? -dt : 0.0),
+                                     x[2] + (a == 4 ? dth : a == 5 ? -dth : 0.0)};
+            double xa[3] = {0, 0, 0}, my_error = 0;
+            int my_valid = 0, my_iters = 0;
+            __syncthreads();
+            const bool ok = plicp_loop(P, L, start, xa, my_error, my_valid, my_iters);
+            if (a < 0) {
+                iters = my_iters;
+                if (!ok) break;
+                ok_first = true;
+                x[0] = xa[0]; x[1] = xa[1]; x[2] = xa[2];
+                best[0] = xa[0]; best[1] = xa[1]; best[2] = xa[2]; best_error = my_error; nvalid = my_valid;
+                if (P.restart && my_error / my_valid > P.restart_threshold_mean_error) { restarted = true; runs = 7; }
+            } else if (ok) {
+                iters += my_iters;
+                if (my_error < best_error) { best_error = my_error; best[0] = xa[0]; best[1] = xa[1]; best[2] = xa[2]; }
             }
+        }
+        if (ok_first) {
             res[0] = best[0]; res[1] = best[1]; res[2] = best[2]; res[3] = 1; res[4] = best_error; res[5] = iters; res[6] = nvalid;
             if (COV) {
                 if (restarted) {                  // sm_icp recomputes the correspondences at the result after restarts (no outlier rejection)
