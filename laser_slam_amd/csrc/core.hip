@@ -158,6 +158,18 @@ int lsa_debug_plicp_trace(double* out, int* n)
 }
 #endif
 
+#ifdef LSA_CHECK_INDEX
+// diagnostic build only: read and reset the wild-index counters of icp_kernel
+int lsa_debug_bad_index(unsigned int* out4)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out4, HIP_SYMBOL(lsa::lsa_bad_index), sizeof(unsigned int) * 4));
+    unsigned int z[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lsa::lsa_bad_index), z, sizeof z));
+    return LSA_OK;
+}
+#endif
+
 const char* lsa_version(void) { return "laser_slam_amd 0.2 (gfx950)"; }
 
 const char* lsa_last_error(void) { return g_err.c_str(); }

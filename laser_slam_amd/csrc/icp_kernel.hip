@@ -39,6 +39,14 @@ __device__ unsigned long long lsa_phase_cycles[16];
 #define STAMP_ARGS
 #define STAMP_PASS
 #endif
+// -DLSA_CHECK_INDEX: beam indices taken from match records are checked before they address HBM (a wild index is counted in
+// lsa_bad_index and clamped instead of faulting the GPU).  Diagnostic builds only.
+#ifdef LSA_CHECK_INDEX
+__device__ unsigned int lsa_bad_index[4];
+#define CHECK_INDEX(i, n, slot) do { if ((unsigned)(i) >= (unsigned)(n)) { atomicAdd(&lsa_bad_index[slot], 1u); (i) = 0; } } while (0)
+#else
+#define CHECK_INDEX(i, n, slot) do {} while (0)
+#endif
 // ------------------------------------------------------------------------------------------------------------
 constexpr float NN_CAP = 10001.0f;     // matches with d^2 >= 100^2 are rejected anyway (:1811)
 
@@ -128,6 +136,7 @@ constexpr float REF_FAR = 1.0e18f;
 
 __device__ __forceinline__ float2 ref_point(const DevParam& P, const Lds& L, int j)
 {
+    CHECK_INDEX(j, P.n, 0);
     float2 q = L.ref_xy[j];
     if (q.x >= 0.5f * REF_FAR) { const float rr = L.g_ref_r[j]; q = make_float2(rr * P.co[j], rr * P.si[j]); }   // :1710-1711
     return q;
@@ -151,6 +160,7 @@ __device__ __forceinline__ float2 interp_candidate(const DevParam& P, const Lds&
 __device__ __forceinline__ float2 cur_point(const DevParam& P, const float* g_act_r, int i,
                                             float co, float si, float ax, float ay)
 {
+    CHECK_INDEX(i, P.n, 1);
     float rr = g_act_r[i];
     float cx = rr * P.co[i], cy = rr * P.si[i];
     return make_float2(cx * co - cy * si + ax, cx * si + cy * co + ay);
@@ -442,7 +452,10 @@ __device__ __forceinline__ int count_ge_from(const float* row, int cnt, float d,
 
 __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt STAMP_ARGS)
 {
-    const int tid = threadIdx.x;
+    // (opaque copy of the thread index: what is derived from it - LDS addresses of a dozen arrays - is formed again every
+    //  iteration instead of being hoisted out of the pair loop, where it occupied registers that then spilled)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     unsigned long long* A = L.key;
     unsigned long long* Pc = L.poolA;
     unsigned long long* Pn = L.poolB;
@@ -578,6 +591,24 @@ __device__ __forceinline__ float ordered_sum(const float* arr, int cnt)
     return acc;
 }
 
+// pm_error_index2 behind a successful match (FMatch, :105), once per pair and out of line: one more projection and the
+// two ordered sums.  Its own function so that the second inlined copy of scan_project (with its constants) does not
+// lengthen the live ranges of the matcher's main loop; the dynamic LDS block is the kernel's (same layout).
+template <int NC>
+__device__ __noinline__ void icp_error_tail(DevParam P, const float* g_ref_row, const float* g_act_row, float ex, float ey, float eth,
+                                            float* exy, int* n_assoc)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (NC > 0) P.n = NC;
+    const int N = P.n;
+    Lds L = carve_icp(smem, N);
+    L.g_act_r = g_act_row; L.g_ref_r = g_ref_row;
+    for (int i = threadIdx.x; i < N; i += ICP_THREADS) L.ref_r[i] = g_ref_row[i];      // ref_xy is no longer needed
+    __syncthreads();
+    scan_project(P, L, ex, ey, eth);
+    error_index2_tail(P, L, exy, n_assoc);
+}
+
 // ---------------------------------------------------------------------------
 #ifndef LSA_ICP_WG_PER_CU
 #define LSA_ICP_WG_PER_CU 6
@@ -631,15 +662,25 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
             }
         }
         if (tid == 0) { L.good[((N + 63) & ~63) >> 5] = 0; L.pair_mask[((N + 63) & ~63) >> 5] = 0; }   // spare words
-        float ax, ay, ath;
-        rel_pose(init_pose ? init_pose + 6 * (size_t)b : nullptr, ax, ay, ath);
-        const float ax0 = init_pose ? init_pose[6 * (size_t)b + 3] : 0.0f;
-        const float ay0 = init_pose ? init_pose[6 * (size_t)b + 4] : 0.0f;
-        const float ath0 = init_pose ? init_pose[6 * (size_t)b + 5] : 0.0f;
-        float dx = 0, dy = 0, dth = 0;
+        // The pair's pose state lives in the broadcast slots, not in registers: one lane writes it, every phase reads what it
+        // needs (LDS broadcast reads), and nothing uniform is carried in vector registers across the phases.
+        //   PS_DX..PS_DTH  last update          PS_AX, PS_AY, PS_ATH  pose of the coming iteration, PS_CO / PS_SI its cos / sin (:1753-1754)
+        //   PS_PAX.. PS_PSI  frame of the last completed iteration (what :2015-2020 evaluates the residuals in)
+        enum { PS_DX = 8, PS_DY = 9, PS_DTH = 10, PS_ATH = 11, PS_CO = 12, PS_SI = 13, PS_AX = 14, PS_AY = 15,
+               PS_PAX = 16, PS_PAY = 17, PS_PCO = 18, PS_PSI = 19 };
+        if (tid == 0) {
+            float ax = 0.0f, ay = 0.0f, ath = 0.0f;
+            if (init_pose) {
+                const float* ip = init_pose + 6 * (size_t)b;
+                const float4 q = rel_pose_cold(ip[0], ip[1], ip[2], ip[3], ip[4], ip[5]);
+                ax = q.x; ay = q.y; ath = q.z;
+            }
+            fmisc[PS_DX] = 0.0f; fmisc[PS_DY] = 0.0f; fmisc[PS_DTH] = 0.0f;
+            fmisc[PS_AX] = ax; fmisc[PS_AY] = ay; fmisc[PS_ATH] = ath;
+            fmisc[PS_CO] = cosf_(ath); fmisc[PS_SI] = sinf_(ath);
+            fmisc[PS_PAX] = 0.0f; fmisc[PS_PAY] = 0.0f; fmisc[PS_PCO] = 1.0f; fmisc[PS_PSI] = 0.0f;
+        }
         int small = 0, status = LSA_ST_OK, n = 0, drop = 0, keep = 0;
-        float nco = cosf_(ath), nsi = sinf_(ath);       // :1753-1754 for the coming iteration, refreshed with every pose update
-        float co = 1.0f, si = 0.0f, pax = 0.0f, pay = 0.0f;
         uint32_t jpk0 = 0, jpk1 = 0, jpk2 = 0;           // last matches (+1, 0 = none) of this thread's up to six beams, u16 pairs
         __syncthreads();
 #ifdef LSA_PHASE_STAMPS
@@ -649,11 +690,10 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
 
         int iter = -1;
         while (++iter < LSA_ITER_ICP && small < 3) {
-            if (((double)(fabsf_(dx) + fabsf_(dy)) + (double)fabsf_(dth) * LSA_ZR2D) < LSA_STOP_ICP) small++;
+            if (((double)(fabsf_(fmisc[PS_DX]) + fabsf_(fmisc[PS_DY])) + (double)fabsf_(fmisc[PS_DTH]) * LSA_ZR2D) < LSA_STOP_ICP) small++;
             else small = 0;                                                     // :1728
 
-            co = nco; si = nsi;
-            scan_project(P, L, ax, ay, ath);                                    // flags only, :1750
+            scan_project(P, L, fmisc[PS_AX], fmisc[PS_AY], fmisc[PS_ATH]);      // flags only, :1750
             STAMP(0);
 #ifdef LSA_PHASE_STAMPS
             t_sub = t_last;
@@ -663,6 +703,7 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
                 // this wave's beams, 64 at a time; last iteration's matches (the seeds) live in registers
                 const float inv_dfi = 1.0f / P.dfi;
                 const float T = 6.2831853f * inv_dfi;                 // one turn in rays
+                const float co = fmisc[PS_CO], si = fmisc[PS_SI], ax = fmisc[PS_AX], ay = fmisc[PS_AY];
                 for (int base = wave * WAVE, trip = 0; base < N; base += ICP_THREADS, ++trip) {
                     const int i0 = base + lane;
                     const bool lv0 = i0 < N && key_bad(L.key[i0 < N ? i0 : 0]) == 0;
@@ -734,6 +775,7 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
                     }
                 }
                 __syncthreads();
+                const float co = fmisc[PS_CO], si = fmisc[PS_SI], ax = fmisc[PS_AX], ay = fmisc[PS_AY];
                 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int k = k0 + u * ICP_THREADS + tid;
@@ -765,24 +807,21 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
             if (wave == sw) {
                 const float sum = lane < 4 ? ordered_sum(my_list, keep) : 0.0f;
                 const float sxx = bcast_f(sum, 0), sxy = bcast_f(sum, 1), syx = bcast_f(sum, 2), syy = bcast_f(sum, 3);
+                const float ax = fmisc[PS_AX], ay = fmisc[PS_AY], ath = fmisc[PS_ATH];
                 const float ndth = atan2f_(sxy - syx, sxx + syy);                // :1984
                 const float cd = cosf_(ndth), sd = sinf_(ndth);
                 const float ndx = mqx - ax - (cd * (mpx - ax) - sd * (mpy - ay));
                 const float ndy = mqy - ay - (sd * (mpx - ax) + cd * (mpy - ay));
                 const float nath = norm_a(ath + ndth);
                 if (lane == 0) {
-                    fmisc[8] = ndx; fmisc[9] = ndy; fmisc[10] = ndth; fmisc[11] = nath;
-                    fmisc[12] = cosf_(nath); fmisc[13] = sinf_(nath);
+                    fmisc[PS_PAX] = ax; fmisc[PS_PAY] = ay; fmisc[PS_PCO] = fmisc[PS_CO]; fmisc[PS_PSI] = fmisc[PS_SI];
+                    fmisc[PS_DX] = ndx; fmisc[PS_DY] = ndy; fmisc[PS_DTH] = ndth;
+                    fmisc[PS_AX] = ax + ndx; fmisc[PS_AY] = ay + ndy; fmisc[PS_ATH] = nath;      // :1993-1996
+                    fmisc[PS_CO] = cosf_(nath); fmisc[PS_SI] = sinf_(nath);
                 }
             }
             __syncthreads();
             STAMP(6);
-            dx = fmisc[8]; dy = fmisc[9]; dth = fmisc[10];
-            pax = ax; pay = ay;          // (co, si, pax, pay): this iteration's frame, for :2015-2020
-            ax += dx;
-            ay += dy;
-            ath = fmisc[11];
-            nco = fmisc[12]; nsi = fmisc[13];
             STAMP(7);
         }
 #ifdef LSA_PHASE_STAMPS
@@ -795,7 +834,7 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
             float* resid = Lnx;                 // (the lists are dead by now)
             for (int k = tid; k < drop; k += ICP_THREADS) {
                 const uint32_t ij = L.first_ij[k];
-                const float2 p = cur_point(P, L.g_act_r, ij & 0xffff, co, si, pax, pay);
+                const float2 p = cur_point(P, L.g_act_r, ij & 0xffff, fmisc[PS_PCO], fmisc[PS_PSI], fmisc[PS_PAX], fmisc[PS_PAY]);
                 const float2 c = interp_candidate(P, L, N, p, ij >> 16);
                 resid[k] = sqrtf((p.x - c.x) * (p.x - c.x) + (p.y - c.y) * (p.y - c.y));
             }
@@ -806,11 +845,12 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
                 if (ret_out) ret_out[b] = acc / (float)drop;
             }
         } else if (tid == 0 && ret_out) ret_out[b] = 0.0f;
+        const float ax = fmisc[PS_AX], ay = fmisc[PS_AY], ath = fmisc[PS_ATH];
         if (tid == 0) {
             const bool ok = status == LSA_ST_OK;
-            pose_out[3 * (size_t)b + 0] = ok ? ax : ax0;       // lsa untouched on throw
-            pose_out[3 * (size_t)b + 1] = ok ? ay : ay0;
-            pose_out[3 * (size_t)b + 2] = ok ? ath : ath0;
+            pose_out[3 * (size_t)b + 0] = ok ? ax : (init_pose ? init_pose[6 * (size_t)b + 3] : 0.0f);       // lsa untouched on throw
+            pose_out[3 * (size_t)b + 1] = ok ? ay : (init_pose ? init_pose[6 * (size_t)b + 4] : 0.0f);
+            pose_out[3 * (size_t)b + 2] = ok ? ath : (init_pose ? init_pose[6 * (size_t)b + 5] : 0.0f);
             if (status_out) status_out[b] = status;
             if (iters_out) iters_out[b] = iter;
         }
@@ -818,15 +858,12 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
             __syncthreads();
             if (status == LSA_ST_OK) {
                 // pm_error_index2 at the result (FMatch, :105): ref at its pose, cur at (ax,ay,ath)
-                for (int i = tid; i < N; i += ICP_THREADS) L.ref_r[i] = g_r[ro + i];   // ref_xy no longer needed
                 float ex, ey, eth;
                 if (init_pose) {
-                    float ip[6] = {init_pose[6 * (size_t)b], init_pose[6 * (size_t)b + 1], init_pose[6 * (size_t)b + 2], ax, ay, ath};
-                    rel_pose(ip, ex, ey, eth);
+                    const float4 q = rel_pose_cold(init_pose[6 * (size_t)b], init_pose[6 * (size_t)b + 1], init_pose[6 * (size_t)b + 2], ax, ay, ath);
+                    ex = q.x; ey = q.y; eth = q.z;
                 } else { ex = ax; ey = ay; eth = ath; }
-                __syncthreads();
-                scan_project(P, L, ex, ey, eth);
-                error_index2_tail(P, L, err_xy + 2 * (size_t)b, n_assoc ? n_assoc + b : nullptr);
+                icp_error_tail<NC>(P, g_r + ro, g_r + ao, ex, ey, eth, err_xy + 2 * (size_t)b, n_assoc ? n_assoc + b : nullptr);
             } else if (tid < 2) {
                 err_xy[2 * (size_t)b + tid] = -1.0f;
                 if (tid == 0 && n_assoc) n_assoc[b] = 0;

@@ -199,6 +199,17 @@ __device__ __forceinline__ void rel_pose(const float* ip, float& ax, float& ay, 
     ath = th - rth;
 }
 
+// The same out of line, once per pair (pm_icp's set-up and the error index behind it): the six inlined sine / cosine
+// evaluations with their constants would otherwise sit in the matcher's main function, whose scalar registers are
+// oversubscribed as it is.  Returned by value (x, y, theta, -): a noinline function's reference outputs live in scratch.
+__device__ __noinline__ float4 rel_pose_cold(float rx, float ry, float rth, float x, float y, float th)
+{
+    const float ip[6] = {rx, ry, rth, x, y, th};
+    float ax, ay, ath;
+    rel_pose(ip, ax, ay, ath);
+    return make_float4(ax, ay, ath, 0.0f);
+}
+
 // norm_a, ZHPolar_Match.h:77-87 (sic)
 __device__ __forceinline__ float norm_a(float a)
 {
