@@ -75,16 +75,7 @@ static lsa::DevParam dev_param(const lsa_ctx* c)
     return P;
 }
 
-#ifdef LSA_LDS_PAD      // diagnostics: extra dynamic LDS to lower the number of resident workgroups per CU
-static int icp_lds(int n)
-{
-    static bool once = false;
-    if (!once) { once = true; (void)hipFuncSetAttribute((const void*)lsa::icp_kernel<1081>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
-    return lsa::icp_lds_bytes(n) + (LSA_LDS_PAD);
-}
-#else
 static int icp_lds(int n) { return lsa::icp_lds_bytes(n); }
-#endif
 static int psm_lds(int n) { return lsa::psm_lds_bytes(n); }
 static int pre_lds(int n) { int Np = (n + 63) & ~63; return 12 * Np; }
 
@@ -124,16 +115,6 @@ int lsa_debug_grid_cycles(unsigned long long* out16)
 }
 #endif
 
-#ifdef LSA_NN_STATS
-int lsa_debug_nn_stats(unsigned long long* out8 /* 24 entries */)
-{
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(lsa::lsa_nn_stats), sizeof(unsigned long long) * 24));
-    unsigned long long z[24] = {0};
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lsa::lsa_nn_stats), z, sizeof z));
-    return LSA_OK;
-}
-#endif
 
 #ifdef LSA_PLICP_STAMPS
 int lsa_debug_plicp_cycles(unsigned long long* out8)

@@ -397,11 +397,7 @@ __device__ __forceinline__ void own_walk(const GridParam& G, uint32_t* lh, uint3
         bool ok = (unsigned)(minor - N0) < (unsigned)OWN_T && cc != robot_cc;
         if (!inside) ok = ok && inb(G, x_major ? m0 + t : minor, x_major ? minor : m0 + t);
         if (ok) {
-#ifdef LSA_GRID_DIAG_NOCONFLICT        // diagnostics (wrong counts): what same-address LDS adds cost
-            atomicAdd(&ls[(cc + (int)(threadIdx.x & 63) * 67) & (OWN_T * OWN_T - 1)], 1u);
-#else
             atomicAdd(&ls[cc], 1u);                                                      // :87
-#endif
             if (t == len) atomicAdd(&lh[cc], 1u);                                        // last generated cell, :84-86
         }
         cc += c_major;
@@ -672,14 +668,6 @@ __device__ __forceinline__ void bin_walk(uint32_t* lt, int X0, int Y0, int X1, i
     int d = (int)(2ll * dmin * (t_lo + 1) - len - 2ll * len * steps);                   // |d| <= 2 len
     int cc = x_major ? (m0 + t_lo - X0) * BIN_T + (minor - Y0) : (minor - X0) * BIN_T + (m0 + t_lo - Y0);
     int n = t_hi - t_lo + 1;
-#if defined(LSA_GRID_STAMPS) && defined(LSA_GRID_STATS)
-    {
-        int mx = n;
-        for (int o = 32; o; o >>= 1) { const int v = __shfl_xor(mx, o); mx = v > mx ? v : mx; }      // (inactive lanes: stale values, close enough for a diagnostic)
-        atomicAdd(&lsa_grid_cycles[10], (unsigned long long)n);
-        if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) { atomicAdd(&lsa_grid_cycles[11], (unsigned long long)mx); atomicAdd(&lsa_grid_cycles[13], 1ull); }
-    }
-#endif
     // Neighbouring beams run through the same cells while they are close to the robot, and 64 adds of one wave
     // instruction to one LDS address are executed one after the other (measured: half of this kernel's time).
     // The lanes are in bearing order, so equal cells sit in runs of adjacent lanes: the first lane of a run adds
@@ -689,15 +677,6 @@ __device__ __forceinline__ void bin_walk(uint32_t* lt, int X0, int Y0, int X1, i
     const int lane = (int)(threadIdx.x & 63);
     const uint32_t sentinel = 0x80000000u >> (lane & 31);
     do {
-#if defined(LSA_GRID_DIAG_STORE)            // diagnostics (wrong counts): what the LDS adds cost
-        lt[cc] = 1u;
-#elif defined(LSA_GRID_DIAG_SPREAD)
-        atomicAdd(&lt[(cc + (int)(threadIdx.x & 63) * 67) & (BIN_T * BIN_T - 1)], 1u);
-#elif defined(LSA_GRID_DIAG_NOADD)
-        asm volatile("" :: "v"(cc));
-#elif defined(LSA_GRID_DIAG_PLAIN)
-        atomicAdd(&lt[cc], 1u);
-#else
         const int prev = __builtin_amdgcn_update_dpp(-2, cc, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // lane 0 / idle neighbour: -2
         const unsigned long long act = __ballot(1);
         const unsigned long long heads = __ballot(cc != prev) | ~act | 0x100000001ull;   // run starts, idle lanes, lanes 0 and 32
@@ -705,7 +684,6 @@ __device__ __forceinline__ void bin_walk(uint32_t* lt, int X0, int Y0, int X1, i
             const uint32_t h = lane < 32 ? (uint32_t)heads : (uint32_t)(heads >> 32);
             atomicAdd(&lt[cc], (uint32_t)__ffs((int)((h >> 1 >> (lane & 31)) | sentinel)));   // distance to the next run start above
         }
-#endif
         const bool keep = d < 0;
         cc += keep ? c_major : c_major + c_minor;
         d += keep ? inc_keep : inc_step;

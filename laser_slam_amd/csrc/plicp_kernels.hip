@@ -176,7 +176,6 @@ __device__ bool plicp_quartic_largest_root(double a3, double a2, double a1, doub
 __device__ bool plicp_gpm_multiplier(double trS, double detS, double hh, double hah, double aa, double& root)
 {
     const double a3 = 2 * trS, a2 = trS * trS + 2 * detS - hh, a1 = 2 * trS * detS - 2 * hah, a0 = detS * detS - aa;
-#ifndef LSA_PLICP_DIAG_QUARTIC
     const double disc = trS * trS * 0.25 - detS;
     const double lo = -(trS * 0.5 - sqrt(disc > 0 ? disc : 0));               // -s_min
     if (lo < 0) {
@@ -200,7 +199,6 @@ __device__ bool plicp_gpm_multiplier(double trS, double detS, double hh, double 
             if (isfinite(l) && fabs(p) <= 1e-6 * (1 + m * (1 + fabs(l)) * (1 + l * l))) { root = l; return true; }
         }
     }
-#endif
     return plicp_quartic_largest_root(a3, a2, a1, a0, root);
 }
 
@@ -273,18 +271,11 @@ __device__ __forceinline__ int plicp_correspondences(const PlicpParam& P, const 
                 const float tq = sqrtf((float)bound) * 1.0001f / rho_f;
                 const int M = tq < 1.0f ? (int)((tq + 0.5708f * tq * tq * tq) / P.dfi) + 5 : n;      // asin t <= t + (pi/2 - 1) t^3
                 fast = M + 8 <= range_min;
-#ifdef LSA_PLICP_DIAG_FULLSCAN          // diagnostic build only: the reference's whole window, no pruning
-                fast = false;
-#endif
                 lo0 = c0f - M > 0 ? c0f - M : 0; hi0 = c0f + M < n - 1 ? c0f + M : n - 1;
                 // (Scanning in rings outwards from the bearing with a half width that shrinks as closer points
                 //  turn up was measured slower than this one ascending scan from the seeds' bound.)
             }
-#ifdef LSA_PLICP_DIAG_NOSLOW
-            if (false) {
-#else
             if (!fast) {
-#endif
                 const double rho = sqrt(wx * wx + wy * wy);
                 const double phi = atan2(wy, wx);
                 const double delta = fabs(P.max_angular_correction_deg * (PI / 180.0)) + fabs(atan(P.max_linear_correction / rho));
@@ -301,11 +292,7 @@ __device__ __forceinline__ int plicp_correspondences(const PlicpParam& P, const 
                 if (prev >= from && prev <= to && L.rx[prev] < 1e100) { const double d = plicp_dist2(wx, wy, L.rx[prev], L.ry[prev]); bound = d < bound ? d : bound; }
                 const double sb = sqrt(bound) * (1.0 + 1e-9) + 1e-12;
                 lo0 = from; hi0 = to;
-#ifdef LSA_PLICP_DIAG_FULLSCAN
-                if (false) {
-#else
                 if (sb < rho) {
-#endif
                     const double tq = sb / rho;                                      // asin t <= t + (pi/2 - 1) t^3 on [0, 1]
                     const int M = (int)((tq + 0.5708 * tq * tq * tq) / (double)P.dfi) + 3;   // bearings are float(fi_min + dfi j): margin
                     const int T = (int)rint(2 * PI / (double)P.dfi);
@@ -318,21 +305,11 @@ __device__ __forceinline__ int plicp_correspondences(const PlicpParam& P, const 
                     nseg = 3;
                 }
             }
-#ifdef LSA_PLICP_COUNTS
-            {
-                const int cand = (hi0 >= lo0 ? hi0 - lo0 + 1 : 0) + (hi1 >= lo1 ? hi1 - lo1 + 1 : 0) + (hi2 >= lo2 ? hi2 - lo2 + 1 : 0);
-                atomicAdd(&lsa_plicp_cycles[6], fast ? 0ull : (nseg == 3 ? 1ull : 1ull << 20));          // slow bounded | slow unbounded << 20
-                atomicAdd(&lsa_plicp_cycles[7], (unsigned long long)cand | ((unsigned long long)(cand > 64) << 32));
-            }
-#endif
             PSTAMP(6);
             for (int sg = 0; sg < nseg; ++sg) {
                 const int a = sg == 0 ? lo0 : sg == 1 ? lo1 : lo2, e = sg == 0 ? hi0 : sg == 1 ? hi1 : hi2;
                 // (invalid reference rays carry coordinates of 1e150: their distance exceeds every limit)
                 int j = a;
-#ifdef LSA_PLICP_DIAG_NOSCAN
-                j = e + 1;
-#endif
                 for (; j + 3 <= e; j += 4) {
                     const double d0 = plicp_dist2(wx, wy, L.rx[j], L.ry[j]), d1 = plicp_dist2(wx, wy, L.rx[j + 1], L.ry[j + 1]);
                     const double d2 = plicp_dist2(wx, wy, L.rx[j + 2], L.ry[j + 2]), d3 = plicp_dist2(wx, wy, L.rx[j + 3], L.ry[j + 3]);
@@ -467,11 +444,7 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
                 const double ah0 = S11 * h0 - S01 * h1, ah1 = -S10 * h0 + S00 * h1;
                 const double hh = h0 * h0 + h1 * h1, hah = h0 * ah0 + h1 * ah1, aa = ah0 * ah0 + ah1 * ah1;
                 double l;
-#ifdef LSA_PLICP_DIAG_L0                 // diagnostics (wrong poses): what the multiplier costs
-                l = 0; solved = hh + hah + aa == hh + hah + aa;
-#else
                 solved = plicp_gpm_multiplier(trS, detS, hh, hah, aa, l);
-#endif
                 if (solved) {
                     const double det = l * l + trS * l + detS;
                     solved = fabs(det) > 1e-300;

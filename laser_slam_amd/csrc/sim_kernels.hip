@@ -54,15 +54,11 @@ __device__ __forceinline__ int sim_idx1(float r, float off, int center, double r
 // of its instructions in the two double divisions per step otherwise.)
 __device__ __forceinline__ int sim_idx1_fast(float r, float off, int center, double res, double inv_res)
 {
-#ifdef LSA_SIM_EXACT_DIV
-    return sim_idx1(r, off, center, res);
-#else
     const double t = (double)(r - off) + 0.0005;
     const double v = (double)center + t * inv_res;
     const double f = v - floor(v);
     if (__builtin_expect(!(f > 1e-6 && f < 1.0 - 1e-6), 0)) return (int)((double)center + t / res);
     return (int)v;
-#endif
 }
 
 // class of a cell value: bit 0 = the march stops here (!(occ < thr_free), :59), bit 1 = unknown (:60, :66)
