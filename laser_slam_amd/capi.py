@@ -40,6 +40,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch carries its own HIP runtime; when both live in one process it has to be loaded first, or this library's
+    # runtime comes up without a device.  (The binding is test and bench plumbing: those processes use torch tensors.)
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(LIB_PATH):
         raise LsaError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
     L = C.CDLL(LIB_PATH)
