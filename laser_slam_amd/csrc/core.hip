@@ -151,6 +151,18 @@ int lsa_debug_bad_index(unsigned int* out4)
 }
 #endif
 
+#ifdef LSA_ORIENT_STATS
+// diagnostic build only: read and reset the counters of the bounded orientation search
+int lsa_debug_orient_stats(unsigned long long* out8)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(lsa::lsa_orient_stats), sizeof(unsigned long long) * 8));
+    unsigned long long z[8] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lsa::lsa_orient_stats), z, sizeof z));
+    return LSA_OK;
+}
+#endif
+
 const char* lsa_version(void) { return "laser_slam_amd 0.2 (gfx950)"; }
 
 const char* lsa_last_error(void) { return g_err.c_str(); }
@@ -483,7 +495,7 @@ int lsa_match_batch(lsa_ctx* c, int which, int B,
 #undef LSA_LAUNCH_ICP
     } else
     {
-#define LSA_LAUNCH_PSM(NC) hipLaunchKernelGGL(lsa::psm_kernel<NC>, dim3(B), dim3(lsa::PSM_THREADS), lsa::psm_compact_lds_bytes(P.n), c->stream, P, B, \
+#define LSA_LAUNCH_PSM(NC) hipLaunchKernelGGL(lsa::psm_kernel<NC>, dim3(B), dim3(lsa::PSM_THREADS), lsa::psm_compact_lds_bytes(P.n, P.window), c->stream, P, B, \
                            d_r, d_bad, d_seg, d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters)
         switch (P.n) {
         case 181:  LSA_LAUNCH_PSM(181); break;

@@ -249,7 +249,7 @@ __device__ void error_index2_tail(const DevParam& P, const Lds& L, float* exy, i
         const float* tab = lane == 0 ? P.co : P.si;
         for (int i = 0; i < N; ++i) {
             unsigned long long k = L.key[i];
-            float rr = L.ref_r[i];
+            float rr = L.ref_r ? L.ref_r[i] : L.g_ref_r[i];
             float delta = (float)((double)fabsf_(key_r(k) - rr) * 0.01);
             if (key_bad(k) == 0 && !ref_is_bad(L, i) && (double)delta < 50.0 && delta < 1.0f) {
                 float a = delta * tab[i];

@@ -10,14 +10,14 @@
 //   translation estimation (:1015-1131): per-beam terms in parallel, six ordered sums in
 //     six lanes.
 //
-// LDS of psm_kernel (Np = N rounded up to 64; 28 Np bytes + 64 + bit masks = 31.0 KiB at N = 1081
-// -> 5 pairs per CU; the stand-alone stage kernels keep the 35 Np byte-flag layout of carve_psm):
-//   [ 0, 4) ref_r   [ 4,20) projection scratch (pr, pf, u64 keys)
-//                           -> NaN-masked rows for the orientation search
-//                           -> translation terms 0..3
-//   [20,24) new_r -> |dr| term   [24,28) err[2W+1] -> term 4
+// LDS of psm_kernel (Np = N rounded up to 64): four float rows, 16 Np bytes + 64 + bit masks = 17.9 KiB at
+// N = 1081 -> 8 pairs per CU (the stand-alone stage kernels keep the 35 Np byte-flag layout of carve_psm):
+//   row A  [ 0, 4)  projected range pr -> new_r (unpacked from the keys) -> NaN-masked new_r of the search
+//   rows B-D [ 4,16) pf | u64 keys  -> NaN-masked, W-padded reference row + err[2W+1] of the search
+//                                   -> six term rows of half a scan each (translation, two passes)
 //   broadcast slots (64 B), validity masks of the orientation search, then one bit per beam for
-//   ref_bad / pair_ok / new_bad.  The current scan's ranges are read from HBM/L2.
+//   ref_bad / pair_ok / new_bad.  Both scans' ranges are read from HBM/L2 where they are needed (the current
+//   scan once per projection, the reference scan once per search / translation step).
 
 constexpr int PSM_THREADS = 256;
 
@@ -30,27 +30,36 @@ __host__ __device__ inline int psm_scratch_bytes(int Np) { return 64 + 4 * ((psm
 __host__ __device__ inline int psm_lds_bytes(int n) { int Np = (n + 63) & ~63; return 35 * Np + psm_scratch_bytes(Np); }
 // compact layout of psm_kernel
 __host__ __device__ inline int psm_flag_mask_bytes(int Np) { return (Np / 8 + 8 + 15) & ~15; }
-__host__ __device__ inline int psm_compact_lds_bytes(int n)
+// floats of the padded reference row of the orientation search, and of the rows B-D (the reference row and the
+// 2W + 1 errors behind it; three rows unless the window is close to half the scan)
+__host__ __device__ inline int psm_ref_row_floats(int n, int W) { return (n + 2 * W + 4 + 63) & ~63; }
+__host__ __device__ inline int psm_compact_bcd_floats(int n, int W)
+{
+    int Np = (n + 63) & ~63, need = psm_ref_row_floats(n, W) + ((2 * W + 1 + 63) & ~63);
+    return need > 3 * Np ? need : 3 * Np;
+}
+__host__ __device__ inline int psm_compact_lds_bytes(int n, int W)
 {
     int Np = (n + 63) & ~63;
-    return 28 * Np + psm_scratch_bytes(Np) + 3 * psm_flag_mask_bytes(Np);
+    return 4 * Np + 4 * psm_compact_bcd_floats(n, W) + psm_scratch_bytes(Np) + 3 * psm_flag_mask_bytes(Np);
 }
-__device__ __forceinline__ Lds carve_psm_compact(char* base, int Np, float*& bc)
+__device__ __forceinline__ Lds carve_psm_compact(char* base, int Np, int bcd_floats, float*& bc)
 {
     Lds L = {};
-    L.ref_r = (float*)base;
-    L.pr = (float*)(base + 4 * Np);
-    L.pf = (float*)(base + 8 * Np);
-    L.key = (unsigned long long*)(base + 12 * Np);
-    L.new_r = (float*)(base + 20 * Np);
-    L.err = (float*)(base + 24 * Np);
-    bc = (float*)(base + 28 * Np);
-    char* m = base + 28 * Np + psm_scratch_bytes(Np);
+    L.pr = (float*)base;
+    L.new_r = (float*)base;                         // the unpacked projection replaces pr
+    L.pf = (float*)(base + 4 * Np);
+    L.key = (unsigned long long*)(base + 8 * Np);
+    char* m = base + 4 * Np + 4 * bcd_floats;
+    bc = (float*)m;
+    m += psm_scratch_bytes(Np);
     L.good = (uint32_t*)m;
     L.pair_mask = (uint32_t*)(m + psm_flag_mask_bytes(Np));
     L.new_mask = (uint32_t*)(m + 2 * psm_flag_mask_bytes(Np));
-    return L;                       // act_r, ref_bad, pair_ok, new_bad stay null: HBM / bit masks
+    return L;                       // ref_r, act_r, err, ref_bad, pair_ok, new_bad stay null: HBM / bit masks
 }
+// the reference scan's ranges: LDS row of the byte-flag layout, HBM/L2 in the compact one
+__device__ __forceinline__ float ref_range(const Lds& L, int i) { return L.ref_r ? L.ref_r[i] : L.g_ref_r[i]; }
 
 // NaN-masked rows: nrm[i] = new_r or NaN; rfm[W + j] = ref_r[j] or NaN, NaN outside [0,N); and the
 // same validity as bit masks (newm bit i, refm bit j of the padded row), built with ballots.  Both
@@ -68,11 +77,11 @@ __device__ __forceinline__ void build_masked_rows(const DevParam& P, const Lds& 
         const unsigned long long m = __ballot(ok);
         if (lane0) { newm[i >> 5] = (uint32_t)m; newm[(i >> 5) + 1] = (uint32_t)(m >> 32); }
     }
-    const int Jp = (N + 2 * W + 4 + 63) & ~63;                 // <= 2 Np + 64 <= 3 Np floats: pf row + key rows
+    const int Jp = psm_ref_row_floats(N, W);                   // pf row + key rows
     for (int j = threadIdx.x; j < Jp; j += blockDim.x) {
         const int src = j - W;
         const bool ok = src >= 0 && src < N && !ref_is_bad(L, src);
-        rfm[j] = ok ? L.ref_r[src] : qnan;
+        rfm[j] = ok ? ref_range(L, src) : qnan;
         const unsigned long long m = __ballot(ok);
         if (lane0) { refm[j >> 5] = (uint32_t)m; refm[(j >> 5) + 1] = (uint32_t)(m >> 32); }
     }
@@ -90,54 +99,118 @@ __device__ __forceinline__ void orient_quad(float& e, const float4 a, const floa
     e += fmaxf(fabsf_(a.w - b3), 0.0f);
 }
 
+#ifdef LSA_ORIENT_STATS
+__device__ unsigned long long lsa_orient_stats[8];   // searches, bounded blocks, abandoned, chunks run, chunks possible, refits
+#endif
+// number of valid terms of shift k: popcount of the new scan's mask against the reference mask moved by k
+__device__ __forceinline__ int orient_count(const uint32_t* newm, const uint32_t* refm, int nw, int k)
+{
+    int c = 0;
+    for (int w = 0; w < nw; ++w) {
+        const int j = 32 * w + k;
+        c += __popc(newm[w] & __builtin_amdgcn_alignbit(refm[(j >> 5) + 1], refm[j >> 5], (uint32_t)j & 31u));
+    }
+    return c;
+}
+
+// Ordered sum of one shift per lane (rb = rfm + k).  The sum only grows (non-negative terms, FP32 addition
+// is monotone), so once it exceeds `lim` in every lane of the wave the final values are known to exceed it
+// too and the wave stops: returns true (abandoned, e meaningless).  lim = +inf never abandons.
+template <bool BOUNDED>
+__device__ __forceinline__ bool orient_sum(const float* nrm, const float* rb, int N4, float lim, float& e)
+{
+    e = 0.0f;
+#ifdef LSA_ORIENT_STATS
+    if (BOUNDED && lane_id() == 0) { atomicAdd(&lsa_orient_stats[1], 1ull); atomicAdd(&lsa_orient_stats[4], (unsigned long long)(N4 >> 4)); }
+#endif
+    const int N16 = N4 & ~15;
+    int i = 0;
+    for (; i < N16; i += 16) {
+        orient_quad(e, *(const float4*)(nrm + i), rb + i);
+        orient_quad(e, *(const float4*)(nrm + i + 4), rb + i + 4);
+        orient_quad(e, *(const float4*)(nrm + i + 8), rb + i + 8);
+        orient_quad(e, *(const float4*)(nrm + i + 12), rb + i + 12);
+#ifdef LSA_ORIENT_STATS
+        if (BOUNDED && lane_id() == 0) atomicAdd(&lsa_orient_stats[3], 1ull);
+        if (BOUNDED && !__ballot(e <= lim)) { if (lane_id() == 0) atomicAdd(&lsa_orient_stats[2], 1ull); return true; }
+#endif
+        if (BOUNDED && !__ballot(e <= lim)) return true;
+    }
+    for (; i < N4; i += 4) orient_quad(e, *(const float4*)(nrm + i), rb + i);
+    return false;
+}
+
+constexpr float ORIENT_ABANDONED = -1.0f;       // err[] entry of a shift whose sum was abandoned (errors are >= 0)
+
 // pm_orientation_search (:1152-1261) on L.new_r/new_bad vs L.ref_r/ref_bad.  Whole
 // workgroup; returns the status, dth by reference.  Uses pr/pf/key as scratch.
-// Thread t owns the shifts di = t - W and t + 256 - W (two independent ordered sums side by
-// side); the number of valid terms of a shift is the popcount of the two validity masks.
-__device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, float* bc)
+//
+// The reference evaluates all 2W + 1 shifts and takes the first strict minimum of the mean |dr|, then fits a
+// parabola through the minimum and its two neighbours.  Only those three values matter, so the shifts are
+// evaluated in blocks of 64 (one per lane) with a bound: wave 0 first evaluates the block centred on zero
+// shift completely; its minimum B bounds the global minimum from above.  The other blocks then stop as soon
+// as every lane's partial sum exceeds B n_k (1 + 1e-6) (n_k = number of valid terms, known from the masks
+// beforehand): the finished mean would be > B, so such a shift can neither be the minimum nor tie with it.
+// A block either runs to the end (all 64 values exact) or is abandoned as a whole; if a neighbour of the
+// minimum lies in an abandoned block it is evaluated again without a bound.  The values that reach the
+// arg-min and the parabola are therefore the reference's, bit for bit.
+__device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, float* bc, int turn = 0)
 {
     const int N = P.n, W = P.window, K = 2 * W + 1, tid = threadIdx.x, Np = (N + 63) & ~63;
     float* nrm = L.pr;                 // Np floats (the pr row)
     float* rfm = L.pf;                 // N + 2W + 4 (+ pad) floats (pf row + the key rows)
-    float* err = L.err;
+    float* err = L.err ? L.err : rfm + psm_ref_row_floats(N, W);
     uint32_t* newm = (uint32_t*)(bc + 16);
     uint32_t* refm = newm + psm_mask_words_new(Np);
     build_masked_rows(P, L, nrm, rfm, newm, refm);
     __syncthreads();
     const int N4 = (N + 3) & ~3, nw = (N + 31) >> 5;
-    for (int k0 = tid; k0 < K; k0 += 2 * blockDim.x) {
-        const int k1 = k0 + blockDim.x;
-        const bool has1 = k1 < K;
-        const float* rb0 = rfm + k0;                // rfm[W + i + di] with di = k - W
-        const float* rb1 = rfm + (has1 ? k1 : k0);
-        float e0 = 0.0f, e1 = 0.0f;
-        if (__ballot(has1)) {
-            for (int i = 0; i < N4; i += 4) {
-                const float4 a = *(const float4*)(nrm + i);
-                orient_quad(e0, a, rb0 + i);
-                orient_quad(e1, a, rb1 + i);
-            }
-        } else {
-            for (int i = 0; i < N4; i += 4) orient_quad(e0, *(const float4*)(nrm + i), rb0 + i);
-        }
-        int c0 = 0, c1 = 0;
-        for (int w = 0; w < nw; ++w) {
-            const uint32_t nm = newm[w];
-            const int j0 = 32 * w + k0, j1 = 32 * w + (has1 ? k1 : k0);
-            c0 += __popc(nm & __builtin_amdgcn_alignbit(refm[(j0 >> 5) + 1], refm[j0 >> 5], (uint32_t)j0 & 31u));
-            c1 += __popc(nm & __builtin_amdgcn_alignbit(refm[(j1 >> 5) + 1], refm[j1 >> 5], (uint32_t)j1 & 31u));
-        }
-        err[k0] = c0 > 0 ? e0 / (float)c0 : 10000.0f;                                 // :1203-1206
-        if (has1) err[k1] = c1 > 0 ? e1 / (float)c1 : 10000.0f;
+    // (`turn` rotates the roles of the waves: the long unbounded block should not always land on the same SIMD)
+    const int lane = lane_id(), nwaves = blockDim.x >> 6, wave = ((tid >> 6) + turn) % nwaves;
+    const int origin = W - 32;                                  // block m holds the shifts origin + 64 m + lane
+    const float inf = u2f(0x7f800000u);
+    if (wave == 0) {
+        const int k = origin + lane;
+        const bool in = k >= 0 && k < K;
+        const int kk = in ? k : W;
+        const int c = orient_count(newm, refm, nw, kk);
+        float e;
+        orient_sum<false>(nrm, rfm + kk, N4, inf, e);
+        const float er = c > 0 ? e / (float)c : 10000.0f;                             // :1203-1206
+        if (in) err[k] = er;
+        float b = in ? er : inf;
+        #pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) b = fminf(b, __shfl_xor(b, off));
+        if (lane == 0) bc[1] = b;
+    }
+    __syncthreads();
+    const float bound = bc[1];
+#ifdef LSA_ORIENT_STATS
+    if (tid == 0) atomicAdd(&lsa_orient_stats[0], 1ull);
+#endif
+    const int m_lo = origin > 0 ? -((origin + 63) >> 6) : 0, m_hi = (K - 1 - origin) >> 6;
+    const int rounds = 2 * (-m_lo > m_hi ? -m_lo : m_hi);
+    for (int j = wave; j < rounds; j += nwaves) {               // blocks -1, +1, -2, +2, ...: nearest (longest) first
+        const int m = (j & 1) ? (j >> 1) + 1 : -((j >> 1) + 1);
+        if (m < m_lo || m > m_hi) continue;
+        const int k = origin + 64 * m + lane;
+        const bool in = k >= 0 && k < K;
+        const int kk = in ? k : W;
+        const int c = orient_count(newm, refm, nw, kk);
+        // a shift without valid terms has err = 10000 > bound whenever bound < 10000; otherwise nothing is abandoned
+        const float lim = !(bound < 10000.0f) ? inf : (in && c > 0) ? bound * (float)c * 1.000001f : -1.0f;
+        float e;
+        const bool abandoned = orient_sum<true>(nrm, rfm + kk, N4, lim, e);
+        if (in) err[k] = abandoned ? ORIENT_ABANDONED : (c > 0 ? e / (float)c : 10000.0f);
     }
     __syncthreads();
     // first strict minimum (:1225-1234): arg-min on (err, k) by wave 0
-    if (tid < WAVE) {
+    if (wave == 0) {
         float bm = 100000.0f;
         int bk = -1;
-        for (int k = tid; k < K; k += WAVE) {
+        for (int k = lane; k < K; k += WAVE) {
             const float e = err[k];
-            if (e < bm) { bm = e; bk = k; }
+            if (e >= 0.0f && e < bm) { bm = e; bk = k; }
         }
         #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -146,13 +219,28 @@ __device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, f
             const bool take = (ok >= 0) && (bk < 0 || om < bm || (om == bm && ok < bk));
             if (take) { bm = om; bk = ok; }
         }
-        if (tid == 0) ((int*)bc)[0] = bk;
+        if (lane == 0) ((int*)bc)[0] = bk;
     }
     __syncthreads();
     const int imin = ((int*)bc)[0];
     if (imin < 0 || err[imin] >= 10000.0f) return LSA_ST_NO_ORIENT;                    // :1236-1240
     dth = (float)(imin - W) * P.dfi;                                                  // :1241
     if (imin >= 1 && imin < K - 1) {                                                  // :1244-1254
+        if (err[imin - 1] < 0.0f || err[imin + 1] < 0.0f) {     // neighbour in an abandoned block: evaluate it fully
+            __syncthreads();
+#ifdef LSA_ORIENT_STATS
+            if (tid == 0) atomicAdd(&lsa_orient_stats[5], 1ull);
+#endif
+            if (wave == 0) {
+                const int k = lane == 0 ? imin - 1 : imin + 1;
+                const bool need = lane < 2 && err[k] < 0.0f;
+                const int c = orient_count(newm, refm, nw, k);
+                float e;
+                orient_sum<false>(nrm, rfm + k, N4, inf, e);
+                if (need) err[k] = c > 0 ? e / (float)c : 10000.0f;
+            }
+            __syncthreads();
+        }
         const float em = err[imin - 1], e0 = err[imin], ep = err[imin + 1];
         const float D = (float)((double)(em + ep) - 2.0 * (double)e0);
         float d = 10000.0f;
@@ -162,33 +250,63 @@ __device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, f
     return LSA_ST_OK;
 }
 
-// pm_translation_estimation (:1015-1131) on L.new_r/new_bad vs L.ref_r/ref_bad.
+// ordered sum acc + arr[0] + arr[1] + ... + arr[cnt-1] (one lane; cnt a multiple of 16, loads software-pipelined)
+__device__ __forceinline__ float ordered_sum_onto(float acc, const float* arr, int cnt)
+{
+    const float4* v = (const float4*)arr;
+    const int nq = cnt >> 2;
+    float4 buf[4];
+    #pragma unroll
+    for (int u = 0; u < 4; ++u) buf[u] = v[u];
+    for (int qd = 0; qd < nq; qd += 4) {
+        float4 nxt[4];
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) nxt[u] = v[qd + 4 + u];      // runs one group past the row: inside the LDS block, unused
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) { acc += buf[u].x; acc += buf[u].y; acc += buf[u].z; acc += buf[u].w; }
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) buf[u] = nxt[u];
+    }
+    return acc;
+}
+
+// pm_translation_estimation (:1015-1131) on L.new_r/new_bad vs the reference scan.
 // Per-beam terms in parallel (zero when the beam is gated out: adding +0.0f leaves an
-// ordered FP32 sum unchanged), then six ordered sums.  Destroys new_r and err.
+// ordered FP32 sum unchanged), then six ordered sums by six lanes.  The terms of half a scan at a time fill
+// the rows B-D (six rows of Np / 2 floats, zero-padded), so the sums run in two legs; new_r is left alone.
 __device__ int translation_estimation(const DevParam& P, const Lds& L, float C, float& dx, float& dy, float& avg,
                                       float* bc)
 {
-    const int N = P.n, Np = (N + 63) & ~63, tid = threadIdx.x;
-    float* const term[6] = {L.pr, L.pf, (float*)L.key, (float*)L.key + Np, L.err, L.new_r};
+    const int N = P.n, Np = (N + 63) & ~63, H = Np >> 1, tid = threadIdx.x;
+    float* const rows = L.pf;
     int mine = 0;
-    for (int i = tid; i < Np; i += blockDim.x) {
-        float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
-        if (i < N) {
-            const float nr = L.new_r[i];
-            const float dr = L.ref_r[i] - nr;
-            const bool ok = !ref_is_bad(L, i) && !new_is_bad(L, i) && nr < (float)P.max_range &&
-                            nr > LSA_MIN_RANGE && fabsf_(dr) < LSA_MAX_ERROR;          // :1034
-            if (ok) {
-                const float w = C / (dr * dr + C);
-                const float c = P.co[i], s = P.si[i];
-                const float wc = c * w, ws = s * w;
-                t0 = wc * dr; t1 = ws * dr; t2 = wc * c; t3 = wc * s; t4 = ws * s;
-                mine++;
+    float acc = 0.0f;
+    for (int leg = 0; leg < 2; ++leg) {
+        for (int l = tid; l < H; l += blockDim.x) {
+            const int i = leg * H + l;
+            float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+            if (i < N) {
+                const float nr = L.new_r[i];
+                const float dr = ref_range(L, i) - nr;
+                const bool ok = !ref_is_bad(L, i) && !new_is_bad(L, i) && nr < (float)P.max_range &&
+                                nr > LSA_MIN_RANGE && fabsf_(dr) < LSA_MAX_ERROR;      // :1034
+                if (ok) {
+                    const float w = C / (dr * dr + C);
+                    const float c = P.co[i], s = P.si[i];
+                    const float wc = c * w, ws = s * w;
+                    t0 = wc * dr; t1 = ws * dr; t2 = wc * c; t3 = wc * s; t4 = ws * s;
+                    mine++;
+                }
+                t5 = fabsf_(dr);
             }
-            t5 = fabsf_(dr);
+            rows[l] = t0; rows[H + l] = t1; rows[2 * H + l] = t2; rows[3 * H + l] = t3; rows[4 * H + l] = t4;
+            rows[5 * H + l] = t5;
         }
-        term[0][i] = t0; term[1][i] = t1; term[2][i] = t2; term[3][i] = t3; term[4][i] = t4; term[5][i] = t5;
+        __syncthreads();
+        if (tid < 6) acc = ordered_sum_onto(acc, rows + tid * H, H);
+        if (leg == 0) __syncthreads();
     }
+    if (tid < 6) bc[tid] = acc;
     // number of gated-in beams
     const int wave = tid >> 6;
     int wsum = mine;
@@ -198,13 +316,6 @@ __device__ int translation_estimation(const DevParam& P, const Lds& L, float C, 
     __syncthreads();
     int cnt = 0;
     for (unsigned w = 0; w < (blockDim.x >> 6); ++w) cnt += ((int*)bc)[8 + w];
-    if (tid < 6) {
-        // (a select chain, not an indexed pointer table: keeps the LDS address space, i.e. ds_read)
-        const float* tp = tid == 0 ? term[0] : tid == 1 ? term[1] : tid == 2 ? term[2]
-                        : tid == 3 ? term[3] : tid == 4 ? term[4] : term[5];
-        bc[tid] = ordered_sum(tp, N);
-    }
-    __syncthreads();
     const float hw1 = bc[0], hw2 = bc[1], h11 = bc[2], h12 = bc[3], h22 = bc[4], abs_err = bc[5];
     __syncthreads();
     if (cnt < P.min_valid) return LSA_ST_FEW_POINTS;                                   // :1089
@@ -237,10 +348,10 @@ __device__ __forceinline__ void load_pair_psm(const DevParam& P, Lds& L, const f
 {
     const int N = P.n, Np = (N + 63) & ~63;
     L.g_act_r = g_r + ao;
+    L.g_ref_r = g_r + ro;
     for (int i = threadIdx.x; i < Np; i += blockDim.x) {
         bool good = false, ok = false;
         if (i < N) {
-            L.ref_r[i] = g_r[ro + i];
             good = g_bad[ro + i] == 0;
             if (i >= 1) {
                 uint16_t s1 = g_seg[ao + i], s0 = g_seg[ao + i - 1];
@@ -256,15 +367,12 @@ __device__ __forceinline__ void load_pair_psm(const DevParam& P, Lds& L, const f
 }
 
 #ifndef LSA_PSM_WG_PER_CU
-#define LSA_PSM_WG_PER_CU 5
+#define LSA_PSM_WG_PER_CU 8
 #endif
 // NC > 0: the beam count as a compile-time constant (see icp_kernel)
 template <int NC>
-// up to 541 beams the LDS leaves room for eight workgroups per CU (64 registers): 23-27 % faster than five there
-#ifndef LSA_PSM_WG_PER_CU_SMALL
-#define LSA_PSM_WG_PER_CU_SMALL 8
-#endif
-__global__ __launch_bounds__(PSM_THREADS, (NC > 0 && NC <= 541) ? (LSA_PSM_WG_PER_CU_SMALL) : (LSA_PSM_WG_PER_CU)) void psm_kernel(
+// eight workgroups per CU (64 registers; 17.9 KiB of LDS at 1081 beams)
+__global__ __launch_bounds__(PSM_THREADS, LSA_PSM_WG_PER_CU) void psm_kernel(
     DevParam P_, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
     const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
     const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
@@ -275,7 +383,7 @@ __global__ __launch_bounds__(PSM_THREADS, (NC > 0 && NC <= 541) ? (LSA_PSM_WG_PE
     if (NC > 0) P.n = NC;
     const int N = P.n, Np = (N + 63) & ~63, tid = threadIdx.x;
     float* bc;
-    Lds L = carve_psm_compact(smem, Np, bc);
+    Lds L = carve_psm_compact(smem, Np, psm_compact_bcd_floats(N, P.window), bc);
 
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const size_t ro = (size_t)ref_idx[b] * N, ao = (size_t)act_idx[b] * N;
@@ -297,7 +405,7 @@ __global__ __launch_bounds__(PSM_THREADS, (NC > 0 && NC <= 541) ? (LSA_PSM_WG_PE
             scan_project(P, L, ax, ay, ath);
             unpack_projection(P, L);
             if ((iter & 1) == 0) {
-                status = orientation_search(P, L, dth, bc);
+                status = orientation_search(P, L, dth, bc, b + (iter >> 1));
                 if (status) break;
                 ath += dth;
                 __syncthreads();
