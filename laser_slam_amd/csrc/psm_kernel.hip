@@ -89,14 +89,18 @@ __device__ __forceinline__ void build_masked_rows(const DevParam& P, const Lds& 
 
 // one beam quad of one shift: e += |a - b| for the valid terms, in beam order.  An invalid term is
 // NaN; fmaxf(NaN, 0) = 0, and adding +0 leaves the (non-negative) ordered sum unchanged.
-// (Packed v_pk_add_f32 over the two shifts of a thread was measured 8 % slower than the scalar form.)
-__device__ __forceinline__ void orient_quad(float& e, const float4 a, const float* rb)
+// The four differences are two packed subtractions (v_pk_add_f32: same IEEE result per half).
+#define LSA_LDS __attribute__((address_space(3)))
+typedef float packed2f __attribute__((ext_vector_type(2)));
+typedef float packed4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void orient_quad(float& e, const packed4f a, const LSA_LDS float* rb)
 {
-    const float b0 = rb[0], b1 = rb[1], b2 = rb[2], b3 = rb[3];
-    e += fmaxf(fabsf_(a.x - b0), 0.0f);
-    e += fmaxf(fabsf_(a.y - b1), 0.0f);
-    e += fmaxf(fabsf_(a.z - b2), 0.0f);
-    e += fmaxf(fabsf_(a.w - b3), 0.0f);
+    const packed2f a01 = {a.x, a.y}, a23 = {a.z, a.w}, b01 = {rb[0], rb[1]}, b23 = {rb[2], rb[3]};
+    const packed2f d01 = a01 - b01, d23 = a23 - b23;
+    e += fmaxf(fabsf_(d01.x), 0.0f);
+    e += fmaxf(fabsf_(d01.y), 0.0f);
+    e += fmaxf(fabsf_(d23.x), 0.0f);
+    e += fmaxf(fabsf_(d23.y), 0.0f);
 }
 
 #ifdef LSA_ORIENT_STATS
@@ -123,20 +127,26 @@ __device__ __forceinline__ bool orient_sum(const float* nrm, const float* rb, in
 #ifdef LSA_ORIENT_STATS
     if (BOUNDED && lane_id() == 0) { atomicAdd(&lsa_orient_stats[1], 1ull); atomicAdd(&lsa_orient_stats[4], (unsigned long long)(N4 >> 4)); }
 #endif
+    // the lane's row offset goes through an opaque register: the reads of a chunk then differ by immediate offsets
+    // only (folded into the row's constant LDS address they each cost an address addition)
+    uint32_t bo = (uint32_t)(uintptr_t)(const LSA_LDS float*)rb;
+    asm volatile("" : "+v"(bo));
+    const LSA_LDS float* b = (const LSA_LDS float*)(uintptr_t)bo;
+    const LSA_LDS packed4f* a = (const LSA_LDS packed4f*)nrm;
     const int N16 = N4 & ~15;
     int i = 0;
-    for (; i < N16; i += 16) {
-        orient_quad(e, *(const float4*)(nrm + i), rb + i);
-        orient_quad(e, *(const float4*)(nrm + i + 4), rb + i + 4);
-        orient_quad(e, *(const float4*)(nrm + i + 8), rb + i + 8);
-        orient_quad(e, *(const float4*)(nrm + i + 12), rb + i + 12);
+    for (; i < N16; i += 16, b += 16, a += 4) {
+        orient_quad(e, a[0], b);
+        orient_quad(e, a[1], b + 4);
+        orient_quad(e, a[2], b + 8);
+        orient_quad(e, a[3], b + 12);
 #ifdef LSA_ORIENT_STATS
         if (BOUNDED && lane_id() == 0) atomicAdd(&lsa_orient_stats[3], 1ull);
         if (BOUNDED && !__ballot(e <= lim)) { if (lane_id() == 0) atomicAdd(&lsa_orient_stats[2], 1ull); return true; }
 #endif
         if (BOUNDED && !__ballot(e <= lim)) return true;
     }
-    for (; i < N4; i += 4) orient_quad(e, *(const float4*)(nrm + i), rb + i);
+    for (; i < N4; i += 4, b += 4, a += 1) orient_quad(e, a[0], b);
     return false;
 }
 
@@ -183,6 +193,9 @@ __device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, f
         for (int off = 32; off >= 1; off >>= 1) b = fminf(b, __shfl_xor(b, off));
         if (lane == 0) bc[1] = b;
     }
+    int n_new = lane < nw ? __popc(newm[lane]) : 0;               // nw <= 64 (LSA_MAX_POINTS)
+    #pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) n_new += __shfl_xor(n_new, off);
     __syncthreads();
     const float bound = bc[1];
 #ifdef LSA_ORIENT_STATS
@@ -196,12 +209,20 @@ __device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, f
         const int k = origin + 64 * m + lane;
         const bool in = k >= 0 && k < K;
         const int kk = in ? k : W;
-        const int c = orient_count(newm, refm, nw, kk);
-        // a shift without valid terms has err = 10000 > bound whenever bound < 10000; otherwise nothing is abandoned
-        const float lim = !(bound < 10000.0f) ? inf : (in && c > 0) ? bound * (float)c * 1.000001f : -1.0f;
+        // abandoning needs only an upper bound of the number of valid terms (the new scan's valid readings, n_new):
+        // e > bound n_new (1 + 1e-6) >= bound c (1 + 1e-6).  A shift without valid terms has err = 10000 > bound
+        // whenever bound < 10000; otherwise nothing is abandoned.  The exact counts are taken for finished blocks only.
+#ifdef LSA_ORIENT_EXACT_COUNT
+        const int c0 = orient_count(newm, refm, nw, kk);
+        const float lim = !(bound < 10000.0f) ? inf : (in && c0 > 0) ? bound * (float)c0 * 1.000001f : -1.0f;
+#else
+        const float lim = !(bound < 10000.0f) ? inf : in ? bound * (float)n_new * 1.000001f : -1.0f;
+#endif
         float e;
         const bool abandoned = orient_sum<true>(nrm, rfm + kk, N4, lim, e);
-        if (in) err[k] = abandoned ? ORIENT_ABANDONED : (c > 0 ? e / (float)c : 10000.0f);
+        if (abandoned) { if (in) err[k] = ORIENT_ABANDONED; continue; }
+        const int c = orient_count(newm, refm, nw, kk);
+        if (in) err[k] = c > 0 ? e / (float)c : 10000.0f;
     }
     __syncthreads();
     // first strict minimum (:1225-1234): arg-min on (err, k) by wave 0

@@ -653,3 +653,46 @@ def test_contexts_are_reentrant_across_threads(torch_mod):
     for (w, t), (pose, st) in res.items():
         want = ref["icp" if w == 1 else "psm"]
         assert np.array_equal(st, want[1]) and same_bits(pose, want[0]), (w, t)
+
+
+@pytest.mark.parametrize("beams,window", [(1081, 200), (361, 40), (181, 20)])
+def test_orientation_search_block_edges(beams, window, torch_mod):
+    """The bounded orientation search evaluates the shifts in blocks of 64 around zero shift and abandons blocks
+    whose partial sums exceed the zero block's minimum.  Rotations that put the minimum on a block edge, inside an
+    outer block, at the ends of the window, a scan without valid readings and sparse scans must all give the
+    oracle's status and bits (pm_orientation_search, src/zhpsm/ZHPolar_Match.cpp:1152-1261)."""
+    from laser_slam_amd import capi, synth
+    from oracle_lib import Oracle
+    kw = dict(points=beams, fov_deg=270, max_range=3000, min_valid=beams // 4, window=window, fi_min_deg=-135, fi_max_deg=135)
+    raw = synth.make_scans(6, noise_seed=synth.WORLD_SEED + 77, **({} if beams == 1081 else dict(n_beams=beams)))[0]
+    o = Oracle(**kw)
+    ctx = capi.Context(capi.param_make(**kw))
+    rng = np.random.default_rng(5)
+    W = window
+    shifts = sorted({s for s in (-W, -W + 1, -161, -160, -97, -96, -95, -34, -33, -32, -31, -1, 0, 1, 30, 31, 32, 33, 95, 96, 97,
+                                 159, 160, W - 1, W) if -W <= s <= W})
+    checked = 0
+    for k in range(3):
+        ref_r, ref_bad, _ = o.preprocess(raw[k])
+        for s in shifts:
+            for sparse in (False, True):
+                new_r = np.roll(ref_r, -s).astype(np.float32) + rng.normal(0, 0.5, beams).astype(np.float32)
+                new_bad = np.roll(ref_bad, -s).astype(np.int32)
+                if s > 0: new_bad[beams - s:] = 1          # readings rolled in from the other end
+                if s < 0: new_bad[:-s] = 1
+                if sparse:
+                    new_bad[rng.random(beams) < 0.9] = 1
+                want = o.orientation_search(ref_r, ref_bad, new_r, new_bad)
+                got = ctx.orientation_search_host(ref_r, ref_bad, new_r, new_bad)
+                assert (got[0] != 0) == (want[0] != 0), (beams, s, sparse)
+                if want[0] == 0:
+                    assert np.float32(got[1]).tobytes() == np.float32(want[1]).tobytes(), (beams, s, sparse, got, want)
+                checked += 1
+    # nothing valid on one side: no orientation
+    ref_r, ref_bad, _ = o.preprocess(raw[0])
+    allbad = np.ones(beams, np.int32)
+    assert o.orientation_search(ref_r, ref_bad, ref_r, allbad)[0] != 0
+    assert ctx.orientation_search_host(ref_r, ref_bad, ref_r, allbad)[0] != 0
+    assert ctx.orientation_search_host(ref_r, allbad, ref_r, ref_bad)[0] != 0
+    ctx.close()
+    assert checked == 6 * len(shifts)
