@@ -194,7 +194,7 @@ def pmc_per_unit(kernel):
     if hbm and key in hbm:
         rec = hbm[key]
         units = rec.get("units_per_launch") or rec.get("pairs_per_launch")
-        if units:
+        if units and "FETCH_SIZE_KB_per_launch" in rec and "WRITE_SIZE_KB_per_launch" in rec:
             out["hbm_bytes_per_unit"] = (2.0 * rec["FETCH_SIZE_KB_per_launch"] + rec["WRITE_SIZE_KB_per_launch"]) * 1024.0 / units
     return out
 

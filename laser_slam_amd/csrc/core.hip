@@ -63,6 +63,9 @@ struct lsa_ctx {
     size_t arena_cap = 0;
     char* d_scratch = nullptr;   // grow-only scratch of the calls that need large temporaries (a context serves one thread)
     size_t scratch_cap = 0;
+    unsigned int* d_queue = nullptr;   // pair counter of the matchers' work queue (zeroed before each launch)
+    int n_cu = 0;
+    int occ_icp = 0, occ_psm = 0;      // workgroups per CU of the matcher kernels for the current laser (0 = not asked yet)
     double* d_trig = nullptr;    // point-to-line ICP: cos | sin of the beam bearings in double, 2*N (host libm, as CSM's ld_compute_cartesian on the CPU)
 };
 
@@ -312,6 +315,12 @@ int lsa_ctx_create(lsa_ctx** out, int device, const lsa_laser_param* p)
     if (e != hipSuccess) { delete c; return fail(LSA_E_HIP, "hipStreamCreate", e); }
     rc = upload_tables(c);
     if (rc) { hipStreamDestroy(c->stream); delete c; return rc; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || hipMalloc((void**)&c->d_queue, sizeof(unsigned int)) != hipSuccess) {
+        hipFree(c->d_tab); hipStreamDestroy(c->stream); delete c;
+        return fail(LSA_E_HIP, "context set-up");
+    }
+    c->n_cu = prop.multiProcessorCount;
     *out = c;
     return LSA_OK;
 }
@@ -324,6 +333,7 @@ int lsa_ctx_set_param(lsa_ctx* c, const lsa_laser_param* p)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->p = *p;
+    c->occ_icp = c->occ_psm = 0;
     if (c->d_trig) { hipFree(c->d_trig); c->d_trig = nullptr; }          // the point-to-line ICP's bearing table follows fi_min / dfi / points
     return upload_tables(c);
 }
@@ -363,6 +373,7 @@ void lsa_ctx_destroy(lsa_ctx* c)
     hipStreamSynchronize(c->stream);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     hipFree(c->d_tab);
+    hipFree(c->d_queue);
     if (c->d_trig) hipFree(c->d_trig);
     if (c->d_stage) hipFree(c->d_stage);
     if (c->h_stage) hipHostFree(c->h_stage);
@@ -482,9 +493,16 @@ int lsa_match_batch(lsa_ctx* c, int which, int B,
     if (B <= 0) return LSA_OK;
     HIP_TRY(hipSetDevice(c->device));
     const lsa::DevParam P = dev_param(c);
+    // Persistent launch: as many workgroups as the chip holds at once, each claiming pairs from a counter until the
+    // batch is done.  A workgroup's set-up (and the registers the compiler parks in scratch memory there) is then paid
+    // once per workgroup, not once per pair; pairs of different iteration counts still balance as they finish.
+    HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned int), c->stream));
     if (which == LSA_MATCH_ICP) {
-#define LSA_LAUNCH_ICP(NC) hipLaunchKernelGGL(lsa::icp_kernel<NC>, dim3(B), dim3(lsa::ICP_THREADS), icp_lds(P.n), c->stream, P, B, d_r, \
-                           d_bad, d_seg, d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters)
+#define LSA_LAUNCH_ICP(NC) do { \
+        if (!c->occ_icp) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_icp, lsa::icp_kernel<NC>, lsa::ICP_THREADS, icp_lds(P.n))); \
+        const long long resident = (long long)(c->occ_icp > 0 ? c->occ_icp : 1) * c->n_cu; \
+        hipLaunchKernelGGL(lsa::icp_kernel<NC>, dim3((unsigned)(B < resident ? B : resident)), dim3(lsa::ICP_THREADS), icp_lds(P.n), c->stream, P, B, d_r, \
+                           d_bad, d_seg, d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters, c->d_queue); } while (0)
         switch (P.n) {          // the reference's presets (PolarParameter.h:75-83) and the 1081-beam benchmark sensor
         case 181:  LSA_LAUNCH_ICP(181); break;
         case 361:  LSA_LAUNCH_ICP(361); break;
@@ -495,8 +513,12 @@ int lsa_match_batch(lsa_ctx* c, int which, int B,
 #undef LSA_LAUNCH_ICP
     } else
     {
-#define LSA_LAUNCH_PSM(NC) hipLaunchKernelGGL(lsa::psm_kernel<NC>, dim3(B), dim3(lsa::PSM_THREADS), lsa::psm_compact_lds_bytes(P.n, P.window), c->stream, P, B, \
-                           d_r, d_bad, d_seg, d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters)
+#define LSA_LAUNCH_PSM(NC) do { \
+        const int lds = lsa::psm_compact_lds_bytes(P.n, P.window); \
+        if (!c->occ_psm) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_psm, lsa::psm_kernel<NC>, lsa::PSM_THREADS, lds)); \
+        const long long resident = (long long)(c->occ_psm > 0 ? c->occ_psm : 1) * c->n_cu; \
+        hipLaunchKernelGGL(lsa::psm_kernel<NC>, dim3((unsigned)(B < resident ? B : resident)), dim3(lsa::PSM_THREADS), lds, c->stream, P, B, \
+                           d_r, d_bad, d_seg, d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters, c->d_queue); } while (0)
         switch (P.n) {
         case 181:  LSA_LAUNCH_PSM(181); break;
         case 361:  LSA_LAUNCH_PSM(361); break;

@@ -625,7 +625,8 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
     DevParam P_, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
     const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
     const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
-    float* __restrict__ err_xy, int* __restrict__ n_assoc, int* __restrict__ status_out, int* __restrict__ iters_out)
+    float* __restrict__ err_xy, int* __restrict__ n_assoc, int* __restrict__ status_out, int* __restrict__ iters_out,
+    unsigned int* __restrict__ queue)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevParam P = P_;
@@ -640,11 +641,17 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
     const float* const my_list = lane == 0 ? Lnx : lane == 1 ? Lny : lane == 2 ? Lix : Liy;    // the list lane 0..3 of the serial wave sums
 
     const int sw = 0;                       // the wave that runs the order-bound single-wave phases
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    // pairs are claimed from the batch's counter (imisc[1] carries the claim to the workgroup); every workgroup leaves
+    // the loop at its first claim past the batch
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) imisc[1] = (int)atomicAdd(queue, 1u);
+        __syncthreads();
+        const int b = imisc[1];
+        if (b >= B) break;
         const size_t ro = (size_t)ref_idx[b] * N, ao = (size_t)act_idx[b] * N;
         L.g_act_r = g_r + ao;
         L.g_ref_r = g_r + ro;
-        __syncthreads();
         for (int i = tid; i < N; i += ICP_THREADS) {
             float rr = g_r[ro + i];
             const uint8_t rb = g_bad[ro + i];

@@ -161,25 +161,39 @@ __device__ __forceinline__ void scatter_pair(const DevParam& P, const Lds& L, in
     }
 }
 
+// PAIRED: two beams per trip so that their (long, independent) dependency chains overlap; pm_psm at eight
+// workgroups per CU has the waves to hide the latency and not the registers for two chains
+template <bool PAIRED = true>
 __device__ void scan_project(const DevParam& P, const Lds& L, float ax, float ay, float ath)
 {
     const int N = P.n, tid = threadIdx.x, nth = blockDim.x;
-    // two beams per trip so that their (long, independent) dependency chains overlap
-    for (int i0 = tid; i0 < N; i0 += 2 * nth) {
-        const int i1 = i0 + nth;
-        const bool has1 = i1 < N;
-        const int j1 = has1 ? i1 : i0;
-        const float d0 = ath + P.fi[i0], d1 = ath + P.fi[j1];
-        const float r0 = L.act_r ? L.act_r[i0] : L.g_act_r[i0];
-        const float r1 = L.act_r ? L.act_r[j1] : L.g_act_r[j1];
-        float pr0, pf0, pr1, pf1;
-        bool sp0, sp1;
-        project_beam(d0, r0, ax, ay, pr0, pf0, sp0);
-        project_beam(d1, r1, ax, ay, pr1, pf1, sp1);
-        if (sp0) { const float2 q = project_beam_slow(d0, r0, ax, ay); pr0 = q.x; pf0 = q.y; }
-        if (sp1) { const float2 q = project_beam_slow(d1, r1, ax, ay); pr1 = q.x; pf1 = q.y; }
-        L.pr[i0] = pr0; L.pf[i0] = pf0; L.key[i0] = KEY_INIT;
-        if (has1) { L.pr[i1] = pr1; L.pf[i1] = pf1; L.key[i1] = KEY_INIT; }
+    if (PAIRED) {
+        for (int i0 = tid; i0 < N; i0 += 2 * nth) {
+            const int i1 = i0 + nth;
+            const bool has1 = i1 < N;
+            const int j1 = has1 ? i1 : i0;
+            const float d0 = ath + P.fi[i0], d1 = ath + P.fi[j1];
+            const float r0 = L.act_r ? L.act_r[i0] : L.g_act_r[i0];
+            const float r1 = L.act_r ? L.act_r[j1] : L.g_act_r[j1];
+            float pr0, pf0, pr1, pf1;
+            bool sp0, sp1;
+            project_beam(d0, r0, ax, ay, pr0, pf0, sp0);
+            project_beam(d1, r1, ax, ay, pr1, pf1, sp1);
+            if (sp0) { const float2 q = project_beam_slow(d0, r0, ax, ay); pr0 = q.x; pf0 = q.y; }
+            if (sp1) { const float2 q = project_beam_slow(d1, r1, ax, ay); pr1 = q.x; pf1 = q.y; }
+            L.pr[i0] = pr0; L.pf[i0] = pf0; L.key[i0] = KEY_INIT;
+            if (has1) { L.pr[i1] = pr1; L.pf[i1] = pf1; L.key[i1] = KEY_INIT; }
+        }
+    } else {
+        for (int i = tid; i < N; i += nth) {
+            const float d = ath + P.fi[i];
+            const float r = L.act_r ? L.act_r[i] : L.g_act_r[i];
+            float pr, pf;
+            bool sp;
+            project_beam(d, r, ax, ay, pr, pf, sp);
+            if (sp) { const float2 q = project_beam_slow(d, r, ax, ay); pr = q.x; pf = q.y; }
+            L.pr[i] = pr; L.pf[i] = pf; L.key[i] = KEY_INIT;
+        }
     }
     __syncthreads();
     for (int i = tid; i < N; i += nth)

@@ -15,7 +15,7 @@
 //   row A  [ 0, 4)  projected range pr -> new_r (unpacked from the keys) -> NaN-masked new_r of the search
 //   rows B-D [ 4,16) pf | u64 keys  -> NaN-masked, W-padded reference row + err[2W+1] of the search
 //                                   -> six term rows of half a scan each (translation, two passes)
-//   broadcast slots (64 B), validity masks of the orientation search, then one bit per beam for
+//   broadcast slots (128 B), validity masks of the orientation search, then one bit per beam for
 //   ref_bad / pair_ok / new_bad.  Both scans' ranges are read from HBM/L2 where they are needed (the current
 //   scan once per projection, the reference scan once per search / translation step).
 
@@ -25,7 +25,8 @@ constexpr int PSM_THREADS = 256;
 // (2 Np / 32 + 4 words; the window satisfies 2W + 1 <= Np)
 __host__ __device__ inline int psm_mask_words_new(int Np) { return Np / 32 + 1; }
 __host__ __device__ inline int psm_mask_words_ref(int Np) { return 2 * Np / 32 + 4; }
-__host__ __device__ inline int psm_scratch_bytes(int Np) { return 64 + 4 * ((psm_mask_words_new(Np) + psm_mask_words_ref(Np) + 3) & ~3); }
+constexpr int PSM_BC_FLOATS = 32;    // broadcast slots ahead of the search masks
+__host__ __device__ inline int psm_scratch_bytes(int Np) { return 4 * PSM_BC_FLOATS + 4 * ((psm_mask_words_new(Np) + psm_mask_words_ref(Np) + 3) & ~3); }
 // byte-flag layout (carve_psm): stage / projection / error-index kernels
 __host__ __device__ inline int psm_lds_bytes(int n) { int Np = (n + 63) & ~63; return 35 * Np + psm_scratch_bytes(Np); }
 // compact layout of psm_kernel
@@ -164,19 +165,18 @@ constexpr float ORIENT_ABANDONED = -1.0f;       // err[] entry of a shift whose 
 // A block either runs to the end (all 64 values exact) or is abandoned as a whole; if a neighbour of the
 // minimum lies in an abandoned block it is evaluated again without a bound.  The values that reach the
 // arg-min and the parabola are therefore the reference's, bit for bit.
-__device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, float* bc, int turn = 0)
+__device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, float* bc)
 {
     const int N = P.n, W = P.window, K = 2 * W + 1, tid = threadIdx.x, Np = (N + 63) & ~63;
     float* nrm = L.pr;                 // Np floats (the pr row)
     float* rfm = L.pf;                 // N + 2W + 4 (+ pad) floats (pf row + the key rows)
     float* err = L.err ? L.err : rfm + psm_ref_row_floats(N, W);
-    uint32_t* newm = (uint32_t*)(bc + 16);
+    uint32_t* newm = (uint32_t*)(bc + PSM_BC_FLOATS);
     uint32_t* refm = newm + psm_mask_words_new(Np);
     build_masked_rows(P, L, nrm, rfm, newm, refm);
     __syncthreads();
     const int N4 = (N + 3) & ~3, nw = (N + 31) >> 5;
-    // (`turn` rotates the roles of the waves: the long unbounded block should not always land on the same SIMD)
-    const int lane = lane_id(), nwaves = blockDim.x >> 6, wave = ((tid >> 6) + turn) % nwaves;
+    const int lane = lane_id(), nwaves = blockDim.x >> 6, wave = tid >> 6;
     const int origin = W - 32;                                  // block m holds the shifts origin + 64 m + lane
     const float inf = u2f(0x7f800000u);
     if (wave == 0) {
@@ -188,14 +188,10 @@ __device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, f
         orient_sum<false>(nrm, rfm + kk, N4, inf, e);
         const float er = c > 0 ? e / (float)c : 10000.0f;                             // :1203-1206
         if (in) err[k] = er;
-        float b = in ? er : inf;
-        #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) b = fminf(b, __shfl_xor(b, off));
+        const float b = wave_min_f32(in ? er : inf);
         if (lane == 0) bc[1] = b;
     }
-    int n_new = lane < nw ? __popc(newm[lane]) : 0;               // nw <= 64 (LSA_MAX_POINTS)
-    #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) n_new += __shfl_xor(n_new, off);
+    const int n_new = wave_sum_i32(lane < nw ? __popc(newm[lane]) : 0);        // nw <= 64 (LSA_MAX_POINTS)
     __syncthreads();
     const float bound = bc[1];
 #ifdef LSA_ORIENT_STATS
@@ -233,14 +229,10 @@ __device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, f
             const float e = err[k];
             if (e >= 0.0f && e < bm) { bm = e; bk = k; }
         }
-        #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float om = __shfl_xor(bm, off);
-            const int ok = __shfl_xor(bk, off);
-            const bool take = (ok >= 0) && (bk < 0 || om < bm || (om == bm && ok < bk));
-            if (take) { bm = om; bk = ok; }
-        }
-        if (lane == 0) ((int*)bc)[0] = bk;
+        // (each lane holds the smallest k of its own minimum; the wave's minimum, then the smallest k that has it)
+        const float vmin = wave_min_f32(bm);
+        const int kmin = wave_min_i32(bk >= 0 && bm == vmin ? bk : 0x7fffffff);
+        if (lane == 0) ((int*)bc)[0] = kmin == 0x7fffffff ? -1 : kmin;
     }
     __syncthreads();
     const int imin = ((int*)bc)[0];
@@ -330,9 +322,7 @@ __device__ int translation_estimation(const DevParam& P, const Lds& L, float C, 
     if (tid < 6) bc[tid] = acc;
     // number of gated-in beams
     const int wave = tid >> 6;
-    int wsum = mine;
-    #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) wsum += __shfl_xor(wsum, off);
+    const int wsum = wave_sum_i32(mine);
     if (lane_id() == 0) ((int*)bc)[8 + wave] = wsum;
     __syncthreads();
     int cnt = 0;
@@ -390,6 +380,9 @@ __device__ __forceinline__ void load_pair_psm(const DevParam& P, Lds& L, const f
 #ifndef LSA_PSM_WG_PER_CU
 #define LSA_PSM_WG_PER_CU 8
 #endif
+#ifndef LSA_PSM_PAIRED
+#define LSA_PSM_PAIRED false
+#endif
 // NC > 0: the beam count as a compile-time constant (see icp_kernel)
 template <int NC>
 // eight workgroups per CU (64 registers; 17.9 KiB of LDS at 1081 beams)
@@ -397,7 +390,8 @@ __global__ __launch_bounds__(PSM_THREADS, LSA_PSM_WG_PER_CU) void psm_kernel(
     DevParam P_, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
     const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
     const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
-    float* __restrict__ err_xy, int* __restrict__ n_assoc, int* __restrict__ status_out, int* __restrict__ iters_out)
+    float* __restrict__ err_xy, int* __restrict__ n_assoc, int* __restrict__ status_out, int* __restrict__ iters_out,
+    unsigned int* __restrict__ queue)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevParam P = P_;
@@ -406,56 +400,72 @@ __global__ __launch_bounds__(PSM_THREADS, LSA_PSM_WG_PER_CU) void psm_kernel(
     float* bc;
     Lds L = carve_psm_compact(smem, Np, psm_compact_bcd_floats(N, P.window), bc);
 
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        const size_t ro = (size_t)ref_idx[b] * N, ao = (size_t)act_idx[b] * N;
+    // pairs are claimed from the batch's counter (slot 15 carries the claim to the workgroup); every workgroup leaves
+    // the loop at its first claim past the batch
+    // The pair's pose state lives in broadcast slots, not in registers: thread 0 writes it, every phase reads what it
+    // needs (LDS broadcast reads), and nothing uniform is carried in vector registers across the phases.
+    enum { PS_AX = 16, PS_AY, PS_ATH, PS_DX, PS_DY, PS_DTH, PS_AVG };
+    for (;;) {
         __syncthreads();
+        if (tid == 0) ((int*)bc)[15] = (int)atomicAdd(queue, 1u);
+        __syncthreads();
+        const int b = __builtin_amdgcn_readfirstlane(((int*)bc)[15]);
+        if (b >= B) break;
+        const size_t ro = (size_t)__builtin_amdgcn_readfirstlane(ref_idx[b]) * N;
+        const size_t ao = (size_t)__builtin_amdgcn_readfirstlane(act_idx[b]) * N;
         load_pair_psm(P, L, g_r, g_bad, g_seg, ro, ao);
-        float ax, ay, ath;
-        rel_pose(init_pose ? init_pose + 6 * (size_t)b : nullptr, ax, ay, ath);
-        const float ax0 = init_pose ? init_pose[6 * (size_t)b + 3] : 0.0f;
-        const float ay0 = init_pose ? init_pose[6 * (size_t)b + 4] : 0.0f;
-        const float ath0 = init_pose ? init_pose[6 * (size_t)b + 5] : 0.0f;
+        if (tid == 0) {
+            float ax, ay, ath;
+            rel_pose(init_pose ? init_pose + 6 * (size_t)b : nullptr, ax, ay, ath);
+            bc[PS_AX] = ax; bc[PS_AY] = ay; bc[PS_ATH] = ath;
+            bc[PS_DX] = 0.0f; bc[PS_DY] = 0.0f; bc[PS_DTH] = 0.0f; bc[PS_AVG] = 100000000.0f;
+        }
         const float C = LSA_WEIGHT;      // `C /= 50` at iter == 10 (:973) is dead code: 10 is even
-        float dx = 0, dy = 0, dth = 0, avg = 100000000.0f;
         int small = 0, status = LSA_ST_OK;
         __syncthreads();
 
         int iter = -1;
         while (++iter < LSA_ITER_PSM && small < 3) {
-            if ((double)(fabsf_(dx) + fabsf_(dy) + fabsf_(dth)) < LSA_STOP_PSM) small++; else small = 0;   // :933
-            scan_project(P, L, ax, ay, ath);
+            if ((double)(fabsf_(bc[PS_DX]) + fabsf_(bc[PS_DY]) + fabsf_(bc[PS_DTH])) < LSA_STOP_PSM) small++; else small = 0;   // :933
+            scan_project<LSA_PSM_PAIRED>(P, L, bc[PS_AX], bc[PS_AY], bc[PS_ATH]);
             unpack_projection(P, L);
             if ((iter & 1) == 0) {
-                status = orientation_search(P, L, dth, bc, b + (iter >> 1));
+                float dth = 0.0f;
+                status = orientation_search(P, L, dth, bc);
                 if (status) break;
-                ath += dth;
+                if (tid == 0) { bc[PS_ATH] += dth; bc[PS_DTH] = dth; }
                 __syncthreads();
                 continue;
             }
+            float dx = 0.0f, dy = 0.0f, avg = 0.0f;
             status = translation_estimation(P, L, C, dx, dy, avg, bc);
             if (status) break;
-            ax += dx;
-            ay += dy;
+            if (tid == 0) { bc[PS_AX] += dx; bc[PS_AY] += dy; bc[PS_DX] = dx; bc[PS_DY] = dy; bc[PS_AVG] = avg; }
+            __syncthreads();
         }
 
+        const bool ok = status == LSA_ST_OK;
         if (tid == 0) {
-            const bool ok = status == LSA_ST_OK;
-            pose_out[3 * (size_t)b + 0] = ok ? ax : ax0;
-            pose_out[3 * (size_t)b + 1] = ok ? ay : ay0;
-            pose_out[3 * (size_t)b + 2] = ok ? ath : ath0;
-            if (ret_out) ret_out[b] = ok ? avg : 0.0f;
+            const float* ip = init_pose ? init_pose + 6 * (size_t)b : nullptr;
+            pose_out[3 * (size_t)b + 0] = ok ? bc[PS_AX] : (ip ? ip[3] : 0.0f);
+            pose_out[3 * (size_t)b + 1] = ok ? bc[PS_AY] : (ip ? ip[4] : 0.0f);
+            pose_out[3 * (size_t)b + 2] = ok ? bc[PS_ATH] : (ip ? ip[5] : 0.0f);
+            if (ret_out) ret_out[b] = ok ? bc[PS_AVG] : 0.0f;
             if (status_out) status_out[b] = status;
             if (iters_out) iters_out[b] = iter;
         }
         if (err_xy) {
-            __syncthreads();
-            if (status == LSA_ST_OK) {
-                float ex, ey, eth;
-                if (init_pose) {
-                    float ip[6] = {init_pose[6 * (size_t)b], init_pose[6 * (size_t)b + 1], init_pose[6 * (size_t)b + 2], ax, ay, ath};
+            if (ok) {
+                __syncthreads();
+                if (tid == 0 && init_pose) {
+                    const float* q = init_pose + 6 * (size_t)b;
+                    const float ip[6] = {q[0], q[1], q[2], bc[PS_AX], bc[PS_AY], bc[PS_ATH]};
+                    float ex, ey, eth;
                     rel_pose(ip, ex, ey, eth);
-                } else { ex = ax; ey = ay; eth = ath; }
-                scan_project(P, L, ex, ey, eth);
+                    bc[PS_AX] = ex; bc[PS_AY] = ey; bc[PS_ATH] = eth;
+                }
+                __syncthreads();
+                scan_project<LSA_PSM_PAIRED>(P, L, bc[PS_AX], bc[PS_AY], bc[PS_ATH]);
                 error_index2_tail(P, L, err_xy + 2 * (size_t)b, n_assoc ? n_assoc + b : nullptr);
             } else if (tid < 2) {
                 err_xy[2 * (size_t)b + tid] = -1.0f;
