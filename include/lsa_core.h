@@ -239,6 +239,11 @@ int lsa_field_download(lsa_field* f, int what /*0 lik, 1 log lik*/, float* h_out
  * [m]; every `decimation`-th point is used (g_scan_decimation = 3, globaldef.cpp:13) */
 int lsa_score_poses(lsa_field* f, const float* d_scan_x, const float* d_scan_y, int n_points, int decimation,
                     const float* d_poses, int n_poses, float* d_score);
+/* the same sum of log-likelihoods with the scan points composed plainly, pose (+) point (x forward, y left, theta
+ * counter-clockwise): the observation model of MRPT's pf-localization as src/pf_localization_main.cpp:627-632 runs it
+ * (MRPT absent: parity unpinned) */
+int lsa_score_poses_std(lsa_field* f, const float* d_scan_x, const float* d_scan_y, int n_points, int decimation,
+                        const float* d_poses, int n_poses, float* d_score);
 /* best of the scored poses: threadLocalization::globalization + topK(1), localization.cpp:126-149,483-540 */
 int lsa_pose_argmax(lsa_ctx* c, const float* d_score, int n_poses, float* h_max, int32_t* h_index);
 /* particle weights w = exp(score - max_score) with their sum and sum of squares
@@ -269,6 +274,10 @@ int lsa_pf_estimate(lsa_ctx* c, const float* d_poses, const float* d_score, int 
  * d_normals [n][3] standard normal draws (the reference's Boost generator is not reproducible) */
 int lsa_pf_predict(lsa_ctx* c, int n, const double mean_pose[3], const double sigma[3], const float* d_normals,
                    float* d_poses);
+/* Prediction step of MRPT's pf-localization (PF.executeOn, src/pf_localization_main.cpp:627-632; MRPT absent: parity
+ * unpinned): pose_i <- pose_i (+) (delta + sigma * normal_i), the increment in the robot frame, theta in (-pi, pi] */
+int lsa_pf_motion(lsa_ctx* c, int n, const double delta[3], const double sigma[3], const float* d_normals,
+                  float* d_poses);
 /* SIR_scheme::roughen_minmax (src/sensorFusion/SIRFlt.cpp:359-413): state += normal * (max - min) * K n^(-1/3) */
 int lsa_pf_roughen(lsa_ctx* c, int n, double K, const float* d_normals, float* d_poses);
 /* CVPmap::laserScanSimulator / simulateScanRay (src/localization/VPmap.cpp:180-303): virtual scans of

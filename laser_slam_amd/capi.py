@@ -103,6 +103,7 @@ def lib():
     L.lsa_field_build_from_grid.argtypes = [vp, vp, C.c_float, C.c_float, C.c_float]
     L.lsa_field_download.argtypes = [vp, C.c_int, vp]
     L.lsa_score_poses.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp]
+    L.lsa_score_poses_std.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp]
     L.lsa_pose_argmax.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     L.lsa_pf_weights.argtypes = [vp, vp, C.c_int, C.c_float, vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.lsa_pf_resample.argtypes = [vp, vp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, vp]
@@ -110,6 +111,7 @@ def lib():
     L.lsa_pose_topk.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     L.lsa_pf_estimate.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
     L.lsa_pf_predict.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.lsa_pf_motion.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.lsa_pf_roughen.argtypes = [vp, C.c_int, C.c_double, vp, vp]
     L.lsa_simulate_scans.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp]
     L.lsa_valid_poses.argtypes = [vp, vp, vp, C.c_int, C.c_float, C.c_float, vp]
@@ -429,9 +431,9 @@ class Field:
         check(self.L.lsa_field_download(self.h, what, _hp(out)), "lsa_field_download")
         return out
 
-    def score_poses(self, d_scan_x, d_scan_y, n_points, decimation, d_poses, P, d_score):
-        check(self.L.lsa_score_poses(self.h, _dp(d_scan_x), _dp(d_scan_y), n_points, decimation, _dp(d_poses), P,
-                                     _dp(d_score)), "lsa_score_poses")
+    def score_poses(self, d_scan_x, d_scan_y, n_points, decimation, d_poses, P, d_score, std_frame=False):
+        fn = self.L.lsa_score_poses_std if std_frame else self.L.lsa_score_poses
+        check(fn(self.h, _dp(d_scan_x), _dp(d_scan_y), n_points, decimation, _dp(d_poses), P, _dp(d_score)), "lsa_score_poses")
 
 
 def pose_argmax(ctx, d_score, P):
@@ -473,6 +475,11 @@ def pf_estimate(ctx, d_poses, d_score, n, k):
 def pf_predict(ctx, n, mean_pose, sigma, d_normals, d_poses):
     m = np.ascontiguousarray(mean_pose, np.float64); sg = np.ascontiguousarray(sigma, np.float64)
     check(lib().lsa_pf_predict(ctx.h, n, _hp(m), _hp(sg), _dp(d_normals), _dp(d_poses)), "lsa_pf_predict")
+
+
+def pf_motion(ctx, n, delta, sigma, d_normals, d_poses):
+    m = np.ascontiguousarray(delta, np.float64); sg = np.ascontiguousarray(sigma, np.float64)
+    check(lib().lsa_pf_motion(ctx.h, n, _hp(m), _hp(sg), _dp(d_normals), _dp(d_poses)), "lsa_pf_motion")
 
 
 def pf_roughen(ctx, n, K, d_normals, d_poses):

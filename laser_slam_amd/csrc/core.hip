@@ -1080,8 +1080,8 @@ int lsa_field_download(lsa_field* f, int what, float* h_out)
     return LSA_OK;
 }
 
-int lsa_score_poses(lsa_field* f, const float* d_scan_x, const float* d_scan_y, int n_points, int decimation,
-                    const float* d_poses, int P, float* d_score)
+static int score_poses(lsa_field* f, bool std_frame, const float* d_scan_x, const float* d_scan_y, int n_points, int decimation,
+                       const float* d_poses, int P, float* d_score)
 {
     if (!f || !d_scan_x || !d_scan_y || !d_poses || !d_score) return fail(LSA_E_ARG, "null argument");
     if (n_points <= 0 || decimation <= 0) return fail(LSA_E_ARG, "bad scan size / decimation");
@@ -1089,10 +1089,26 @@ int lsa_score_poses(lsa_field* f, const float* d_scan_x, const float* d_scan_y, 
     HIP_TRY(hipSetDevice(f->c->device));
     const int nb = (n_points + decimation - 1) / decimation;
     if (nb * 8 > 64 * 1024) return fail(LSA_E_ARG, "too many scan points for the LDS stage");
-    hipLaunchKernelGGL(lsa::score_poses_kernel, dim3(blocks_for((size_t)P, 256)), dim3(256), nb * 8, f->c->stream,
-                       f->F, f->d_loglik, d_scan_x, d_scan_y, n_points, decimation, d_poses, P, d_score);
+    if (std_frame)
+        hipLaunchKernelGGL(lsa::score_poses_kernel<true>, dim3(blocks_for((size_t)P, 256)), dim3(256), nb * 8, f->c->stream,
+                           f->F, f->d_loglik, d_scan_x, d_scan_y, n_points, decimation, d_poses, P, d_score);
+    else
+        hipLaunchKernelGGL(lsa::score_poses_kernel<false>, dim3(blocks_for((size_t)P, 256)), dim3(256), nb * 8, f->c->stream,
+                           f->F, f->d_loglik, d_scan_x, d_scan_y, n_points, decimation, d_poses, P, d_score);
     HIP_TRY(hipGetLastError());
     return LSA_OK;
+}
+
+int lsa_score_poses(lsa_field* f, const float* d_scan_x, const float* d_scan_y, int n_points, int decimation,
+                    const float* d_poses, int P, float* d_score)
+{
+    return score_poses(f, false, d_scan_x, d_scan_y, n_points, decimation, d_poses, P, d_score);
+}
+
+int lsa_score_poses_std(lsa_field* f, const float* d_scan_x, const float* d_scan_y, int n_points, int decimation,
+                        const float* d_poses, int P, float* d_score)
+{
+    return score_poses(f, true, d_scan_x, d_scan_y, n_points, decimation, d_poses, P, d_score);
 }
 
 // best pose of a score array: max score and its index (smallest index among equal scores)
@@ -1217,6 +1233,16 @@ int lsa_pf_predict(lsa_ctx* c, int n, const double mean_pose[3], const double si
     HIP_TRY(hipSetDevice(c->device));
     hipLaunchKernelGGL(lsa::pf_predict_kernel, dim3(blocks_for((size_t)n, 256, 2048)), dim3(256), 0, c->stream, n,
                        mean_pose[0], mean_pose[1], mean_pose[2], sigma[0], sigma[1], sigma[2], d_normals, d_poses);
+    HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+
+int lsa_pf_motion(lsa_ctx* c, int n, const double delta[3], const double sigma[3], const float* d_normals, float* d_poses)
+{
+    if (!c || !delta || !sigma || !d_normals || !d_poses || n <= 0) return fail(LSA_E_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(lsa::pf_motion_kernel, dim3(blocks_for((size_t)n, 256, 2048)), dim3(256), 0, c->stream, n,
+                       delta[0], delta[1], delta[2], sigma[0], sigma[1], sigma[2], d_normals, d_poses);
     HIP_TRY(hipGetLastError());
     return LSA_OK;
 }

@@ -95,6 +95,9 @@ __device__ __forceinline__ int field_idx(float r, float off, int center, double 
 }
 
 // One thread per pose; scan points staged in LDS; log-likelihoods summed in beam order in double.
+// STD = false: the frame of CVPmap::obsLikelyhood3 (heading - pi/2, mirrored y, :366-381);
+// STD = true: the plain composition pose (+) point that MRPT-style callers (pf_localization_main.cpp) use.
+template <bool STD>
 __global__ __launch_bounds__(256) void score_poses_kernel(
     FieldParam F, const float* __restrict__ loglik, const float* __restrict__ sx, const float* __restrict__ sy,
     int n_points, int decim, const float* __restrict__ poses, int P, float* __restrict__ score)
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void score_poses_kernel(
         const double px = poses[3 * (size_t)p], py = poses[3 * (size_t)p + 1];
         // th = normAngle(theta - M_PI/2, -M_PI), :366.  VPmap.cpp includes PolarParameter.h, so M_PI is
         // 3.141592654 there, while normAngle (point.cpp:72-78) wraps with the true 2 pi.
-        double th = (double)poses[3 * (size_t)p + 2] - LSA_ZPI / 2.0;
+        double th = STD ? (double)poses[3 * (size_t)p + 2] : (double)poses[3 * (size_t)p + 2] - LSA_ZPI / 2.0;
         while (th >= -LSA_ZPI + 6.28318530717958647692) th -= 6.28318530717958647692;
         while (th < -LSA_ZPI) th += 6.28318530717958647692;
         float cs, sn;
@@ -122,7 +125,8 @@ __global__ __launch_bounds__(256) void score_poses_kernel(
         for (int k = 0; k < nb; ++k) {
             const float2 q = pts[k];
             const float gx = (float)((double)(cs * q.x - sn * q.y) + px);      // :380
-            const float gy = (float)((double)(-cs * q.y - sn * q.x) + py);     // :381
+            const float gy = STD ? (float)((double)(sn * q.x + cs * q.y) + py)
+                                 : (float)((double)(-cs * q.y - sn * q.x) + py);     // :381
             const int cx = field_idx(gx, F.off_x, F.center_x, F.res, inv_res);                     // x2idx :102-104
             const int cy = field_idx(gy, F.off_y, F.center_y, F.res, inv_res);
             if ((unsigned)cx >= sx1 || (unsigned)cy >= sy1) acc += log_min;   // :388-392
@@ -383,6 +387,26 @@ __global__ __launch_bounds__(256) void pf_predict_kernel(int n, double mx, doubl
         poses[3 * (size_t)i]     = (float)(mx + (double)normals[3 * (size_t)i] * sx);
         poses[3 * (size_t)i + 1] = (float)(my + (double)normals[3 * (size_t)i + 1] * sy);
         poses[3 * (size_t)i + 2] = (float)(mth + (double)normals[3 * (size_t)i + 2] * sth);
+    }
+}
+
+// The prediction step of MRPT's pf-localization as pf_localization_main.cpp:627-632 drives it (PARITY UNPINNED: MRPT
+// is absent): every particle is composed with its own draw of the odometry increment,
+//   increment_i = delta + sigma * normal_i   (robot frame),   pose_i <- pose_i (+) increment_i,   theta wrapped to (-pi, pi].
+// cos / sin of the particle's heading are the library's correctly reproduced float functions, the rest double.
+__global__ __launch_bounds__(256) void pf_motion_kernel(int n, double dx, double dy, double dth, double sx, double sy, double sth,
+                                                        const float* __restrict__ normals, float* __restrict__ poses)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float th = poses[3 * (size_t)i + 2];
+        const double c = (double)cosf_(th), s = (double)sinf_(th);
+        const double ix = dx + (double)normals[3 * (size_t)i] * sx, iy = dy + (double)normals[3 * (size_t)i + 1] * sy;
+        const double it = dth + (double)normals[3 * (size_t)i + 2] * sth;
+        double nt = (double)th + it;
+        if (nt > LSA_ZPI) nt -= 2.0 * LSA_ZPI; else if (nt <= -LSA_ZPI) nt += 2.0 * LSA_ZPI;
+        poses[3 * (size_t)i]     = (float)((double)poses[3 * (size_t)i] + (ix * c - iy * s));
+        poses[3 * (size_t)i + 1] = (float)((double)poses[3 * (size_t)i + 1] + (ix * s + iy * c));
+        poses[3 * (size_t)i + 2] = (float)nt;
     }
 }
 

@@ -124,6 +124,9 @@ void orc_likelihood_field(const float* prob, int sx, int sy, double res, float m
 void orc_score_poses(const float* lik, int sx, int sy, int cx0, int cy0, float offx, float offy, double res,
                      float max_corr, const float* scan_x, const float* scan_y, int n_points, int decim,
                      const float* poses, int P, float* score);
+void orc_score_poses_std(const float* lik, int sx, int sy, int cx0, int cy0, float offx, float offy, double res,
+                         float max_corr, const float* scan_x, const float* scan_y, int n_points, int decim,
+                         const float* poses, int P, float* score);
 void orc_systematic_resample(const float* w, int P, double u0, int n_out, int* parent);
 int orc_standard_resample(const float* w, int P, const double* u, int n_u, int* parent);
 double orc_neff(const float* w, int P);
@@ -144,6 +147,7 @@ void orc_topk(const float* score, int n, int k, int* index);
 void orc_pf_estimate(const float* poses, const float* score, const int* index, int k,
                      double mean[3], double* mean_weight, double* mean_dis);
 void orc_pf_predict(int n, const double mean[3], const double sigma[3], const float* normals, float* poses);
+void orc_pf_motion(int n, const double delta[3], const double sigma[3], const float* normals, float* poses);
 void orc_pf_roughen(int n, double K, const float* normals, float* poses);
 
 /* point-to-line ICP as configured by CCanonicalMatcher (CSM absent: PARITY UNPINNED), plicp_oracle.c */

@@ -51,23 +51,24 @@ void orc_likelihood_field(const float* prob, int sx, int sy, double res, float m
 }
 
 /* obsLikelyhood3 per pose: sum of log lik over every decim-th beam, double accumulation */
-void orc_score_poses(const float* lik, int sx, int sy, int cx0, int cy0, float offx, float offy, double res,
-                     float max_corr, const float* scan_x, const float* scan_y, int n_points, int decim,
-                     const float* poses, int P, float* score)
+static void score_poses(int std_frame, const float* lik, int sx, int sy, int cx0, int cy0, float offx, float offy, double res,
+                        float max_corr, const float* scan_x, const float* scan_y, int n_points, int decim,
+                        const float* poses, int P, float* score)
 {
     const double max_sq = (double)max_corr * (double)max_corr;
     const double min_lik = (double)(0.05f / 50.0f) + (double)0.95f * exp(-0.5 / (0.35 * 0.35) * max_sq);   /* :364 */
     const unsigned sx1 = (unsigned)(sx - 1), sy1 = (unsigned)(sy - 1);
     for (int p = 0; p < P; ++p) {
         const double px = poses[3 * p], py = poses[3 * p + 1];
-        double th = (double)poses[3 * p + 2] - Z_PI / 2.0;            /* :366 */
+        double th = std_frame ? (double)poses[3 * p + 2] : (double)poses[3 * p + 2] - Z_PI / 2.0;            /* :366 */
         while (th >= -Z_PI + 2 * 3.14159265358979323846) th -= 2 * 3.14159265358979323846;
         while (th < -Z_PI) th += 2 * 3.14159265358979323846;
         const float cs = cosf((float)th), sn = sinf((float)th);
         double acc = 0;
         for (int j = 0; j < n_points; j += decim) {
             const float gx = (float)((double)(cs * scan_x[j] - sn * scan_y[j]) + px);     /* :380 */
-            const float gy = (float)((double)(-cs * scan_y[j] - sn * scan_x[j]) + py);    /* :381 */
+            const float gy = std_frame ? (float)((double)(sn * scan_x[j] + cs * scan_y[j]) + py)
+                                       : (float)((double)(-cs * scan_y[j] - sn * scan_x[j]) + py);    /* :381 */
             const int cx = (int)(cx0 + ((double)(gx - offx) + 0.0005) / res);             /* :102-104 */
             const int cy = (int)(cy0 + ((double)(gy - offy) + 0.0005) / res);
             double l;
@@ -77,6 +78,21 @@ void orc_score_poses(const float* lik, int sx, int sy, int cx0, int cy0, float o
         }
         score[p] = (float)acc;
     }
+}
+
+void orc_score_poses(const float* lik, int sx, int sy, int cx0, int cy0, float offx, float offy, double res,
+                     float max_corr, const float* scan_x, const float* scan_y, int n_points, int decim,
+                     const float* poses, int P, float* score)
+{
+    score_poses(0, lik, sx, sy, cx0, cy0, offx, offy, res, max_corr, scan_x, scan_y, n_points, decim, poses, P, score);
+}
+
+/* the plain composition pose (+) point of MRPT-style callers (pf_localization_main.cpp:627-632; MRPT absent) */
+void orc_score_poses_std(const float* lik, int sx, int sy, int cx0, int cy0, float offx, float offy, double res,
+                         float max_corr, const float* scan_x, const float* scan_y, int n_points, int decim,
+                         const float* poses, int P, float* score)
+{
+    score_poses(1, lik, sx, sy, cx0, cy0, offx, offy, res, max_corr, scan_x, scan_y, n_points, decim, poses, P, score);
 }
 
 /* Systematic resampler with Kahan cumulative sum, one uniform u0 in [0,1) */

@@ -167,6 +167,24 @@ void orc_pf_predict(int n, const double mean[3], const double sigma[3], const fl
         for (int d = 0; d < 3; ++d) poses[3 * i + d] = (float)(mean[d] + (double)normals[3 * i + d] * sigma[d]);
 }
 
+/* prediction step of MRPT's pf-localization (pf_localization_main.cpp:627-632 calls PF.executeOn; MRPT is absent, so
+ * this restates the published standard proposal): pose (+) (delta + sigma * normal), theta wrapped to (-pi, pi] */
+void orc_pf_motion(int n, const double delta[3], const double sigma[3], const float* normals, float* poses)
+{
+    const double PI = 3.141592653589793;
+    for (int i = 0; i < n; ++i) {
+        const float th = poses[3 * i + 2];
+        const double c = (double)cosf(th), s = (double)sinf(th);
+        const double ix = delta[0] + (double)normals[3 * i] * sigma[0], iy = delta[1] + (double)normals[3 * i + 1] * sigma[1];
+        const double it = delta[2] + (double)normals[3 * i + 2] * sigma[2];
+        double nt = (double)th + it;
+        if (nt > PI) nt -= 2.0 * PI; else if (nt <= -PI) nt += 2.0 * PI;
+        poses[3 * i]     = (float)((double)poses[3 * i] + (ix * c - iy * s));
+        poses[3 * i + 1] = (float)((double)poses[3 * i + 1] + (ix * s + iy * c));
+        poses[3 * i + 2] = (float)nt;
+    }
+}
+
 /* roughen_minmax, SIRFlt.cpp:359-413 (x_size = 3) */
 void orc_pf_roughen(int n, double K, const float* normals, float* poses)
 {

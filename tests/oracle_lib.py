@@ -259,16 +259,17 @@ def likelihood_field(prob, res, max_corr=1.0, free_thr=0.3, unknown=0.5):
     return out
 
 
-def score_poses(lik, cx, cy, offx, offy, res, scan_x, scan_y, decim, poses, max_corr=1.0):
+def score_poses(lik, cx, cy, offx, offy, res, scan_x, scan_y, decim, poses, max_corr=1.0, std_frame=False):
     if Oracle._L is None:
         Oracle._L = _load_oracle()
     lik = np.ascontiguousarray(lik, f32)
     sx_, sy_ = np.ascontiguousarray(scan_x, f32), np.ascontiguousarray(scan_y, f32)
     poses = np.ascontiguousarray(poses, f32)
     out = np.zeros(len(poses), f32)
-    Oracle._L.orc_score_poses(_p(lik), lik.shape[0], lik.shape[1], cx, cy, C.c_float(offx), C.c_float(offy),
-                              C.c_double(res), C.c_float(max_corr), _p(sx_), _p(sy_), len(sx_), decim, _p(poses),
-                              len(poses), _p(out))
+    fn = Oracle._L.orc_score_poses_std if std_frame else Oracle._L.orc_score_poses
+    fn(_p(lik), lik.shape[0], lik.shape[1], cx, cy, C.c_float(offx), C.c_float(offy),
+       C.c_double(res), C.c_float(max_corr), _p(sx_), _p(sy_), len(sx_), decim, _p(poses),
+       len(poses), _p(out))
     return out
 
 
@@ -532,6 +533,13 @@ def pf_predict(n, mean, sigma, normals):
     mean = np.ascontiguousarray(mean, np.float64); sigma = np.ascontiguousarray(sigma, np.float64)
     normals = np.ascontiguousarray(normals, f32); poses = np.zeros((n, 3), f32)
     _orc().orc_pf_predict(n, _p(mean), _p(sigma), _p(normals), _p(poses))
+    return poses
+
+
+def pf_motion(poses, delta, sigma, normals):
+    poses = np.ascontiguousarray(poses, f32).copy(); normals = np.ascontiguousarray(normals, f32)
+    delta = np.ascontiguousarray(delta, np.float64); sigma = np.ascontiguousarray(sigma, np.float64)
+    _orc().orc_pf_motion(len(poses), _p(delta), _p(sigma), _p(normals), _p(poses))
     return poses
 
 

@@ -60,6 +60,12 @@ def test_scores_argmax_weights_resample(world):
     lik_o = likelihood_field(world["prob"], world["res"])
     want = score_poses(lik_o, 0, 0, 0.0, 0.0, world["res"], scan_x, scan_y, 3, poses)
     assert np.allclose(got, want, rtol=1e-5, atol=2e-3), np.abs(got - want).max()
+    # the plain pose (+) point frame of MRPT-style callers
+    fld.score_poses(d_x, d_y, n, 3, d_p, P, d_s, std_frame=True)
+    ctx.sync()
+    want_std = score_poses(lik_o, 0, 0, 0.0, 0.0, world["res"], scan_x, scan_y, 3, poses, std_frame=True)
+    assert np.allclose(d_s.cpu().numpy(), want_std, rtol=1e-5, atol=2e-3)
+    assert not np.allclose(want_std, want, atol=1.0)
     # decimation 1 (np < 100 rule of the reference is the caller's choice here)
     fld.score_poses(d_x, d_y, 90, 1, d_p, 64, d_s)
     ctx.sync()
@@ -232,6 +238,11 @@ def test_topk_estimate_predict_roughen(world):
     capi.pf_predict(ctx, n, [1.5, -2.0, 0.7], [0.25, 0.25, (np.pi / 6) ** 2], d_n, d_out)
     ctx.sync()
     assert np.array_equal(d_out.cpu().numpy(), ol.pf_predict(n, [1.5, -2.0, 0.7], [0.25, 0.25, (np.pi / 6) ** 2], nrm))
+    d_m = torch.from_numpy(poses).cuda()
+    torch.cuda.synchronize()
+    capi.pf_motion(ctx, n, [0.31, -0.04, 0.11], [0.04, 0.04, 0.035], d_n, d_m)
+    ctx.sync()
+    assert np.array_equal(d_m.cpu().numpy(), ol.pf_motion(poses, [0.31, -0.04, 0.11], [0.04, 0.04, 0.035], nrm))
     d_q = torch.from_numpy(poses).cuda()
     torch.cuda.synchronize()
     capi.pf_roughen(ctx, n, 0.2, d_n, d_q)

@@ -64,6 +64,12 @@ def test_topk_estimate_predict_roughen():
     nrm = rng.normal(size=(500, 3)).astype(np.float32)
     pp = ol.pf_predict(500, [1, 2, 0.5], [0.25, 0.25, 0.27], nrm)
     assert np.allclose(pp, np.array([1, 2, 0.5]) + nrm * [0.25, 0.25, 0.27], atol=1e-6)
+    mm = ol.pf_motion(poses, [0.3, -0.1, 0.2], [0.05, 0.05, 0.02], nrm)
+    inc = np.array([0.3, -0.1, 0.2]) + nrm * [0.05, 0.05, 0.02]
+    c, s_ = np.cos(poses[:, 2].astype(np.float64)), np.sin(poses[:, 2].astype(np.float64))
+    want = np.stack([poses[:, 0] + inc[:, 0] * c - inc[:, 1] * s_, poses[:, 1] + inc[:, 0] * s_ + inc[:, 1] * c,
+                     np.arctan2(np.sin(poses[:, 2] + inc[:, 2]), np.cos(poses[:, 2] + inc[:, 2]))], 1)
+    assert np.allclose(mm, want, atol=2e-6)
     rr = ol.pf_roughen(poses, 0.2, nrm)
     rootq = (poses.max(0).astype(np.float64) - poses.min(0)) * 0.2 * 500 ** (-1 / 3)
     assert np.allclose(rr, poses + nrm * rootq, atol=1e-6)

@@ -86,3 +86,23 @@ int main() {
     a = subprocess.run([ours], capture_output=True, text=True, timeout=60)
     b = subprocess.run([theirs], capture_output=True, text=True, timeout=60)
     assert a.returncode == 0 and a.stdout == b.stdout and a.stdout.count("\n") == 2
+
+
+def test_pf_localization_main_compiles_and_links(tmp_path):
+    """src/pf_localization_main.cpp (MRPT's pf-localization application) compiles unchanged against
+    the MRPT-shaped facade laser_slam_amd/host/mrptpf and links with the product libraries; tests/test_gpu_mrptpf.py
+    runs the binary the oracle Makefile builds the same way."""
+    if not os.path.exists(os.path.join(REF, "pf_localization_main.cpp")):
+        pytest.skip("pf_localization_main.cpp not in the reference tree")
+    shutil.copy(os.path.join(REF, "pf_localization_main.cpp"), tmp_path / "pf_localization_main.cpp")
+    exe = str(tmp_path / "pf_localization")
+    _cc(["-I", os.path.join(HOST, "mrptpf"), "-I", os.path.join(ROOT, "include"), "pf_localization_main.cpp", "-o", exe,
+         "-L", LIBDIR, "-llsa_host", "-llsa_core", "-Wl,-rpath," + LIBDIR], tmp_path)
+    assert os.path.exists(exe)
+    # the copy in src/mrptpf differs from it in one comment only and compiles the same way
+    twin = os.path.join(REF, "mrptpf", "pf_localization_main.cpp")
+    if os.path.exists(twin):
+        d = tmp_path / "twin"
+        d.mkdir()
+        shutil.copy(twin, d / "pf_localization_main.cpp")
+        _cc(["-fsyntax-only", "-I", os.path.join(HOST, "mrptpf"), "-I", os.path.join(ROOT, "include"), "pf_localization_main.cpp"], d)
