@@ -12,7 +12,7 @@ secondary entry over `torch.distributed` (RCCL) with 2^20 particles per rank.
 
 Prints ONE JSON line (rank 0): the contract's fields, `roofline` for the dominant kernel (icp_kernel is bound by
 vector-instruction issue: instructions per pair from the committed PMC pass x pairs/s against 256 CUs x 4 SIMDs x
-2.4 GHz / 4; the HBM figure of SURVEY.md 8d beside it), `secondary` (the other kernels of the path, each with its own
+2.4 GHz / 2; the HBM figure of SURVEY.md 8d beside it), `secondary` (the other kernels of the path, each with its own
 roofline) and `cpu_baseline` (the reference built in place when oracle/_ref travelled, else the oracle port: single
 thread and all host cores, bounded samples, timed before the GPU is touched).
 """
@@ -32,7 +32,9 @@ sys.path.insert(0, ROOT)
 
 BYTES_PER_PAIR = 2 * 1081 * 4 + 12 + 20      # 8 680 B per 1081-beam pair
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec
-VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4.0       # wave64 instructions/s: 256 CUs x 4 SIMDs, one per 4 cycles at 2.4 GHz
+# wave64 vector instructions/s: 256 CUs x 4 SIMD-32 units, a single-precision instruction every 2 cycles when at least two
+# waves of a SIMD are ready (MI355X_MICROARCH.md: `v_fma_f32` 2 cyc, one wave alone 4; transcendentals 8), at 2.4 GHz
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0
 FP32_PEAK_TFLOPS = 157.3
 PROFILE_ROUND = "r02"
 N_BASE, SEEDS = 200, 8
@@ -212,8 +214,11 @@ def valu_roofline(kernel, units_per_s, kernel_ms, units_per_launch, alg_bytes_pe
          "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                  "bytes_per_unit": alg_bytes_per_unit},
          "note": "vector-instruction-issue bound (DESIGN.md 4.1): achieved = wave64 VALU instructions per unit (rocprofv3 "
-                 "SQ_INSTS_VALU, profiles/%s_pmc_sq_counters.json) x units/s measured here; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4; "
-                 "valu_busy_frac = share of issue slots busy at the clock the chip held; hbm = algorithmic bytes of SURVEY 8d" % PROFILE_ROUND}
+                 "SQ_INSTS_VALU, profiles/%s_pmc_sq_counters.json) x units/s measured here; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 "
+                 "cycles per single-precision instruction (the mix here also holds double-precision and transcendental "
+                 "instructions that take 4 and 8, and a lone ready wave issues every 4); valu_busy_frac = rocprof's VALUBusy, "
+                 "SQ_ACTIVE_INST_VALU quad-cycles over the SIMDs' quad-cycles at the clock the chip held; hbm = algorithmic "
+                 "bytes of SURVEY 8d" % PROFILE_ROUND}
     if extra:
         r.update(extra)
     return r

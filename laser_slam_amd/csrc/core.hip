@@ -63,6 +63,8 @@ struct lsa_ctx {
     size_t arena_cap = 0;
     char* d_scratch = nullptr;   // grow-only scratch of the calls that need large temporaries (a context serves one thread)
     size_t scratch_cap = 0;
+    float* d_icp_ref = nullptr;        // pm_icp: one slot of reference points per resident workgroup (icp_ref_slot_bytes)
+    size_t icp_ref_cap = 0;
     unsigned int* d_queue = nullptr;   // pair counter of the matchers' work queue (zeroed before each launch)
     int n_cu = 0;
     int occ_icp = 0, occ_psm = 0;      // workgroups per CU of the matcher kernels for the current laser (0 = not asked yet)
@@ -78,7 +80,10 @@ static lsa::DevParam dev_param(const lsa_ctx* c)
     return P;
 }
 
-static int icp_lds(int n) { return lsa::icp_lds_bytes(n); }
+#ifndef LSA_ICP_LDS_PAD
+#define LSA_ICP_LDS_PAD 0          // occupancy experiments only (tools/README.md)
+#endif
+static int icp_lds(int n, bool ref_global) { return lsa::icp_lds_bytes(n, ref_global) + LSA_ICP_LDS_PAD; }
 static int psm_lds(int n) { return lsa::psm_lds_bytes(n); }
 static int pre_lds(int n) { int Np = (n + 63) & ~63; return 12 * Np; }
 
@@ -374,6 +379,7 @@ void lsa_ctx_destroy(lsa_ctx* c)
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     hipFree(c->d_tab);
     hipFree(c->d_queue);
+    if (c->d_icp_ref) hipFree(c->d_icp_ref);
     if (c->d_trig) hipFree(c->d_trig);
     if (c->d_stage) hipFree(c->d_stage);
     if (c->h_stage) hipHostFree(c->h_stage);
@@ -499,10 +505,21 @@ int lsa_match_batch(lsa_ctx* c, int which, int B,
     HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned int), c->stream));
     if (which == LSA_MATCH_ICP) {
 #define LSA_LAUNCH_ICP(NC) do { \
-        if (!c->occ_icp) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_icp, lsa::icp_kernel<NC>, lsa::ICP_THREADS, icp_lds(P.n))); \
+        const bool refg = lsa::icp_ref_global(NC); \
+        if (!c->occ_icp) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_icp, lsa::icp_kernel<NC>, lsa::ICP_THREADS, icp_lds(P.n, refg))); \
         const long long resident = (long long)(c->occ_icp > 0 ? c->occ_icp : 1) * c->n_cu; \
-        hipLaunchKernelGGL(lsa::icp_kernel<NC>, dim3((unsigned)(B < resident ? B : resident)), dim3(lsa::ICP_THREADS), icp_lds(P.n), c->stream, P, B, d_r, \
-                           d_bad, d_seg, d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters, c->d_queue); } while (0)
+        const unsigned grid = (unsigned)(B < resident ? B : resident); \
+        const size_t need = lsa::icp_ref_slot_bytes(P.n, refg) * grid; \
+        if (need > c->icp_ref_cap) { \
+            HIP_TRY(hipStreamSynchronize(c->stream)); \
+            if (c->d_icp_ref) HIP_TRY(hipFree(c->d_icp_ref)); \
+            c->d_icp_ref = nullptr; c->icp_ref_cap = 0; \
+            HIP_TRY(hipMalloc((void**)&c->d_icp_ref, lsa::icp_ref_slot_bytes(P.n, refg) * (size_t)resident)); \
+            c->icp_ref_cap = lsa::icp_ref_slot_bytes(P.n, refg) * (size_t)resident; \
+        } \
+        hipLaunchKernelGGL(lsa::icp_kernel<NC>, dim3(grid), dim3(lsa::ICP_THREADS), icp_lds(P.n, refg), c->stream, P, B, d_r, \
+                           d_bad, d_seg, d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters, c->d_queue, \
+                           (float2*)c->d_icp_ref); } while (0)
         switch (P.n) {          // the reference's presets (PolarParameter.h:75-83) and the 1081-beam benchmark sensor
         case 181:  LSA_LAUNCH_ICP(181); break;
         case 361:  LSA_LAUNCH_ICP(361); break;

@@ -1,17 +1,18 @@
 // pm_icp (src/zhpsm/ZHPolar_Match.cpp:1653-2021) on gfx950, included from
 // match_kernels.hip inside namespace lsa.
 //
-// One 256-thread workgroup (4 waves) per scan pair, 6 workgroups per CU at 1081 beams:
+// One 256-thread workgroup (4 waves) per scan pair, 8 workgroups per CU (the hardware's limit of 8 waves per SIMD):
 //  - order-free phases (projection, scatter-min, nearest neighbour, interpolation,
 //    products) use all 256 lanes;
 //  - order-bound phases (list compaction, the ordered FP32 sums of the rigid fit) run in wave 0 while
 //    the other waves of the pair wait at a barrier and the CU's other pairs fill the SIMDs.
 //
-// LDS (bytes, Np = N rounded up to 64; 26 656 B at N = 1081 -> 6 pairs per CU):
-//   [ 0   , 8Np)  ref_xy   float2 (reference scan, Cartesian; ranges for the error index)
-//   [ 8Np ,16Np)  K        u64 scatter-min keys -> per-beam NN record -> match list (in place)
+// LDS (bytes, Np = N rounded up to 64; 17 952 B at N = 1081 -> 8 pairs per CU):
+//   [ 0   , 8Np)  ref_xy   float2 (reference scan, Cartesian; ranges for the error index) - up to 541 beams only;
+//                          beyond that the points live in the workgroup's slot of a global scratch (icp_ref_global)
+//   [ ..  , +8Np) K        u64 scatter-min keys -> per-beam NN record -> match list (in place)
 //                          -> the ordered lists nx | ny of the rigid fit (Np floats each), later two product lists
-//   [16Np ,16Np+DB) D      pr,pf of the projection (NN reads them as search centre)
+//   [ ..  , +DB)  D        pr,pf of the projection (NN reads them as search centre)
 //                          -> trim pools and scratch -> owner (u32 per reference beam)
 //                          -> the ordered lists ix | iy, later two product lists, + the first `drop` pairs' beams
 //                             (what :2015-2020 needs after the lists have replaced the match list)
@@ -74,20 +75,33 @@ __host__ __device__ inline int icp_mask_bytes(int n)
     int Np = (n + 63) & ~63;
     return (Np / 8 + 8 + 15) & ~15;            // one bit per ray + one spare word for two-word windows
 }
-__host__ __device__ inline int icp_lds_bytes(int n)
+// Where the reference scan's points live.  In LDS (8 Np bytes) as long as eight workgroups still fit a CU (up to 541
+// beams); beyond that in the workgroup's slot of a global scratch array - written once per pair, read through L1 / L2 by
+// the nearest-neighbour search and the interpolation: at 1081 beams that costs 3.4 % at equal occupancy and buys eight
+// workgroups per CU instead of six (+7.7 %; 3 / 4 / 5 / 6 per CU run at 0.61 / 0.77 / 0.90 / 1.00 of six).  The
+// size-generic instance (NC = 0) always uses the slot, so that the address space is fixed at compile time.
+__host__ __device__ inline int icp_lds_bytes(int n, bool ref_global)
 {
     int Np = (n + 63) & ~63;
-    return 16 * Np + icp_d_bytes(n) + (icp_lists_separate(n) ? 12 * Np : 0) + 256 + 2 * icp_mask_bytes(n);
+    return (ref_global ? 8 : 16) * Np + icp_d_bytes(n) + (icp_lists_separate(n) ? 12 * Np : 0) + 256 + 2 * icp_mask_bytes(n);
 }
+__host__ __device__ constexpr bool icp_ref_global(int nc) { return nc == 0 || nc > 541; }
+// bytes of one workgroup's slot in the global scratch
+__host__ __device__ inline size_t icp_ref_slot_bytes(int n, bool ref_global) { return ref_global ? (size_t)8 * ((n + 63) & ~63) : 0; }
 
-__device__ __forceinline__ Lds carve_icp(char* base, int n)
+__device__ __forceinline__ Lds carve_icp(char* base, int n, bool ref_global, float2* g_ref_slot)
 {
     const int Np = (n + 63) & ~63;
     Lds L = {};
-    L.ref_xy = (float2*)base;
-    L.ref_r = (float*)base;
-    L.key = (unsigned long long*)(base + 8 * Np);
-    char* d = base + 16 * Np;
+    if (ref_global) {
+        L.ref_xy = g_ref_slot;                      // global: ref_r stays null (the error index reads the ranges from HBM)
+    } else {
+        L.ref_xy = (float2*)base;
+        L.ref_r = (float*)base;
+        base += 8 * Np;
+    }
+    L.key = (unsigned long long*)base;
+    char* d = base + 8 * Np;
     L.pr = (float*)d;
     L.pf = (float*)(d + 4 * Np);
     const int kmax = (int)((double)n * 0.2) + 1;
@@ -398,7 +412,12 @@ __device__ __forceinline__ int block_rank(bool flag, int& total, int* wcnt, int&
 
 // #{p < min(limit,cnt) : row[p] > d} + #{limit <= p < cnt : row[p] >= d}.
 // Distances are >= 0, so the IEEE bit patterns order like the values and ">= d" is
-// "> bits(d) - 1" on the signed patterns; rows are padded to a multiple of 4 with -1.
+// "> bits(d) - 1" on the signed patterns; rows are padded to a multiple of 4 with the bit pattern -1.
+// 1 if v > t, for bit patterns v in [-1, 0x7f800000] and thresholds t in [-1, 0x7f800000]: the difference cannot overflow,
+// so its sign bit is the comparison.  A subtraction, a shift and an addition issue at the full vector rate on gfx950;
+// v_cmp + v_addc_co, what `c += v > t` compiles to, at half of it (tools/micro/valu_issue.hip).
+__device__ __forceinline__ int gt_bit(int v, int t) { return (int)(((uint32_t)t - (uint32_t)v) >> 31); }   // (unsigned: a signed difference is folded back into a compare)
+
 __device__ __forceinline__ int count_split(const float* row, int cnt, float d, int limit)
 {
     const int4* r4 = (const int4*)row;
@@ -408,7 +427,7 @@ __device__ __forceinline__ int count_split(const float* row, int cnt, float d, i
     #pragma unroll 4
     for (; qd < qa; ++qd) {
         const int4 v = r4[qd];
-        c += (v.x > t1) + (v.y > t1) + (v.z > t1) + (v.w > t1);
+        c += gt_bit(v.x, t1) + gt_bit(v.y, t1) + gt_bit(v.z, t1) + gt_bit(v.w, t1);
     }
     if (qd < nq && (limit & 3)) {                        // the quad that straddles `limit`
         const int4 v = r4[qd];
@@ -422,12 +441,12 @@ __device__ __forceinline__ int count_split(const float* row, int cnt, float d, i
     #pragma unroll 4
     for (; qd < nq; ++qd) {
         const int4 v = r4[qd];
-        c += (v.x > t2) + (v.y > t2) + (v.z > t2) + (v.w > t2);
+        c += gt_bit(v.x, t2) + gt_bit(v.y, t2) + gt_bit(v.z, t2) + gt_bit(v.w, t2);
     }
     return c;
 }
 
-// #{from <= p < cnt : row[p] >= d} for d >= 0 (rows are padded to a multiple of 4 with -1)
+// #{from <= p < cnt : row[p] >= d} for d >= 0 (rows are padded to a multiple of 4 with the bit pattern -1)
 __device__ __forceinline__ int count_ge_from(const float* row, int cnt, float d, int from)
 {
     const int4* r4 = (const int4*)row;
@@ -445,7 +464,7 @@ __device__ __forceinline__ int count_ge_from(const float* row, int cnt, float d,
     #pragma unroll 4
     for (; qd < nq; ++qd) {
         const int4 v = r4[qd];
-        c += (v.x > t2) + (v.y > t2) + (v.z > t2) + (v.w > t2);
+        c += gt_bit(v.x, t2) + gt_bit(v.y, t2) + gt_bit(v.z, t2) + gt_bit(v.w, t2);
     }
     return c;
 }
@@ -471,7 +490,7 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt STAMP_ARGS)
         const unsigned long long rec = tid < k ? A[tid] : 0ull;
         const float d = rec_d(rec);
         if (tid < k) cd[tid] = d;
-        if (tid < 4 && k + tid < ((k + 3) & ~3)) cd[k + tid] = -1.0f;
+        if (tid < 4 && k + tid < ((k + 3) & ~3)) ((int*)cd)[k + tid] = -1;
         __syncthreads();
         const int seg = k - 64 * wave < 64 ? k - 64 * wave : 64;        // records of this wave (may be <= 0)
         int rank = 0;
@@ -511,7 +530,7 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt STAMP_ARGS)
         SUBSTAMP(14, (float)cpos);
         if (q == 0) { if (valid) A[t - k] = rec; continue; }
         if (cand) cd[cpos] = d;
-        if (tid < 4 && q + tid < ((q + 3) & ~3)) cd[q + tid] = -1.0f;      // pad the row
+        if (tid < 4 && q + tid < ((q + 3) & ~3)) ((int*)cd)[q + tid] = -1;      // pad the row (bit pattern -1: see gt_bit)
         int g1 = 0;                                  // pool records strictly greater
         if (cand) {
             int lo = 0, hi = k;
@@ -532,7 +551,7 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt STAMP_ARGS)
         if (valid && !ent) A[t - k] = rec;           // passes straight through
         if (E == 0) continue;
         if (ent) ce[epos] = d;
-        if (tid < 4 && E + tid < ((E + 3) & ~3)) ce[E + tid] = -1.0f;
+        if (tid < 4 && E + tid < ((E + 3) & ~3)) ((int*)ce)[E + tid] = -1;
         const unsigned long long pv = tid < k ? Pc[tid] : 0ull;            // this thread's pool record
         __syncthreads();
         // rank of this thread's record among the entering ones (greater key first) ...
@@ -601,9 +620,9 @@ __device__ __noinline__ void icp_error_tail(DevParam P, const float* g_ref_row, 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (NC > 0) P.n = NC;
     const int N = P.n;
-    Lds L = carve_icp(smem, N);
+    Lds L = carve_icp(smem, N, icp_ref_global(NC), nullptr);
     L.g_act_r = g_act_row; L.g_ref_r = g_ref_row;
-    for (int i = threadIdx.x; i < N; i += ICP_THREADS) L.ref_r[i] = g_ref_row[i];      // ref_xy is no longer needed
+    if (L.ref_r) for (int i = threadIdx.x; i < N; i += ICP_THREADS) L.ref_r[i] = g_ref_row[i];      // ref_xy is no longer needed
     __syncthreads();
     scan_project(P, L, ex, ey, eth);
     error_index2_tail(P, L, exy, n_assoc);
@@ -611,28 +630,24 @@ __device__ __noinline__ void icp_error_tail(DevParam P, const float* g_ref_row, 
 
 // ---------------------------------------------------------------------------
 #ifndef LSA_ICP_WG_PER_CU
-#define LSA_ICP_WG_PER_CU 6
+#define LSA_ICP_WG_PER_CU 8
 #endif
 // NC > 0: the beam count as a compile-time constant (the sensors' usual sizes), so that the LDS
 // layout and the trip counts are immediates instead of scalar registers; NC = 0: any size.
+// eight workgroups per CU (64 registers, some twenty spilled): the register cap alone costs 1.3 % against 80 registers
 template <int NC>
-// up to 541 beams the LDS would allow more workgroups per CU than 96 registers do: eight (64 registers, some spills)
-// measured 9-14 % faster than five at 181 / 361 / 541 beams
-#ifndef LSA_ICP_WG_PER_CU_SMALL
-#define LSA_ICP_WG_PER_CU_SMALL 8
-#endif
-__global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PER_CU_SMALL) : (LSA_ICP_WG_PER_CU)) void icp_kernel(
+__global__ __launch_bounds__(ICP_THREADS, LSA_ICP_WG_PER_CU) void icp_kernel(
     DevParam P_, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
     const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
     const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
     float* __restrict__ err_xy, int* __restrict__ n_assoc, int* __restrict__ status_out, int* __restrict__ iters_out,
-    unsigned int* __restrict__ queue)
+    unsigned int* __restrict__ queue, float2* __restrict__ ref_scratch)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevParam P = P_;
     if (NC > 0) P.n = NC;
     const int N = P.n, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    Lds L = carve_icp(smem, N);
+    Lds L = carve_icp(smem, N, icp_ref_global(NC), icp_ref_global(NC) ? ref_scratch + (size_t)blockIdx.x * ((N + 63) & ~63) : nullptr);
     int* imisc = (int*)L.misc;              // [0] n
     float* fmisc = L.misc + 8;      // [0..3] means  [4..7] covariances
     // ordered value lists (SoA): nx | ny in the K region, ix | iy in the D region, later the four product lists
