@@ -1,13 +1,13 @@
 // pm_icp (src/zhpsm/ZHPolar_Match.cpp:1653-2021) on gfx950, included from
 // match_kernels.hip inside namespace lsa.
 //
-// One 256-thread workgroup (4 waves) per scan pair, 8 workgroups per CU (the hardware's limit of 8 waves per SIMD):
+// One 256-thread workgroup (4 waves) per scan pair, 7 workgroups per CU at 1081 beams (8 up to 541):
 //  - order-free phases (projection, scatter-min, nearest neighbour, interpolation,
 //    products) use all 256 lanes;
 //  - order-bound phases (list compaction, the ordered FP32 sums of the rigid fit) run in wave 0 while
 //    the other waves of the pair wait at a barrier and the CU's other pairs fill the SIMDs.
 //
-// LDS (bytes, Np = N rounded up to 64; 17 952 B at N = 1081 -> 8 pairs per CU):
+// LDS (bytes, Np = N rounded up to 64; 17 952 B at N = 1081: the registers, not the LDS, set 7 pairs per CU):
 //   [ 0   , 8Np)  ref_xy   float2 (reference scan, Cartesian; ranges for the error index) - up to 541 beams only;
 //                          beyond that the points live in the workgroup's slot of a global scratch (icp_ref_global)
 //   [ ..  , +8Np) K        u64 scatter-min keys -> per-beam NN record -> match list (in place)
@@ -77,8 +77,8 @@ __host__ __device__ inline int icp_mask_bytes(int n)
 }
 // Where the reference scan's points live.  In LDS (8 Np bytes) as long as eight workgroups still fit a CU (up to 541
 // beams); beyond that in the workgroup's slot of a global scratch array - written once per pair, read through L1 / L2 by
-// the nearest-neighbour search and the interpolation: at 1081 beams that costs 3.4 % at equal occupancy and buys eight
-// workgroups per CU instead of six (+7.7 %; 3 / 4 / 5 / 6 per CU run at 0.61 / 0.77 / 0.90 / 1.00 of six).  The
+// the nearest-neighbour search and the interpolation: at 1081 beams that costs 3.4 % at equal occupancy and buys seven
+// workgroups per CU instead of six (+6.6 %; 3 / 4 / 5 / 6 per CU run at 0.61 / 0.77 / 0.90 / 1.00 of six).  The
 // size-generic instance (NC = 0) always uses the slot, so that the address space is fixed at compile time.
 __host__ __device__ inline int icp_lds_bytes(int n, bool ref_global)
 {
@@ -629,14 +629,19 @@ __device__ __noinline__ void icp_error_tail(DevParam P, const float* g_ref_row, 
 }
 
 // ---------------------------------------------------------------------------
+// workgroups per CU the registers are budgeted for: eight (64 registers) up to 541 beams, seven (72 registers) beyond.
+// At 1081 beams eight per CU are 1 % faster than seven, but their spilled registers are reloaded inside the iteration
+// loop and, with the larger scratch footprint, miss the L2: 293 KB of counter traffic per pair instead of 48 KB.
 #ifndef LSA_ICP_WG_PER_CU
-#define LSA_ICP_WG_PER_CU 8
+#define LSA_ICP_WG_PER_CU 7
+#endif
+#ifndef LSA_ICP_WG_PER_CU_SMALL
+#define LSA_ICP_WG_PER_CU_SMALL 8
 #endif
 // NC > 0: the beam count as a compile-time constant (the sensors' usual sizes), so that the LDS
 // layout and the trip counts are immediates instead of scalar registers; NC = 0: any size.
-// eight workgroups per CU (64 registers, some twenty spilled): the register cap alone costs 1.3 % against 80 registers
 template <int NC>
-__global__ __launch_bounds__(ICP_THREADS, LSA_ICP_WG_PER_CU) void icp_kernel(
+__global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PER_CU_SMALL) : (LSA_ICP_WG_PER_CU)) void icp_kernel(
     DevParam P_, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
     const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
     const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
