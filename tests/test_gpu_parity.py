@@ -688,6 +688,16 @@ def test_orientation_search_block_edges(beams, window, torch_mod):
                 if want[0] == 0:
                     assert np.float32(got[1]).tobytes() == np.float32(want[1]).tobytes(), (beams, s, sparse, got, want)
                 checked += 1
+    # ranges beyond 2^19 cm: the search leaves its clamp form (terms would no longer stay below 1 after scaling)
+    ref_r, ref_bad, _ = o.preprocess(raw[1])
+    big_ref = (ref_r * np.float32(1000.0)).astype(np.float32)
+    big_new = (np.roll(big_ref, -3) + rng.normal(0, 500.0, beams)).astype(np.float32)
+    assert big_ref[ref_bad == 0].max() > 2.0 ** 19
+    want = o.orientation_search(big_ref, ref_bad, big_new, np.roll(ref_bad, -3).astype(np.int32))
+    got = ctx.orientation_search_host(big_ref, ref_bad, big_new, np.roll(ref_bad, -3).astype(np.int32))
+    assert (got[0] != 0) == (want[0] != 0)
+    if want[0] == 0:
+        assert np.float32(got[1]).tobytes() == np.float32(want[1]).tobytes()
     # nothing valid on one side: no orientation
     ref_r, ref_bad, _ = o.preprocess(raw[0])
     allbad = np.ones(beams, np.int32)
