@@ -377,6 +377,7 @@ def main():
             sec.update(sec_pf)
             if world == 1:
                 sec.update(secondary_grid(torch, capi, ctx, raw, p))
+                sec.update(secondary_logs(torch, capi))
     if rank == 0:
         out["secondary"] = sec
         if cpu is not None:
@@ -438,6 +439,39 @@ def secondary_matchers(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, which
     res["preprocess"] = {"value": Sp / (ms * 1e-3), "unit": "scans/s", "scans": Sp,
                          "roofline": hbm_roofline("preprocess_lanes_kernel", Sp * n * 12.0, ms, Sp,
                                                   "12 B per beam: ranges read and written, flags read and written, segments written")}
+    return res
+
+
+def secondary_logs(torch, capi, pairs=1 << 17):
+    """Both matchers on the heads of the reference's own logs (tests/golden/*_head.log, consecutive scans, zero prior),
+    each head's pairs repeated to `pairs` per launch: real scans need more iterations than the synthetic set and have a
+    third to a half of its beams."""
+    res = {}
+    for name, preset, fname, tag in (("fr079", "LMS511", "fr079_head.log", "ROBOTLASER1"), ("intel", "LMS211", "intel_head.log", "ROBOTLASER1"),
+                                     ("mit", "LMS511", "mit_head.log", "ROBOTLASER1")):
+        path = os.path.join(ROOT, "tests", "golden", fname)
+        if not os.path.exists(path):
+            continue
+        p = capi.param_preset(preset)
+        r, _, _, bad, _ = capi.carmen_read(p, path, tag)
+        S, n = r.shape
+        ctx = capi.Context(p)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)        # (so that torch's events bracket the kernels)
+        d_r = torch.from_numpy(r).cuda(); d_bad = torch.from_numpy(bad.astype(np.uint8)).cuda()
+        d_seg = torch.zeros(S, n, dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        ctx.preprocess_batch(S, d_r, d_bad, d_seg)
+        idx = (np.arange(pairs) % (S - 1)).astype(np.int32)
+        d_ri = torch.from_numpy(idx).cuda(); d_ai = d_ri + 1
+        pose = torch.zeros(pairs, 3, device="cuda"); st = torch.zeros(pairs, dtype=torch.int32, device="cuda")
+        it = torch.zeros(pairs, dtype=torch.int32, device="cuda")
+        entry = {"beams": n, "scans": S, "pairs": pairs}
+        for which, nm in ((capi.MATCH_ICP, "pm_icp"), (capi.MATCH_PSM, "pm_psm")):
+            ms = timed(torch, lambda: ctx.match_batch(which, pairs, d_r, d_bad, d_seg, d_ri, d_ai, pose, d_status=st, d_iters=it), reps=1)
+            entry[nm] = {"value": pairs / (ms * 1e-3), "unit": "scan-matches/s", "mean_iterations": float(it.float().mean().item()),
+                         "failed_fraction": float((st != 0).float().mean().item())}
+        ctx.close()
+        res["logs_" + name] = entry
     return res
 
 
