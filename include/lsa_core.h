@@ -148,7 +148,12 @@ int lsa_preprocess_stages_batch(lsa_ctx* c, int n_scans, float* d_r, uint8_t* d_
  * (x,y,th) in cm/rad, or NULL for all-zero (what FMatch uses, :97-99).
  * Outputs (any may be NULL except d_pose_out): pose [B][3] = lsa->rx,ry,th;
  * ret [B] = matcher return value; err_xy [B][2] + n_assoc [B] = pm_error_index2 at
- * the result; status [B]; iters [B]. */
+ * the result; status [B]; iters [B].
+ * One launch per call: as many workgroups as the device holds at once claim the pairs from a counter, so any
+ * n_pairs is one launch and pairs of different iteration counts balance.  The context owns what the launch needs
+ * beside the arguments (the counter; for scans of more than 541 beams 8 B per beam and resident workgroup of pm_icp's
+ * reference points, 15 MB at 1081 beams); like every call on a context it is asynchronous on the context's stream
+ * and a context serves one host thread at a time. */
 int lsa_match_batch(lsa_ctx* c, int which, int n_pairs,
                     const float* d_r, const uint8_t* d_bad, const uint16_t* d_seg,
                     const int32_t* d_ref_idx, const int32_t* d_act_idx,
