@@ -217,7 +217,7 @@ class Context:
 
     def __del__(self):
         # (not at interpreter shutdown: the HIP runtime may already be gone, and calling into it then aborts the process)
-        if sys.is_finalizing():
+        if sys is None or sys.is_finalizing():          # (module globals are cleared late in shutdown)
             return
         try:
             self.close()
@@ -348,7 +348,7 @@ class Grid:
 
     def __del__(self):
         # (not at interpreter shutdown: the HIP runtime may already be gone, and calling into it then aborts the process)
-        if sys.is_finalizing():
+        if sys is None or sys.is_finalizing():          # (module globals are cleared late in shutdown)
             return
         try:
             self.close()
@@ -413,7 +413,7 @@ class Field:
 
     def __del__(self):
         # (not at interpreter shutdown: the HIP runtime may already be gone, and calling into it then aborts the process)
-        if sys.is_finalizing():
+        if sys is None or sys.is_finalizing():          # (module globals are cleared late in shutdown)
             return
         try:
             self.close()
