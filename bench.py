@@ -18,6 +18,7 @@ thread and all host cores, bounded samples, timed before the GPU is touched).
 """
 import argparse
 import json
+import threading
 import os
 import socket
 import subprocess
@@ -368,16 +369,44 @@ def main():
                                        "effective_fp32_frac": flops_pair * B / (kernel_ms * 1e-3) / (FP32_PEAK_TFLOPS * 1e12)}),
         }
     # ---- secondary kernels of the path -------------------------------------------------------------------------
+    # The headline figure stands from here on.  With several ranks the particle-filter entry below runs collectives that
+    # this build container could never exercise on more than one GPU: a watchdog on every rank makes sure that a rank
+    # that raises or a collective that never returns costs that entry, not the line - after `deadline` seconds rank 0
+    # prints what it has and every rank leaves.
     sec = {}
+    printed = threading.Lock()
+
+    def emit_and_leave(note):
+        if rank == 0 and printed.acquire(blocking=False):
+            out["secondary"] = dict(sec, pf_step={"error": note})
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    watchdog = None
+    if world > 1 and not args.no_extras:
+        watchdog = threading.Timer(float(os.environ.get("LSA_BENCH_SECONDARY_DEADLINE", "240")), emit_and_leave,
+                                   ("multi-rank secondary entries did not finish in time",))
+        watchdog.daemon = True
+        watchdog.start()
     if not args.no_extras:
         if rank == 0:
             sec.update(secondary_matchers(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, which, raw, n))
-        sec_pf = secondary_pf(torch, capi, ctx, dist, rank, world, raw, p, coll_dev)     # (all ranks: it has collectives)
+        try:
+            sec_pf = secondary_pf(torch, capi, ctx, dist, rank, world, raw, p, coll_dev)     # (all ranks: it has collectives)
+        except Exception as e:                              # (the other ranks' watchdogs release them from the collective)
+            if world == 1:
+                raise
+            sec_pf = {"pf_step": {"error": "%s: %s" % (type(e).__name__, e)}}
+            if rank != 0:
+                os._exit(0)
+            emit_and_leave(sec_pf["pf_step"]["error"])
         if rank == 0:
             sec.update(sec_pf)
             if world == 1:
                 sec.update(secondary_grid(torch, capi, ctx, raw, p))
                 sec.update(secondary_logs(torch, capi))
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
         out["secondary"] = sec
         if cpu is not None:
@@ -398,7 +427,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
+    if rank == 0 and printed.acquire(blocking=False):
         print(json.dumps(out), flush=True)
 
 
