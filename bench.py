@@ -194,6 +194,8 @@ def pmc_per_unit(kernel):
         if units:
             out["valu_instr_per_unit"] = rec["SQ_INSTS_VALU"] / units
         out["valu_busy_frac"] = rec["SQ_ACTIVE_INST_VALU"] / (rec["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0)
+        if rec.get("SQ_THREAD_CYCLES_VALU") and rec.get("SQ_INSTS_VALU"):
+            out["valu_lane_util"] = rec["SQ_THREAD_CYCLES_VALU"] / (rec["SQ_INSTS_VALU"] * 64.0)
     if hbm and key in hbm:
         rec = hbm[key]
         units = rec.get("units_per_launch") or rec.get("pairs_per_launch")
@@ -212,13 +214,15 @@ def valu_roofline(kernel, units_per_s, kernel_ms, units_per_launch, alg_bytes_pe
          "frac": ipu * units_per_s / 1e9 / VALU_PEAK_GINSTR if ipu else None,
          "traffic": pm["hbm_bytes_per_unit"] * units_per_launch if "hbm_bytes_per_unit" in pm else None,
          "kernel": kernel, "kernel_ms": kernel_ms, "valu_instr_per_unit": ipu, "valu_busy_frac": pm.get("valu_busy_frac"),
+         "valu_lane_util": pm.get("valu_lane_util"),
          "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                  "bytes_per_unit": alg_bytes_per_unit},
          "note": "vector-instruction-issue bound (DESIGN.md 4.1): achieved = wave64 VALU instructions per unit (rocprofv3 "
                  "SQ_INSTS_VALU, profiles/%s_pmc_sq_counters.json) x units/s measured here; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 "
                  "cycles per single-precision instruction (the mix here also holds double-precision and transcendental "
                  "instructions that take 4 and 8, and a lone ready wave issues every 4); valu_busy_frac = rocprof's VALUBusy, "
-                 "SQ_ACTIVE_INST_VALU quad-cycles over the SIMDs' quad-cycles at the clock the chip held; hbm = algorithmic "
+                 "SQ_ACTIVE_INST_VALU quad-cycles over the SIMDs' quad-cycles at the clock the chip held; valu_lane_util = active "
+                 "lanes per vector instruction / 64 (SQ_THREAD_CYCLES_VALU); hbm = algorithmic "
                  "bytes of SURVEY 8d" % PROFILE_ROUND}
     if extra:
         r.update(extra)
