@@ -1512,7 +1512,10 @@ static int plicp_launch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const float
             done.fetch_or(bit, std::memory_order_release);
         }
     }
-    hipLaunchKernelGGL((lsa::plicp_kernel<WG, COV>), dim3(B), dim3(lsa::PLICP_THREADS), lsa::plicp_lds_bytes(P.n), c->stream, P, B, d_r,
+#ifndef LSA_PLICP_LDS_PAD
+#define LSA_PLICP_LDS_PAD 0        // occupancy experiments only (tools/README.md)
+#endif
+    hipLaunchKernelGGL((lsa::plicp_kernel<WG, COV>), dim3(B), dim3(lsa::PLICP_THREADS), lsa::plicp_lds_bytes(P.n) + LSA_PLICP_LDS_PAD, c->stream, P, B, d_r,
                        d_ref_idx, d_act_idx, c->d_trig, d_out8, sigma, d_cov9);
     HIP_TRY(hipGetLastError());
     return LSA_OK;
