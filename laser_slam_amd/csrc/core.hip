@@ -353,7 +353,11 @@ int lsa_ctx_get_param(const lsa_ctx* c, lsa_laser_param* out)
 int lsa_ctx_set_stream(lsa_ctx* c, void* s)
 {
     if (!c) return fail(LSA_E_ARG, "null context");
-    if (c->own_stream && c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+    HIP_TRY(hipSetDevice(c->device));
+    // work queued on the old stream may still use the context's scratch (staging block, pair counter, arena): drain it
+    // before anything is queued on the new one
+    if (c->stream || c->own_stream) HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
     else {
         HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamDefault));
