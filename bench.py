@@ -620,8 +620,9 @@ def secondary_pf(torch, capi, ctx, dist, rank, world, raw, p, coll_dev):
                                    "frac": n_total * bytes_pp / dt / 1e9 / (HBM_PEAK_GBS * comm_ranks), "traffic": None, "kernel": "pf step (10 launches)",
                                    "kernel_ms": dt * 1e3,
                                    "note": "about 140 B of particle arrays per particle and step (predict, score, weights, fixed-point scan, "
-                                           "bounds, parents, gather, roughen) + the field gather; a host-synchronised sequence of short "
-                                           "launches and three small collectives, i.e. latency bound at this size"}}
+                                           "bounds, parents, gather, roughen) + the field gather; nine tenths of the step is the likelihood-"
+                                           "field scoring (score_poses above: a cache gather, not an HBM stream), the rest a host-synchronised "
+                                           "sequence of short launches and, with several ranks, three small collectives"}}
     fld.close(); grid.close()
     return res
 
