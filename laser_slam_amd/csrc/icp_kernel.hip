@@ -7,9 +7,10 @@
 //  - order-bound phases (list compaction, the ordered FP32 sums of the rigid fit) run in wave 0 while
 //    the other waves of the pair wait at a barrier and the CU's other pairs fill the SIMDs.
 //
-// LDS (bytes, Np = N rounded up to 64; 17 952 B at N = 1081: the registers, not the LDS, set 7 pairs per CU):
+// LDS (bytes, Np = N rounded up to 64; 22 304 B at N = 1081 -> 7 pairs per CU):
 //   [ 0   , 8Np)  ref_xy   float2 (reference scan, Cartesian; ranges for the error index) - up to 541 beams only;
 //                          beyond that the points live in the workgroup's slot of a global scratch (icp_ref_global)
+//   [ ..  , +4Np) act_r    the current scan's ranges (read by every phase of every iteration)
 //   [ ..  , +8Np) K        u64 scatter-min keys -> per-beam NN record -> match list (in place)
 //                          -> the ordered lists nx | ny of the rigid fit (Np floats each), later two product lists
 //   [ ..  , +DB)  D        pr,pf of the projection (NN reads them as search centre)
@@ -20,7 +21,7 @@
 //   [.. , +Np/8)  good: one bit per reference ray (ref_bad == 0)
 //   [.. , +Np/8)  pair_mask: one bit per beam (beams i-1,i form a valid pair)
 // Last iteration's match per beam (the NN seed) lives in registers: a thread always handles the
-// same beams.  The current scan's ranges stay in HBM/L2 (read coalesced once per phase).
+// same beams.
 
 constexpr int ICP_THREADS = 256;
 
@@ -83,7 +84,7 @@ __host__ __device__ inline int icp_mask_bytes(int n)
 __host__ __device__ inline int icp_lds_bytes(int n, bool ref_global)
 {
     int Np = (n + 63) & ~63;
-    return (ref_global ? 8 : 16) * Np + icp_d_bytes(n) + (icp_lists_separate(n) ? 12 * Np : 0) + 256 + 2 * icp_mask_bytes(n);
+    return (ref_global ? 12 : 20) * Np + icp_d_bytes(n) + (icp_lists_separate(n) ? 12 * Np : 0) + 256 + 2 * icp_mask_bytes(n);
 }
 __host__ __device__ constexpr bool icp_ref_global(int nc) { return nc == 0 || nc > 541; }
 // bytes of one workgroup's slot in the global scratch
@@ -100,6 +101,8 @@ __device__ __forceinline__ Lds carve_icp(char* base, int n, bool ref_global, flo
         L.ref_r = (float*)base;
         base += 8 * Np;
     }
+    L.act_r = (float*)base;                         // the current scan's ranges (every phase of every iteration reads them)
+    base += 4 * Np;
     L.key = (unsigned long long*)base;
     char* d = base + 8 * Np;
     L.pr = (float*)d;
@@ -675,6 +678,7 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
         for (int i = tid; i < N; i += ICP_THREADS) {
             float rr = g_r[ro + i];
             const uint8_t rb = g_bad[ro + i];
+            L.act_r[i] = g_r[ao + i];
             L.ref_xy[i] = rb == 0 ? make_float2(rr * P.co[i], rr * P.si[i]) : make_float2(REF_FAR, REF_FAR);      // :1710-1711
             bool ok = false;
             if (i >= 1) {
@@ -734,7 +738,7 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
                 for (int base = wave * WAVE, trip = 0; base < N; base += ICP_THREADS, ++trip) {
                     const int i0 = base + lane;
                     const bool lv0 = i0 < N && key_bad(L.key[i0 < N ? i0 : 0]) == 0;
-                    const float2 p0 = cur_point(P, L.g_act_r, i0 < N ? i0 : N - 1, co, si, ax, ay);
+                    const float2 p0 = cur_point(P, L.act_r, i0 < N ? i0 : N - 1, co, si, ax, ay);
                     const uint32_t jpw = trip < 2 ? jpk0 : (trip < 4 ? jpk1 : jpk2);
                     const int jp0 = (int)((trip & 1) ? jpw >> 16 : jpw & 0xffffu) - 1;   // -1 in the first iteration
                     NnBeam b0;
@@ -808,8 +812,8 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
                     const int k = k0 + u * ICP_THREADS + tid;
                     if (k < keep) {
                         const int i = ijs[u] & 0xffff, j = ijs[u] >> 16, io = ios[u];
-                        const float2 p = cur_point(P, L.g_act_r, i, co, si, ax, ay);
-                        const float2 po = io == i ? p : cur_point(P, L.g_act_r, io, co, si, ax, ay);
+                        const float2 p = cur_point(P, L.act_r, i, co, si, ax, ay);
+                        const float2 po = io == i ? p : cur_point(P, L.act_r, io, co, si, ax, ay);
                         const float2 q = interp_candidate(P, L, N, po, j);
                         Lnx[k] = p.x; Lny[k] = p.y; Lix[k] = q.x; Liy[k] = q.y;
                         if (k < drop) L.first_ij[k] = ijs[u];
@@ -861,7 +865,7 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
             float* resid = Lnx;                 // (the lists are dead by now)
             for (int k = tid; k < drop; k += ICP_THREADS) {
                 const uint32_t ij = L.first_ij[k];
-                const float2 p = cur_point(P, L.g_act_r, ij & 0xffff, fmisc[PS_PCO], fmisc[PS_PSI], fmisc[PS_PAX], fmisc[PS_PAY]);
+                const float2 p = cur_point(P, L.act_r, ij & 0xffff, fmisc[PS_PCO], fmisc[PS_PSI], fmisc[PS_PAX], fmisc[PS_PAY]);
                 const float2 c = interp_candidate(P, L, N, p, ij >> 16);
                 resid[k] = sqrtf((p.x - c.x) * (p.x - c.x) + (p.y - c.y) * (p.y - c.y));
             }
