@@ -706,3 +706,46 @@ def test_orientation_search_block_edges(beams, window, torch_mod):
     assert ctx.orientation_search_host(ref_r, allbad, ref_r, ref_bad)[0] != 0
     ctx.close()
     assert checked == 6 * len(shifts)
+
+
+def test_contexts_on_concurrent_host_threads(torch_mod):
+    """One matcher object per thread is the reference's threading model (threadLocal1.cpp:20,144): four host threads,
+    each with its own context (stream, pair counter, scratch), match the same batch at the same time with both matchers;
+    every thread gets the single-threaded result bit for bit."""
+    import threading
+    from laser_slam_amd import capi, synth
+    torch = torch_mod
+    raw = synth.make_scans(40, noise_seed=synth.WORLD_SEED + 9)[0]
+    p = capi.param_make(**synth.SYN1081)
+    S, n = raw.shape
+    B = 4096
+    idx = (np.arange(B) % (S - 1)).astype(np.int32)
+
+    def run(out, slot):
+        ctx = capi.Context(p)
+        d_r = torch.from_numpy(raw).cuda(); d_bad = torch.zeros(S, n, dtype=torch.uint8, device="cuda")
+        d_seg = torch.zeros(S, n, dtype=torch.int16, device="cuda")
+        ri = torch.from_numpy(idx).cuda(); ai = ri + 1
+        torch.cuda.synchronize()
+        ctx.preprocess_batch(S, d_r, d_bad, d_seg)
+        res = []
+        for which in (capi.MATCH_ICP, capi.MATCH_PSM):
+            pose = torch.zeros(B, 3, device="cuda"); st = torch.zeros(B, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            for _ in range(3):
+                ctx.match_batch(which, B, d_r, d_bad, d_seg, ri, ai, pose, d_status=st)
+            ctx.sync()
+            res.append((pose.cpu().numpy().copy(), st.cpu().numpy().copy()))
+        ctx.close()
+        out[slot] = res
+
+    ref = [None]
+    run(ref, 0)
+    outs = [None] * 4
+    threads = [threading.Thread(target=run, args=(outs, k)) for k in range(4)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    for res in outs:
+        assert res is not None
+        for (pose, st), (pose0, st0) in zip(res, ref[0]):
+            assert np.array_equal(st, st0) and np.array_equal(pose.view(np.uint32), pose0.view(np.uint32))
