@@ -159,18 +159,6 @@ int lsa_debug_bad_index(unsigned int* out4)
 }
 #endif
 
-#ifdef LSA_ORIENT_STATS
-// diagnostic build only: read and reset the counters of the bounded orientation search
-int lsa_debug_orient_stats(unsigned long long* out8)
-{
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(lsa::lsa_orient_stats), sizeof(unsigned long long) * 8));
-    unsigned long long z[8] = {0};
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lsa::lsa_orient_stats), z, sizeof z));
-    return LSA_OK;
-}
-#endif
-
 const char* lsa_version(void) { return "laser_slam_amd 0.2 (gfx950)"; }
 
 const char* lsa_last_error(void) { return g_err.c_str(); }

@@ -104,9 +104,6 @@ __device__ __forceinline__ void orient_quad(float& e, const packed4f a, const LS
     e += fmaxf(fabsf_(d23.y), 0.0f);
 }
 
-#ifdef LSA_ORIENT_STATS
-__device__ unsigned long long lsa_orient_stats[8];   // searches, bounded blocks, abandoned, chunks run, chunks possible, refits
-#endif
 // number of valid terms of shift k: popcount of the new scan's mask against the reference mask moved by k
 __device__ __forceinline__ int orient_count(const uint32_t* newm, const uint32_t* refm, int nw, int k)
 {
@@ -125,9 +122,6 @@ template <bool BOUNDED>
 __device__ __forceinline__ bool orient_sum(const float* nrm, const float* rb, int N4, float lim, float& e)
 {
     e = 0.0f;
-#ifdef LSA_ORIENT_STATS
-    if (BOUNDED && lane_id() == 0) { atomicAdd(&lsa_orient_stats[1], 1ull); atomicAdd(&lsa_orient_stats[4], (unsigned long long)(N4 >> 4)); }
-#endif
     // the lane's row offset goes through an opaque register: the reads of a chunk then differ by immediate offsets
     // only (folded into the row's constant LDS address they each cost an address addition)
     uint32_t bo = (uint32_t)(uintptr_t)(const LSA_LDS float*)rb;
@@ -141,10 +135,6 @@ __device__ __forceinline__ bool orient_sum(const float* nrm, const float* rb, in
         orient_quad(e, a[1], b + 4);
         orient_quad(e, a[2], b + 8);
         orient_quad(e, a[3], b + 12);
-#ifdef LSA_ORIENT_STATS
-        if (BOUNDED && lane_id() == 0) atomicAdd(&lsa_orient_stats[3], 1ull);
-        if (BOUNDED && !__ballot(e <= lim)) { if (lane_id() == 0) atomicAdd(&lsa_orient_stats[2], 1ull); return true; }
-#endif
         if (BOUNDED && !__ballot(e <= lim)) return true;
     }
     for (; i < N4; i += 4, b += 4, a += 1) orient_quad(e, a[0], b);
@@ -194,9 +184,6 @@ __device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, f
     const int n_new = wave_sum_i32(lane < nw ? __popc(newm[lane]) : 0);        // nw <= 64 (LSA_MAX_POINTS)
     __syncthreads();
     const float bound = bc[1];
-#ifdef LSA_ORIENT_STATS
-    if (tid == 0) atomicAdd(&lsa_orient_stats[0], 1ull);
-#endif
     const int m_lo = origin > 0 ? -((origin + 63) >> 6) : 0, m_hi = (K - 1 - origin) >> 6;
     const int rounds = 2 * (-m_lo > m_hi ? -m_lo : m_hi);
     for (int j = wave; j < rounds; j += nwaves) {               // blocks -1, +1, -2, +2, ...: nearest (longest) first
@@ -208,12 +195,7 @@ __device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, f
         // abandoning needs only an upper bound of the number of valid terms (the new scan's valid readings, n_new):
         // e > bound n_new (1 + 1e-6) >= bound c (1 + 1e-6).  A shift without valid terms has err = 10000 > bound
         // whenever bound < 10000; otherwise nothing is abandoned.  The exact counts are taken for finished blocks only.
-#ifdef LSA_ORIENT_EXACT_COUNT
-        const int c0 = orient_count(newm, refm, nw, kk);
-        const float lim = !(bound < 10000.0f) ? inf : (in && c0 > 0) ? bound * (float)c0 * 1.000001f : -1.0f;
-#else
         const float lim = !(bound < 10000.0f) ? inf : in ? bound * (float)n_new * 1.000001f : -1.0f;
-#endif
         float e;
         const bool abandoned = orient_sum<true>(nrm, rfm + kk, N4, lim, e);
         if (abandoned) { if (in) err[k] = ORIENT_ABANDONED; continue; }
@@ -241,9 +223,6 @@ __device__ int orientation_search(const DevParam& P, const Lds& L, float& dth, f
     if (imin >= 1 && imin < K - 1) {                                                  // :1244-1254
         if (err[imin - 1] < 0.0f || err[imin + 1] < 0.0f) {     // neighbour in an abandoned block: evaluate it fully
             __syncthreads();
-#ifdef LSA_ORIENT_STATS
-            if (tid == 0) atomicAdd(&lsa_orient_stats[5], 1ull);
-#endif
             if (wave == 0) {
                 const int k = lane == 0 ? imin - 1 : imin + 1;
                 const bool need = lane < 2 && err[k] < 0.0f;

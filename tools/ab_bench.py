@@ -31,7 +31,3 @@ for which, nm in ((1, "icp"), (0, "psm")):
     for _ in range(3): ctx.match_batch(which, B, d_r, d_bad, d_seg, ri, ai, pose)
     ctx.sync(); dt = (time.perf_counter() - t0) / 3
     print("%s %s: %.0f matches/s" % (" ".join(flags) or "base", nm, B / dt))
-    if which == 0 and hasattr(capi.lib(), "lsa_debug_orient_stats"):
-        import ctypes as C
-        buf = (C.c_ulonglong * 8)(); capi.lib().lsa_debug_orient_stats(buf)
-        print("orientation search: searches, bounded blocks, abandoned, chunks run, chunks possible, refits:", list(buf)[:6])
