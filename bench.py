@@ -381,10 +381,14 @@ def main():
     printed = threading.Lock()
 
     def emit_and_leave(note):
+        """the headline line with the failure marked, then a non-zero exit status: a launcher that only looks at the status
+        must not take a hung or failed multi-rank entry for a passing run"""
         if rank == 0 and printed.acquire(blocking=False):
             out["secondary"] = dict(sec, pf_step={"error": note})
+            out["secondary_failed"] = True
             print(json.dumps(out), flush=True)
-        os._exit(0)
+            sys.stdout.flush()
+        os._exit(3)
 
     watchdog = None
     if world > 1 and not args.no_extras:
@@ -402,7 +406,7 @@ def main():
                 raise
             sec_pf = {"pf_step": {"error": "%s: %s" % (type(e).__name__, e)}}
             if rank != 0:
-                os._exit(0)
+                os._exit(3)
             emit_and_leave(sec_pf["pf_step"]["error"])
         if rank == 0:
             sec.update(sec_pf)
@@ -413,6 +417,7 @@ def main():
         watchdog.cancel()
     if rank == 0:
         out["secondary"] = sec
+        out["secondary_failed"] = False
         if cpu is not None:
             m = len(cpu_st)
             ri = torch.arange(0, m, dtype=torch.int32, device="cuda"); ai = ri + 1
@@ -538,15 +543,12 @@ def secondary_grid(torch, capi, ctx, raw, p):
     return res
 
 
-def secondary_pf(torch, capi, ctx, dist, rank, world, raw, p, coll_dev):
-    """Particle-filter localisation step (config 4), 2^20 particles PER RANK sharded over the ranks (pf.py over
-    torch.distributed; at one rank no collective runs): predict, likelihood-field scores, best pose, weights / N_eff,
-    fixed-point systematic resampling with the surplus exchange, roughening.  Also the scorer alone."""
-    from laser_slam_amd import pf, synth
-    res = {}
+def pf_world(torch, capi, ctx, raw, p):
+    """Map, likelihood field and observed scan of the particle-filter entries: 256 synthetic scans inserted at their true
+    poses into 4096^2 @ 5 cm, the field built from it, the first scan as laser-frame points."""
+    from laser_slam_amd import synth
     n = raw.shape[1]
     fi = capi.param_tables(p)[0]
-    # a map of the synthetic world: 256 scans inserted at their true poses, then the likelihood field
     nb = 256
     poses = synth.path_pose(np.arange(nb) * 6)
     rr = raw[(np.arange(nb) * 6) % N_BASE] / 100.0
@@ -557,73 +559,116 @@ def secondary_pf(torch, capi, ctx, dist, rank, world, raw, p, coll_dev):
     grid.update_batch(nb, n, torch.from_numpy(gx).cuda(), torch.from_numpy(gy).cuda(), torch.from_numpy(poses[:, :2].astype(np.float32)).cuda())
     grid.compute_prob()
     fld = capi.Field(ctx, G, G, 1024, 1024, 0.0, 0.0, 0.05)
-    t0 = time.perf_counter()
     fld.build_from_grid(grid); ctx.sync()
-    res["field_build"] = {"value": (time.perf_counter() - t0) * 1e3, "unit": "ms", "grid": "%dx%d" % (G, G)}
-    P = 1 << 20
-    n_total = P * world
-    rng = np.random.default_rng(1 + rank)
-    pp = np.stack([10 + rng.normal(0, 1.0, P), 7.5 + rng.normal(0, 1.0, P), rng.normal(0, 0.3, P)], 1).astype(np.float32)
-    d_p = torch.from_numpy(pp).cuda()
     sxy = (rr[0][:, None] * np.stack([np.cos(fi), np.sin(fi)], 1)).astype(np.float32)
     d_sx, d_sy = torch.from_numpy(np.ascontiguousarray(sxy[:, 0])).cuda(), torch.from_numpy(np.ascontiguousarray(sxy[:, 1])).cuda()
-    d_sc = torch.zeros(P, device="cuda")
-    torch.cuda.synchronize()
-    ms = timed(torch, lambda: fld.score_poses(d_sx, d_sy, n, 3, d_p, P, d_sc), reps=3)
-    nbm = (n + 2) // 3
-    res["score_poses"] = {"value": P / (ms * 1e-3), "unit": "poses/s", "poses": P, "beams_per_pose": nbm,
-                          "roofline": {"bound": "cache-gather", "achieved": P * nbm * 4 / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": P * nbm * 4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "score_poses_kernel",
-                                       "kernel_ms": ms,
-                                       "note": "gathered bytes (P x beams x 4) of the 64 MiB likelihood field, served by L2 / Infinity "
-                                               "Cache; peak = the HBM figure for scale, the gather itself is not an HBM stream"}}
-    prims = pf.DevicePrims(ctx, fld, d_sx, d_sy, n, 3)
-    filt = pf.ShardedParticleFilter(n_total, prims, resample_threshold=2.0, device=coll_dev)     # (threshold 2: every step resamples)
-    d_nrm = torch.randn(P, 3, device="cuda"); d_cur = d_p.clone()
-    comm_ranks = world
+    return grid, fld, d_sx, d_sy, n
 
-    def pf_step():
-        capi.pf_predict(ctx, P, [10.0, 7.5, 0.0], [0.25, 0.25, 0.27], d_nrm, d_cur)
-        new, info = filt.step(d_cur, 0.37)
-        if world == 1:
-            capi.pf_roughen(ctx, P, 0.2, d_nrm, new)
-        else:                                                # extremes of the whole set: two tiny all-reduces
-            lo = new.min(0).values; hi = new.max(0).values
-            lo_c, hi_c = lo.to(coll_dev), hi.to(coll_dev)
-            dist.all_reduce(lo_c, op=dist.ReduceOp.MIN); dist.all_reduce(hi_c, op=dist.ReduceOp.MAX)
-            scale = 0.2 * float(n_total) ** (-1.0 / 3.0)
-            new += d_nrm * ((hi_c - lo_c).to(new.device) * scale)
-        ctx.sync()
-        return info
 
-    pf_step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+PF_PREDICT = ("predict", [10.0, 7.5, 0.0], [0.25, 0.25, 0.27])
+PF_BYTES_PER_PARTICLE = 92.0     # predict 12 r + 12 w, score 12 r + 4 w, weights 4 r + 8 w, offspring 8 r + 12 r + 12 w, roughen 12 r + 12 r + 12 w (less the re-reads L2 serves)
+
+
+def pf_cloud(torch, P, seed):
+    rng = np.random.default_rng(seed)
+    pp = np.stack([10 + rng.normal(0, 1.0, P), 7.5 + rng.normal(0, 1.0, P), rng.normal(0, 0.3, P)], 1).astype(np.float32)
+    return torch.from_numpy(pp).cuda()
+
+
+def secondary_pf(torch, capi, ctx, dist, rank, world, raw, p, coll_dev):
+    """Particle-filter localisation (config 4): the likelihood-field scorer alone, then whole steps - prediction, scores,
+    best pose, weights / N_eff, fixed-point systematic resampling with the surplus exchange, roughening - in the fused
+    form (four launches, one read-back; pf.py over torch.distributed = RCCL with several ranks):
+      pf_step         weak scaling, 2^20 particles PER RANK;
+      pf_step_strong  config 4 as written: 2^20 particles OVER the ranks (131 072 each at eight);
+      pf_shard_131072 (one rank only) the shard one rank of eight owns, alone on one GPU - no collective in it."""
+    from laser_slam_amd import pf
+    res = {}
     t0 = time.perf_counter()
-    reps = 3
-    for _ in range(reps):
-        info = pf_step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = (time.perf_counter() - t0) / reps
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    bytes_pp = 140.0                                         # predict 12 w, score 12 r + 4 w, weights 4 r + 4 w, scan 4 r + 8 w + 8 r,
-    res["pf_step"] = {"value": n_total / dt, "unit": "particles/s", "ms_per_step": dt * 1e3, "particles_total": n_total,
-                      "particles_per_gpu": P, "n_gpus": comm_ranks, "scaling": "weak", "resampled_every_step": bool(info["resampled"]),
-                      "bytes_sent_per_step_rank0": filt.bytes_sent / (reps + 1),
-                      "roofline": {"bound": "hbm", "achieved": n_total * bytes_pp / dt / 1e9, "peak": HBM_PEAK_GBS * comm_ranks, "unit": "GB/s",
-                                   "frac": n_total * bytes_pp / dt / 1e9 / (HBM_PEAK_GBS * comm_ranks), "traffic": None, "kernel": "pf step (10 launches)",
-                                   "kernel_ms": dt * 1e3,
-                                   "note": "about 140 B of particle arrays per particle and step (predict, score, weights, fixed-point scan, "
-                                           "bounds, parents, gather, roughen) + the field gather; nine tenths of the step is the likelihood-"
-                                           "field scoring (score_poses above: a cache gather, not an HBM stream), the rest a host-synchronised "
-                                           "sequence of short launches and, with several ranks, three small collectives"}}
+    grid, fld, d_sx, d_sy, n = pf_world(torch, capi, ctx, raw, p)
+    res["field_build"] = {"value": timed(torch, lambda: fld.build_from_grid(grid), reps=3), "unit": "ms", "grid": "4096x4096"}
+    nbm = (n + 2) // 3
+    P = 1 << 20
+    if rank == 0:
+        d_p = pf_cloud(torch, P, 1); d_sc = torch.zeros(P, device="cuda")
+        torch.cuda.synchronize()
+        ms = timed(torch, lambda: fld.score_poses(d_sx, d_sy, n, 3, d_p, P, d_sc), reps=5)
+        res["score_poses"] = {"value": P / (ms * 1e-3), "unit": "poses/s", "poses": P, "beams_per_pose": nbm,
+                              "roofline": {"bound": "cache-gather", "achieved": P * nbm * 4 / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": P * nbm * 4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "pf_score_kernel",
+                                           "kernel_ms": ms,
+                                           "note": "gathered bytes (P x beams x 4) of the 64 MiB likelihood field, served by L2 / Infinity "
+                                                   "Cache; peak = the HBM figure for scale, the gather itself is not an HBM stream"}}
+
+    def run(n_total, reps):
+        """fused step over this process's ranks: (ms per step max over ranks, info, bytes rank 0 sent per step)"""
+        first, cnt = pf.shard_bounds(n_total, rank, world)
+        fp = pf.FusedDevicePrims(ctx, fld, cnt, d_sx, d_sy, n, 3)
+        filt = pf.FusedParticleFilter(n_total, fp, resample_threshold=2.0, roughen_K=0.2)       # (threshold 2: every step resamples)
+        d_cur = pf_cloud(torch, cnt, 1 + rank)
+        g = torch.Generator(device="cuda"); g.manual_seed(7 + rank)
+        d_nrm = torch.randn(cnt, 3, device="cuda", generator=g)
+        info = None
+        for it in range(reps + 2):
+            if it == 2:
+                torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                t1 = time.perf_counter()
+            d_cur, info = filt.step(d_cur, 0.37, predict=PF_PREDICT, normals_predict=d_nrm, normals_roughen=d_nrm)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = (time.perf_counter() - t1) / reps
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        sent = filt.bytes_sent / (reps + 2)
+        fp.close()
+        return dt, info, sent, cnt
+
+    def entry(n_total, scaling, reps):
+        dt, info, sent, cnt = run(n_total, reps)
+        return {"value": n_total / dt, "unit": "particles/s", "ms_per_step": dt * 1e3, "particles_total": n_total,
+                "particles_per_gpu": cnt, "n_gpus": world, "scaling": scaling, "resampled_every_step": bool(info["resampled"]),
+                "bytes_sent_per_step_rank0": sent, "launches_per_step": 4, "host_readbacks_per_step": 1,
+                "collectives_per_step": 0 if world == 1 else 4,
+                "roofline": {"bound": "hbm", "achieved": n_total * PF_BYTES_PER_PARTICLE / dt / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                             "frac": n_total * PF_BYTES_PER_PARTICLE / dt / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
+                             "kernel": "pf step (pf_score / pf_weights / pf_offspring / pf_roughen_keys)", "kernel_ms": dt * 1e3,
+                             "note": "about 92 B of particle arrays per particle and step beside the field gather; the step is the "
+                                     "likelihood-field scoring (score_poses above: a cache gather, not an HBM stream) plus three short "
+                                     "launches and one read-back; with several ranks two all-gathers (8 B and 48 B per rank), the surplus "
+                                     "exchange and one all-reduce of 24 B"}}
+
+    res["pf_step"] = entry(P * world, "weak", 5)
+    res["pf_step_strong"] = entry(P, "strong", 10)
+    if world == 1:
+        Ps = 1 << 17
+        e = entry(Ps, "one shard of eight, alone on one GPU", 20)
+        # the same step as the C ABI's one call (lsa_pf_filter_step: what a C++ host runs; no Python between the launches)
+        flt = capi.PfFilter(fld, Ps)
+        d_cur = pf_cloud(torch, Ps, 1); d_out = torch.zeros(Ps, 3, device="cuda"); d_nrm = torch.randn(Ps, 3, device="cuda")
+        torch.cuda.synchronize()
+
+        def one():
+            flt.step(d_sx, d_sy, n, 3, d_cur, d_out, Ps, Ps, 0.37, resample_threshold=2.0, roughen_K=0.2, d_normals_roughen=d_nrm,
+                     predict=PF_PREDICT, d_normals_predict=d_nrm)
+        one(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            one()
+        torch.cuda.synchronize()
+        e["ms_per_step_c_abi"] = (time.perf_counter() - t1) / 20 * 1e3
+        e["speedup_of_full_set_step"] = res["pf_step_strong"]["ms_per_step"] / e["ms_per_step"]
+        e["note"] = ("ms_per_step = pf.py's phases over torch (what pf_step times); ms_per_step_c_abi = lsa_pf_filter_step; "
+                     "speedup_of_full_set_step = one-GPU step over 2^20 particles / this: the compute side of strong scaling to "
+                     "eight ranks, collectives excluded (no multi-GPU box here)")
+        res["pf_shard_131072"] = e
+        flt.close()
     fld.close(); grid.close()
+    res["pf_entries_s"] = time.perf_counter() - t0
     return res
 
 

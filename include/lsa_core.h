@@ -411,6 +411,58 @@ int lsa_pf_plan(int world, int64_t n_total, const uint64_t* shard_sum, double u0
 int lsa_pf_offspring_bounds(lsa_ctx* c, const uint64_t* d_cum, int n, uint64_t offset, int64_t n_total, uint64_t u0_fixed, uint64_t total,
                             int32_t* d_e);
 int lsa_pf_parents(lsa_ctx* c, const int32_t* d_e, int n, int64_t m_first, int m_count, int32_t* d_parent);
+/* host only: from lsa_pf_plan's bounds, how many of this rank's produced offspring go to every rank's block of the new
+ * particle array (send[world], ascending = destination order) and how many it receives from every rank (recv[world]);
+ * send[rank] = recv[rank] = the part that stays */
+int lsa_pf_exchange_plan(int world, int64_t n_total, const int64_t* bounds, int rank, int64_t* send, int64_t* recv);
+
+/* ---- fused localisation step (config 4; CParticles::update, src/localization/particles.cpp:321-387) ---------------------
+ * One step of the filter in four launches and one read-back: (1) prediction + obsLikelyhood3 score of every particle +
+ * the shard's best (score, index); (2) weights against the best of ALL shards, N_eff sums, fixed-point cumulative weights,
+ * the shard's record; read-back of the records (N_eff decides, particles.cpp:350); (3) Systematic_resampler
+ * (src/sensorFusion/SIRFlt.cpp:118-191) in the fixed-point scheme above: every produced offspring finds its parent and
+ * copies its pose; (4) roughen_minmax (SIRFlt.cpp:359-413).  The filter object owns the step's device buffers (scores,
+ * cumulative weights, records) for up to `capacity` particles of this rank.  PARITY UNPINNED (Qt4 / Boost absent). */
+typedef struct lsa_pf_filter lsa_pf_filter;
+#define LSA_PF_RECORD_BYTES 48     /* a shard's record: u64 fixed-point weight sum, f64 sum w, f64 sum w^2, u64 best key, f32 pose[3], u32 flag */
+typedef struct lsa_pf_info {
+    float best_score;              /* best particle of all shards: score, global index, pose (if has_best_pose) */
+    int32_t has_best_pose;
+    int64_t best_index;
+    float best_pose[3];
+    int32_t resampled;
+    double weight_sum, weight_sq_sum, n_eff;      /* over all shards, w = exp(score - best score); CParticles::neff */
+} lsa_pf_info;
+int lsa_pf_filter_create(lsa_pf_filter** out, lsa_field* f, int capacity);
+void lsa_pf_filter_destroy(lsa_pf_filter* w);
+/* The whole step.  predict_mode 0: poses as they are; 1: pose_i = mean + sigma * normal_i (CParticles::predict,
+ * particles.cpp:119-153); 2: pose_i (+) (delta + sigma * normal_i) (MRPT's motion step as pf_localization_main.cpp:627-632
+ * drives it).  std_frame as lsa_score_poses_std.  Resampling when n_eff < resample_threshold * n_total: the new block of
+ * this rank goes to d_poses_out (info->resampled = 1; roughened when roughen_K > 0), otherwise d_poses_out is untouched.
+ * m = NULL: one rank, no collective.  With a communicator: n_local = this rank's lsa_shard_bounds block of n_total; two
+ * small all-gathers (8 and 48 bytes per rank), one grouped send / recv of the offspring that change ranks, one
+ * all-reduce of six extremes. */
+int lsa_pf_filter_step(lsa_pf_filter* w, lsa_comm* m, const float* d_scan_x, const float* d_scan_y, int n_points, int decimation,
+                       int std_frame, int predict_mode, const double mean_or_delta[3], const double sigma[3],
+                       const float* d_normals_predict, float* d_poses, float* d_poses_out, int n_local, int64_t n_total,
+                       double resample_threshold, double u0, double roughen_K, const float* d_normals_roughen, lsa_pf_info* info);
+/* The phases one by one, for hosts that bring their own transport (all asynchronous on the context's stream except _read):
+ *   _score      launch 1; the shard's best key (ordered score << 32 | ~global index) is left in the key slot
+ *   _weights    launch 2 against the largest of n_keys keys (d_keys = NULL: the own slot); d_w (may be NULL) gets the weights
+ *   _read       copies `world` records (d_records = NULL: the own one) to the host and waits; fills info and the shards' sums
+ *   _offspring  launch 3: poses of offspring m_first .. m_first + m_count - 1 (inside this shard's range of lsa_pf_plan)
+ *               -> d_out, and the extremes of those poses into the min/max slot (six int32 keys, combined by a signed MAX)
+ *   _roughen    launch 4 with the extremes at d_minmax (NULL: the own slot)
+ *   _slots      device addresses of the key (8 B), the record (48 B), the extremes (24 B) and the scores, for the collectives */
+int lsa_pf_filter_score(lsa_pf_filter* w, const float* d_scan_x, const float* d_scan_y, int n_points, int decimation, int std_frame,
+                        int predict_mode, const double mean_or_delta[3], const double sigma[3], const float* d_normals,
+                        float* d_poses, int n_local, int64_t first_index);
+int lsa_pf_filter_weights(lsa_pf_filter* w, const uint64_t* d_keys, int n_keys, const float* d_poses, float* d_w);
+int lsa_pf_filter_read(lsa_pf_filter* w, const void* d_records, int world, int64_t n_total, lsa_pf_info* info, uint64_t* shard_q_sums);
+int lsa_pf_filter_offspring(lsa_pf_filter* w, uint64_t shard_offset, int64_t n_total, uint64_t u0_fixed, uint64_t total,
+                            int64_t m_first, int m_count, const float* d_poses, float* d_out);
+int lsa_pf_filter_roughen(lsa_pf_filter* w, const int32_t* d_minmax, int n, int64_t n_total, double K, const float* d_normals, float* d_poses);
+int lsa_pf_filter_slots(lsa_pf_filter* w, void** d_key, void** d_record, void** d_minmax, void** d_score);
 
 #ifdef __cplusplus
 }

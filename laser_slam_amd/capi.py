@@ -28,6 +28,19 @@ class LaserParam(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class PfInfo(C.Structure):
+    """lsa_pf_info (include/lsa_core.h)"""
+    _fields_ = [("best_score", C.c_float), ("has_best_pose", C.c_int32), ("best_index", C.c_int64), ("best_pose", C.c_float * 3),
+                ("resampled", C.c_int32), ("weight_sum", C.c_double), ("weight_sq_sum", C.c_double), ("n_eff", C.c_double)]
+
+    def as_dict(self):
+        return dict(best_score=self.best_score, best_index=self.best_index, best_pose=tuple(self.best_pose) if self.has_best_pose else None,
+                    weight_sum=self.weight_sum, weight_sq_sum=self.weight_sq_sum, n_eff=self.n_eff, resampled=bool(self.resampled))
+
+
+PF_RECORD_BYTES = 48
+
+
 class LsaError(RuntimeError):
     pass
 
@@ -139,6 +152,18 @@ def lib():
     L.lsa_pf_plan.argtypes = [C.c_int, C.c_int64, vp, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp]
     L.lsa_pf_offspring_bounds.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_int64, C.c_uint64, C.c_uint64, vp]
     L.lsa_pf_parents.argtypes = [vp, vp, C.c_int, C.c_int64, C.c_int, vp]
+    L.lsa_pf_exchange_plan.argtypes = [C.c_int, C.c_int64, vp, C.c_int, vp, vp]
+    L.lsa_pf_filter_create.argtypes = [C.POINTER(vp), vp, C.c_int]
+    L.lsa_pf_filter_destroy.argtypes = [vp]
+    L.lsa_pf_filter_destroy.restype = None
+    L.lsa_pf_filter_slots.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.lsa_pf_filter_score.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int64]
+    L.lsa_pf_filter_weights.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.lsa_pf_filter_read.argtypes = [vp, vp, C.c_int, C.c_int64, C.POINTER(PfInfo), vp]
+    L.lsa_pf_filter_offspring.argtypes = [vp, C.c_uint64, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, vp, vp]
+    L.lsa_pf_filter_roughen.argtypes = [vp, vp, C.c_int, C.c_int64, C.c_double, vp, vp]
+    L.lsa_pf_filter_step.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int64,
+                                     C.c_double, C.c_double, C.c_double, vp, C.POINTER(PfInfo)]
     L.lsa_icp_goodness_scores.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp, vp]
     L.lsa_gather_poses.argtypes = [vp, vp, vp, C.c_int, vp]
     L.lsa_p2p_icp_host.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp]
@@ -592,6 +617,72 @@ def pf_offspring_bounds(ctx, d_cum, n, offset, n_total, U0, W, d_e):
 
 def pf_parents(ctx, d_e, n, m_first, m_count, d_parent):
     check(lib().lsa_pf_parents(ctx.h, _dp(d_e), n, int(m_first), int(m_count), _dp(d_parent)), "lsa_pf_parents")
+
+
+def pf_exchange_plan(bounds, n_total, rank, world):
+    """lsa_pf_exchange_plan (host only): (send[world], recv[world]) of the surplus exchange."""
+    b = np.ascontiguousarray(bounds, np.int64)
+    send = np.zeros(world, np.int64); recv = np.zeros(world, np.int64)
+    check(lib().lsa_pf_exchange_plan(int(world), int(n_total), _hp(b), int(rank), _hp(send), _hp(recv)), "lsa_pf_exchange_plan")
+    return [int(v) for v in send], [int(v) for v in recv]
+
+
+class PfFilter:
+    """lsa_pf_filter: the fused localisation step's device buffers and launches for up to `capacity` particles."""
+
+    def __init__(self, field, capacity):
+        self.h = vp()
+        self.L = lib()
+        self.field = field
+        check(self.L.lsa_pf_filter_create(C.byref(self.h), field.h, int(capacity)), "lsa_pf_filter_create")
+        k, r, m, sc = vp(), vp(), vp(), vp()
+        check(self.L.lsa_pf_filter_slots(self.h, C.byref(k), C.byref(r), C.byref(m), C.byref(sc)), "lsa_pf_filter_slots")
+        self.d_key, self.d_record, self.d_minmax, self.d_score = k.value, r.value, m.value, sc.value
+
+    def close(self):
+        if self.h:
+            self.L.lsa_pf_filter_destroy(self.h)
+            self.h = vp()
+
+    def score(self, d_scan_x, d_scan_y, n_points, decimation, d_poses, n_local, first_index=0, std_frame=False, predict=None,
+              d_normals=None):
+        """predict = None | ("predict", mean[3], sigma[3]) | ("motion", delta[3], sigma[3])"""
+        mode, m, sg = 0, None, None
+        if predict is not None:
+            mode = 1 if predict[0] == "predict" else 2
+            m = np.ascontiguousarray(predict[1], np.float64); sg = np.ascontiguousarray(predict[2], np.float64)
+        check(self.L.lsa_pf_filter_score(self.h, _dp(d_scan_x), _dp(d_scan_y), n_points, decimation, int(std_frame), mode, _hp(m), _hp(sg),
+                                         _dp(d_normals), _dp(d_poses), int(n_local), int(first_index)), "lsa_pf_filter_score")
+
+    def weights(self, d_poses, d_keys=None, n_keys=1, d_w=None):
+        check(self.L.lsa_pf_filter_weights(self.h, _dp(d_keys), int(n_keys), _dp(d_poses), _dp(d_w)), "lsa_pf_filter_weights")
+
+    def read(self, n_total, d_records=None, world=1):
+        info = PfInfo(); sums = np.zeros(world, np.uint64)
+        check(self.L.lsa_pf_filter_read(self.h, _dp(d_records), int(world), int(n_total), C.byref(info), _hp(sums)), "lsa_pf_filter_read")
+        return info.as_dict(), [int(v) for v in sums]
+
+    def offspring(self, offset, n_total, U0, W, m_first, m_count, d_poses, d_out):
+        check(self.L.lsa_pf_filter_offspring(self.h, int(offset), int(n_total), int(U0), int(W), int(m_first), int(m_count), _dp(d_poses),
+                                             _dp(d_out)), "lsa_pf_filter_offspring")
+
+    def roughen(self, n, n_total, K, d_normals, d_poses, d_minmax=None):
+        check(self.L.lsa_pf_filter_roughen(self.h, _dp(d_minmax), int(n), int(n_total), float(K), _dp(d_normals), _dp(d_poses)),
+              "lsa_pf_filter_roughen")
+
+    def step(self, d_scan_x, d_scan_y, n_points, decimation, d_poses, d_poses_out, n_local, n_total, u0, resample_threshold=0.5,
+             roughen_K=0.0, d_normals_roughen=None, predict=None, d_normals_predict=None, std_frame=False, comm=None):
+        """lsa_pf_filter_step: the whole step in one call (comm = None: one rank)."""
+        mode, m, sg = 0, None, None
+        if predict is not None:
+            mode = 1 if predict[0] == "predict" else 2
+            m = np.ascontiguousarray(predict[1], np.float64); sg = np.ascontiguousarray(predict[2], np.float64)
+        info = PfInfo()
+        check(self.L.lsa_pf_filter_step(self.h, comm.h if comm is not None else None, _dp(d_scan_x), _dp(d_scan_y), n_points, decimation,
+                                        int(std_frame), mode, _hp(m), _hp(sg), _dp(d_normals_predict), _dp(d_poses), _dp(d_poses_out),
+                                        int(n_local), int(n_total), float(resample_threshold), float(u0), float(roughen_K),
+                                        _dp(d_normals_roughen), C.byref(info)), "lsa_pf_filter_step")
+        return info.as_dict()
 
 
 def comm_unique_id():

@@ -16,6 +16,7 @@
 #include "match_kernels.hip"
 #include "grid_kernels.hip"
 #include "pose_kernels.hip"
+#include "pfstep_kernels.hip"
 #include "sim_kernels.hip"
 #include "p2p_kernels.hip"
 #include "plicp_kernels.hip"
@@ -1023,6 +1024,7 @@ struct lsa_field {
     float* d_lik = nullptr;
     float* d_loglik = nullptr;
     uint16_t* d_col = nullptr;
+    float* d_tab = nullptr;      // the scorer's table: log-likelihoods with a four-cell apron (pf_table_kernel)
     size_t cells = 0;
     uint32_t* d_cls = nullptr;   // scan simulator: two-bit cell classes in 16 x 16 tiles (sim_class_kernel), rebuilt per call
 };
@@ -1042,7 +1044,8 @@ int lsa_field_create(lsa_field** out, lsa_ctx* c, int sx, int sy, int cx, int cy
     hipError_t e;
     if ((e = hipMalloc((void**)&f->d_lik, f->cells * 4)) != hipSuccess ||
         (e = hipMalloc((void**)&f->d_loglik, f->cells * 4)) != hipSuccess ||
-        (e = hipMalloc((void**)&f->d_col, f->cells * 2)) != hipSuccess) {
+        (e = hipMalloc((void**)&f->d_col, f->cells * 2)) != hipSuccess ||
+        (e = hipMalloc((void**)&f->d_tab, ((size_t)sx + 8) * ((size_t)sy + 8) * 4)) != hipSuccess) {
         lsa_field_destroy(f);
         return fail(LSA_E_NOMEM, "hipMalloc(field)", e);
     }
@@ -1055,8 +1058,27 @@ void lsa_field_destroy(lsa_field* f)
     if (!f) return;
     hipSetDevice(f->c->device);
     hipStreamSynchronize(f->c->stream);
-    hipFree(f->d_lik); hipFree(f->d_loglik); hipFree(f->d_col); hipFree(f->d_cls);
+    hipFree(f->d_lik); hipFree(f->d_loglik); hipFree(f->d_col); hipFree(f->d_cls); hipFree(f->d_tab);
     delete f;
+}
+
+static lsa::PfField pf_field(const lsa_field* f)
+{
+    lsa::PfField F{};
+    F.size_x = f->F.size_x; F.size_y = f->F.size_y; F.center_x = f->F.center_x; F.center_y = f->F.center_y;
+    F.off_x = f->F.off_x; F.off_y = f->F.off_y; F.res = f->F.res;
+    int fb = 20;
+    const double need = (double)((f->F.size_x > f->F.size_y ? f->F.size_x : f->F.size_y) + 8);
+    while (fb > 4 && need * (double)(1u << fb) >= 4294967296.0) --fb;
+    F.fb = fb;
+    const double s = (double)(1u << fb);
+    F.inv_s = s / f->F.res;
+    F.cx_s = ((double)f->F.center_x + 4.0) * s + 0.0005 * F.inv_s; F.cy_s = ((double)f->F.center_y + 4.0) * s + 0.0005 * F.inv_s;
+    F.lo_x = (float)((-2.5 - (double)f->F.center_x) * f->F.res); F.hi_x = (float)(((double)f->F.size_x + 2.5 - (double)f->F.center_x) * f->F.res);
+    F.lo_y = (float)((-2.5 - (double)f->F.center_y) * f->F.res); F.hi_y = (float)(((double)f->F.size_y + 2.5 - (double)f->F.center_y) * f->F.res);
+    const double max_sq = (double)f->F.max_corr * (double)f->F.max_corr;
+    F.log_min = (float)log((double)(0.05f / 50.0f) + (double)0.95f * exp(-0.5 / (0.35 * 0.35) * max_sq));      // VPmap.cpp:364
+    return F;
 }
 
 int lsa_field_build(lsa_field* f, const float* d_prob, float max_corr_dist, float free_thr, float unknown_value)
@@ -1070,6 +1092,7 @@ int lsa_field_build(lsa_field* f, const float* d_prob, float max_corr_dist, floa
     const int blocks = blocks_for(f->cells, 256);
     hipLaunchKernelGGL(lsa::field_col_kernel, dim3(blocks), dim3(256), 0, f->c->stream, f->F, d_prob, f->d_col);
     hipLaunchKernelGGL(lsa::field_row_kernel, dim3(blocks), dim3(256), 0, f->c->stream, f->F, f->d_col, f->d_lik, f->d_loglik);
+    hipLaunchKernelGGL(lsa::pf_table_kernel, dim3(blocks), dim3(256), 0, f->c->stream, pf_field(f), f->d_loglik, f->d_tab);
     HIP_TRY(hipGetLastError());
     return LSA_OK;
 }
@@ -1089,6 +1112,41 @@ int lsa_field_download(lsa_field* f, int what, float* h_out)
     return LSA_OK;
 }
 
+static int pf_lanes(int n_poses, int nb)
+{
+    // lanes per pose: enough of them that a small set still fills the chip, as few as that allows for a large one
+    const char* e = getenv("LSA_PF_LANES");               // (experiments: tools/pf_probe.py)
+    const int forced = e ? atoi(e) : 0;
+    if (forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
+    if (nb < 64) return 8;
+    return n_poses >= (1 << 19) ? 16 : 32;
+}
+
+// scores of n poses with the lanes-over-beams kernel (also behind lsa_score_poses / lsa_score_poses_std)
+static int pf_score(lsa_field* f, bool std_frame, const float* d_scan_x, const float* d_scan_y, int n_points, int decimation,
+                    const lsa::PfPredict& pr, const float* d_normals, float* d_poses, int P, long long first, float* d_score,
+                    unsigned long long* d_key)
+{
+    const int nb = (n_points + decimation - 1) / decimation;
+    if (nb * 8 > 60 * 1024) return fail(LSA_E_ARG, "too many scan points for the LDS stage");
+    if (((size_t)f->F.size_x + 8) * ((size_t)f->F.size_y + 8) >= (1ull << 32)) return fail(LSA_E_ARG, "field too large for 32-bit cell offsets");
+    const int L = pf_lanes(P, nb), G = 256 / L;
+    const int blocks = blocks_for((size_t)P, G, 2048);
+    const lsa::PfField F = pf_field(f);
+    const size_t lds = (size_t)nb * 8;
+    hipStream_t st = f->c->stream;
+    const float* loglik = f->d_tab;
+#define LSA_PF_LAUNCH(SS, LL) hipLaunchKernelGGL((lsa::pf_score_kernel<SS, LL>), dim3(blocks), dim3(256), lds, st, F, loglik, d_scan_x, d_scan_y, \
+                                                 n_points, decimation, pr, d_normals, d_poses, P, first, d_score, d_key)
+#define LSA_PF_LANES(SS) do { if (L == 8) LSA_PF_LAUNCH(SS, 8); else if (L == 16) LSA_PF_LAUNCH(SS, 16); else if (L == 32) LSA_PF_LAUNCH(SS, 32); \
+                              else LSA_PF_LAUNCH(SS, 64); } while (0)
+    if (std_frame) LSA_PF_LANES(true); else LSA_PF_LANES(false);
+#undef LSA_PF_LANES
+#undef LSA_PF_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return LSA_OK;
+}
+
 static int score_poses(lsa_field* f, bool std_frame, const float* d_scan_x, const float* d_scan_y, int n_points, int decimation,
                        const float* d_poses, int P, float* d_score)
 {
@@ -1096,16 +1154,8 @@ static int score_poses(lsa_field* f, bool std_frame, const float* d_scan_x, cons
     if (n_points <= 0 || decimation <= 0) return fail(LSA_E_ARG, "bad scan size / decimation");
     if (P <= 0) return LSA_OK;
     HIP_TRY(hipSetDevice(f->c->device));
-    const int nb = (n_points + decimation - 1) / decimation;
-    if (nb * 8 > 64 * 1024) return fail(LSA_E_ARG, "too many scan points for the LDS stage");
-    if (std_frame)
-        hipLaunchKernelGGL(lsa::score_poses_kernel<true>, dim3(blocks_for((size_t)P, 256)), dim3(256), nb * 8, f->c->stream,
-                           f->F, f->d_loglik, d_scan_x, d_scan_y, n_points, decimation, d_poses, P, d_score);
-    else
-        hipLaunchKernelGGL(lsa::score_poses_kernel<false>, dim3(blocks_for((size_t)P, 256)), dim3(256), nb * 8, f->c->stream,
-                           f->F, f->d_loglik, d_scan_x, d_scan_y, n_points, decimation, d_poses, P, d_score);
-    HIP_TRY(hipGetLastError());
-    return LSA_OK;
+    lsa::PfPredict none{};
+    return pf_score(f, std_frame, d_scan_x, d_scan_y, n_points, decimation, none, nullptr, const_cast<float*>(d_poses), P, 0, d_score, nullptr);
 }
 
 int lsa_score_poses(lsa_field* f, const float* d_scan_x, const float* d_scan_y, int n_points, int decimation,
@@ -1658,5 +1708,6 @@ int lsa_p2p_icp_host(lsa_ctx* c, const float* ref_x, const float* ref_y, int n_r
 }
 
 #include "shard_host.inc"
+#include "pfstep_host.inc"
 
 } // extern "C"

@@ -94,47 +94,7 @@ __device__ __forceinline__ int field_idx(float r, float off, int center, double 
     return (int)v;
 }
 
-// One thread per pose; scan points staged in LDS; log-likelihoods summed in beam order in double.
-// STD = false: the frame of CVPmap::obsLikelyhood3 (heading - pi/2, mirrored y, :366-381);
-// STD = true: the plain composition pose (+) point that MRPT-style callers (pf_localization_main.cpp) use.
-template <bool STD>
-__global__ __launch_bounds__(256) void score_poses_kernel(
-    FieldParam F, const float* __restrict__ loglik, const float* __restrict__ sx, const float* __restrict__ sy,
-    int n_points, int decim, const float* __restrict__ poses, int P, float* __restrict__ score)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* pts = (float2*)smem;
-    const int nb = (n_points + decim - 1) / decim;
-    for (int k = threadIdx.x; k < nb; k += blockDim.x) pts[k] = make_float2(sx[k * decim], sy[k * decim]);
-    __syncthreads();
-    const double max_sq = (double)F.max_corr * (double)F.max_corr;
-    const double min_lik = (double)(0.05f / 50.0f) + (double)0.95f * exp(-0.5 / (0.35 * 0.35) * max_sq);   // :364
-    const double log_min = log(min_lik);
-    const unsigned sx1 = (unsigned)(F.size_x - 1), sy1 = (unsigned)(F.size_y - 1);
-    const double inv_res = 1.0 / F.res;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        const double px = poses[3 * (size_t)p], py = poses[3 * (size_t)p + 1];
-        // th = normAngle(theta - M_PI/2, -M_PI), :366.  VPmap.cpp includes PolarParameter.h, so M_PI is
-        // 3.141592654 there, while normAngle (point.cpp:72-78) wraps with the true 2 pi.
-        double th = STD ? (double)poses[3 * (size_t)p + 2] : (double)poses[3 * (size_t)p + 2] - LSA_ZPI / 2.0;
-        while (th >= -LSA_ZPI + 6.28318530717958647692) th -= 6.28318530717958647692;
-        while (th < -LSA_ZPI) th += 6.28318530717958647692;
-        float cs, sn;
-        sincosf_fast((float)th, sn, cs);
-        double acc = 0.0;
-        for (int k = 0; k < nb; ++k) {
-            const float2 q = pts[k];
-            const float gx = (float)((double)(cs * q.x - sn * q.y) + px);      // :380
-            const float gy = STD ? (float)((double)(sn * q.x + cs * q.y) + py)
-                                 : (float)((double)(-cs * q.y - sn * q.x) + py);     // :381
-            const int cx = field_idx(gx, F.off_x, F.center_x, F.res, inv_res);                     // x2idx :102-104
-            const int cy = field_idx(gy, F.off_y, F.center_y, F.res, inv_res);
-            if ((unsigned)cx >= sx1 || (unsigned)cy >= sy1) acc += log_min;   // :388-392
-            else acc += (double)loglik[(size_t)cx * F.size_y + cy];
-        }
-        score[p] = (float)acc;
-    }
-}
+// (the pose scorer itself, obsLikelyhood3 over lanes-by-beams, lives in pfstep_kernels.hip: pf_score_kernel)
 
 // ---- reductions / weights / resampling ----------------------------------------------
 // out[0] = max score, out[1] = arg max (as int bits); grid-stride + one atomic per block on a packed key

@@ -18,6 +18,10 @@ Exchange steps of one step (messages are tiny except the last one):
     particles are split, so the sharded step reproduces the single-process step exactly (csrc/shard_kernels.hip).
 
 Compute = HIP kernels behind the C ABI, handed in as `prims` (see `DevicePrims`); the CPU tests pass numpy stand-ins.
+
+`FusedParticleFilter` is the same step cut to four launches, one read-back and - with several ranks - two small
+all-gathers (the 8-byte best keys, the 48-byte records), the surplus exchange and one all-reduce of six extremes
+(csrc/pfstep_kernels.hip, `lsa_pf_filter_*`); `ShardedParticleFilter` keeps the call-by-call form.
 """
 import numpy as np
 import torch
@@ -199,3 +203,190 @@ class ShardedParticleFilter:
             poses = self.resample(w, poses, u0)
             info["resampled"] = True
         return poses, info
+
+
+# ---- the fused step ---------------------------------------------------------------------------------------------
+RECORD = np.dtype([("q_sum", "<u8"), ("w_sum", "<f8"), ("w2_sum", "<f8"), ("best_key", "<u8"), ("best_pose", "<f4", (3,)),
+                   ("has_best", "<u4")])          # lsa::PfRecord, LSA_PF_RECORD_BYTES = 48
+assert RECORD.itemsize == 48
+
+
+def key_of(score, global_index):
+    """ordered(score) << 32 | ~index: the larger key is the larger score, equal scores the smaller index"""
+    u = int(np.float32(score).view(np.uint32))
+    o = (~u & 0xFFFFFFFF) if u & 0x80000000 else (u | 0x80000000)
+    return (o << 32) | (0xFFFFFFFF - int(global_index))
+
+
+def key_score_index(key):
+    o = (int(key) >> 32) & 0xFFFFFFFF
+    bits = (o & 0x7FFFFFFF) if o & 0x80000000 else (~o & 0xFFFFFFFF)
+    return float(np.uint32(bits).view(np.float32)), 0xFFFFFFFF - (int(key) & 0xFFFFFFFF)
+
+
+def parse_records(raw, n_total):
+    """raw: the ranks' records as bytes / int64 array (rank order) -> (info dict, fixed-point weight sum per rank).
+    The same arithmetic as lsa_pf_filter_read: sums added in rank order, N_eff as CParticles::neff (sic)."""
+    recs = np.frombuffer(np.ascontiguousarray(raw).tobytes(), dtype=RECORD)
+    s = s2 = 0.0
+    pose = None
+    for r in recs:
+        s += float(r["w_sum"]); s2 += float(r["w2_sum"])
+        if r["has_best"]:
+            pose = tuple(float(v) for v in r["best_pose"])
+    score, index = key_score_index(int(recs[0]["best_key"]))
+    info = dict(best_score=score, best_index=index, best_pose=pose, weight_sum=s, weight_sq_sum=s2,
+                n_eff=1.0 / (1.0 + s2 / (s * s)), resampled=False)
+    return info, [int(r["q_sum"]) for r in recs]
+
+
+def f_ord(v):
+    """order-preserving float32 -> uint32 map (csrc/lsa_device.h f_ord), vectorised"""
+    u = np.ascontiguousarray(v, np.float32).view(np.uint32)
+    return np.where(u & 0x80000000, ~u, u | np.uint32(0x80000000)).astype(np.uint32)
+
+
+def ord_f(o):
+    o = np.asarray(o, np.uint32)
+    return np.where(o & 0x80000000, o & np.uint32(0x7FFFFFFF), ~o).astype(np.uint32).view(np.float32)
+
+
+def minmax_keys(poses):
+    """six int32 keys of a pose block as pf_offspring_kernel leaves them: [0:3] minima (complemented), [3:6] maxima, both
+    sign-flipped so that a signed MAX combines blocks; an empty block gives the identity"""
+    out = np.full(6, -2 ** 31, np.int64)
+    p = np.asarray(poses, np.float32).reshape(-1, 3)
+    if p.shape[0]:
+        k = f_ord(p)
+        out[3:] = (k.max(0) ^ np.uint32(0x80000000)).view(np.int32)
+        out[:3] = ((~k).max(0) ^ np.uint32(0x80000000)).view(np.int32)
+    return out.astype(np.int32)
+
+
+def decode_minmax(mm):
+    """-> (min[3], max[3]) float32 of the keys above"""
+    k = np.asarray(mm, np.int32).view(np.uint32) ^ np.uint32(0x80000000)
+    return ord_f(~k[:3]), ord_f(k[3:])
+
+
+class _DeviceView:
+    """zero-copy torch view of device memory the library owns (the filter's slots)"""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class FusedDevicePrims:
+    """The four launches of the fused step on this rank's GPU (capi.PfFilter) with torch views of the slots the
+    collectives move."""
+
+    def __init__(self, ctx, field, capacity, d_scan_x, d_scan_y, n_points, decimation=3, std_frame=False):
+        from . import capi
+        self.capi, self.ctx = capi, ctx
+        self.flt = capi.PfFilter(field, capacity)
+        self.sx, self.sy, self.n_points, self.decim, self.std = d_scan_x, d_scan_y, n_points, decimation, std_frame
+        dev = d_scan_x.device
+        self.key = torch.as_tensor(_DeviceView(self.flt.d_key, 1, "<i8"), device=dev)
+        self.rec = torch.as_tensor(_DeviceView(self.flt.d_record, 6, "<i8"), device=dev)
+        self.mm = torch.as_tensor(_DeviceView(self.flt.d_minmax, 6, "<i4"), device=dev)
+        self.n_local = 0
+
+    def close(self):
+        self.flt.close()
+
+    def score_best(self, poses, first, predict=None, normals=None):
+        self.n_local = poses.shape[0]
+        self.flt.score(self.sx, self.sy, self.n_points, self.decim, poses, self.n_local, first, self.std, predict, normals)
+        return self.key
+
+    def weights(self, poses, keys):
+        own = keys.data_ptr() == self.key.data_ptr()
+        self.flt.weights(poses, None if own else keys, keys.shape[0])
+        return self.rec
+
+    def read(self, recs, n_total):
+        """the records on the host: through the library's pinned mirror on the context's stream (device records), or parsed
+        here (records a host-memory transport gathered)"""
+        if not recs.is_cuda:
+            return parse_records(recs.numpy(), n_total)
+        own = recs.data_ptr() == self.rec.data_ptr()
+        return self.flt.read(n_total, None if own else recs, 1 if own else recs.shape[0] // 6)
+
+    def offspring(self, poses, offset, n_total, U0, W, m_first, m_count):
+        out = torch.empty(m_count, 3, dtype=poses.dtype, device=poses.device)
+        self.flt.offspring(offset, n_total, U0, W, m_first, m_count, poses, out)
+        return out, self.mm
+
+    def roughen(self, new, normals, mm, n_total, K):
+        own = mm.data_ptr() == self.mm.data_ptr()
+        self.flt.roughen(new.shape[0], n_total, K, normals, new, None if own else mm)
+
+
+class FusedParticleFilter:
+    """One localisation step over this rank's particle shard in four launches, one read-back and (several ranks) four
+    collectives.  `prims`: score_best / weights / read / offspring / roughen (FusedDevicePrims, or stand-ins in the CPU
+    tests).  With several ranks over RCCL the context has to launch on torch's current stream (`ctx.set_stream`): the
+    collectives are ordered against that stream."""
+
+    def __init__(self, n_total, prims, resample_threshold=0.5, roughen_K=0.0):
+        self.rank, self.world = _world()
+        self.n_total = n_total
+        self.first, self.count = shard_bounds(n_total, self.rank, self.world)
+        self.prims = prims
+        self.resample_threshold = resample_threshold          # g_resample_threshold, globaldef.cpp:22
+        self.roughen_K = roughen_K
+        self.bytes_sent = 0
+        self._stage = self.world > 1 and dist.get_backend() == "gloo"      # gloo moves host memory (CPU tests, rehearsals)
+
+    def _all_gather(self, t):
+        world = self.world
+        if self._stage and t.is_cuda:
+            h = t.cpu()
+            out = torch.empty(world * h.shape[0], dtype=h.dtype)
+            dist.all_gather(list(out.chunk(world)), h)
+            return out.to(t.device)
+        out = torch.empty(world * t.shape[0], dtype=t.dtype, device=t.device)
+        if self._stage:
+            dist.all_gather(list(out.chunk(world)), t)
+        else:
+            dist.all_gather_into_tensor(out, t)
+        return out
+
+    def step(self, poses, u0, predict=None, normals_predict=None, normals_roughen=None):
+        """poses: this rank's [count, 3] tensor (updated in place by the prediction).  Returns (poses of this rank after
+        the step, info dict)."""
+        P, rank, world, N = self.prims, self.rank, self.world, self.n_total
+        key = P.score_best(poses, self.first, predict, normals_predict)
+        keys = self._all_gather(key) if world > 1 else key
+        rec = P.weights(poses, keys)
+        recs = self._all_gather(rec) if world > 1 else rec
+        info, sums = P.read(recs, N)                                            # the step's read-back
+        if world > 1:
+            self.bytes_sent += (8 + RECORD.itemsize) * (world - 1)
+        if not info["n_eff"] < self.resample_threshold * N:                     # particles.cpp:350
+            return poses, info
+        from . import capi
+        W, U0, bounds = capi.pf_plan(sums, N, u0)
+        p_lo, p_cnt = int(bounds[rank]), int(bounds[rank + 1] - bounds[rank])
+        prod, mm = P.offspring(poses, sum(sums[:rank]), N, U0, W, p_lo, p_cnt)
+        if world == 1:
+            new = prod
+        else:
+            send, recv = exchange_plan(bounds, N, rank, world)
+            new = torch.empty(self.count, 3, dtype=poses.dtype, device=poses.device)
+            if self._stage and prod.is_cuda:
+                out_h = torch.empty(self.count, 3, dtype=poses.dtype)
+                dist.all_to_all_single(out_h, prod.cpu().contiguous(), output_split_sizes=recv, input_split_sizes=send)
+                new.copy_(out_h)
+                mm_h = mm.cpu()
+                dist.all_reduce(mm_h, op=dist.ReduceOp.MAX)
+                mm = mm_h.to(poses.device)
+            else:
+                dist.all_to_all_single(new, prod, output_split_sizes=recv, input_split_sizes=send)
+                if self.roughen_K > 0:
+                    dist.all_reduce(mm, op=dist.ReduceOp.MAX)
+            self.bytes_sent += 12 * (sum(send) - send[rank]) + 24 * (world - 1)
+        info["resampled"] = True
+        if self.roughen_K > 0:
+            P.roughen(new, normals_roughen, mm, N, self.roughen_K)
+        return new, info

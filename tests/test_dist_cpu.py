@@ -63,6 +63,58 @@ class NumpyPrims:
         return poses[parent.long()]
 
 
+class NumpyFusedPrims:
+    """Stand-ins for the four launches of the fused step (laser_slam_amd.pf.FusedDevicePrims, csrc/pfstep_kernels.hip) in
+    Python integers: best key, weights / fixed-point cumulative sums / record, offspring by the definition, roughening."""
+
+    def score_best(self, poses, first, predict=None, normals=None):
+        from laser_slam_amd import pf
+        if predict is not None:
+            assert predict[0] == "predict"
+            m, sg = np.asarray(predict[1], np.float64), np.asarray(predict[2], np.float64)
+            poses.copy_(torch.from_numpy((m + normals.numpy().astype(np.float64) * sg).astype(np.float32)))
+        self.s, self.first, self.poses = _scores(poses), first, poses
+        best = max(pf.key_of(float(v), first + i) for i, v in enumerate(self.s))
+        return torch.from_numpy(np.array([best], np.uint64).view(np.int64))
+
+    def weights(self, poses, keys):
+        from laser_slam_amd import pf
+        gkey = max(int(k) for k in keys.numpy().view(np.uint64))
+        gmax, gidx = pf.key_score_index(gkey)
+        w = torch.exp(self.s - np.float32(gmax)).float()
+        self.cum, c = [], 0
+        for q in NumpyPrims.quantise(w):
+            c += q
+            self.cum.append(c)
+        rec = np.zeros(1, pf.RECORD)
+        wd = w.double()
+        rec["q_sum"], rec["w_sum"], rec["w2_sum"], rec["best_key"] = c, float(wd.sum()), float((wd * wd).sum()), gkey
+        if self.first <= gidx < self.first + len(self.s):
+            rec["has_best"] = 1
+            rec["best_pose"] = poses[gidx - self.first].numpy()
+        return torch.from_numpy(rec.view(np.int64).copy())
+
+    def read(self, recs, n_total):
+        from laser_slam_amd import pf
+        return pf.parse_records(recs.numpy(), n_total)
+
+    def offspring(self, poses, offset, n_total, U0, W, m_first, m_count):
+        from laser_slam_amd import pf
+        parent, i = [], 0
+        for m in range(m_first, m_first + m_count):
+            while (offset + self.cum[i]) * n_total <= m * W + U0:
+                i += 1
+            parent.append(i)
+        out = poses[torch.tensor(parent, dtype=torch.long)] if parent else poses[:0]
+        return out.contiguous(), torch.from_numpy(pf.minmax_keys(out.numpy()))
+
+    def roughen(self, new, normals, mm, n_total, K):
+        from laser_slam_amd import pf
+        lo, hi = pf.decode_minmax(mm.numpy())
+        rootq = (hi.astype(np.float64) - lo.astype(np.float64)) * (K * float(n_total) ** (-1.0 / 3.0))
+        new.copy_(torch.from_numpy((new.numpy().astype(np.float64) + normals.numpy().astype(np.float64) * rootq).astype(np.float32)))
+
+
 def _reference_resample(w_all, n_total, u0):
     """Systematic resampling of the whole set straight from the definition: offspring m sits at m W + U0 on the axis of
     N-fold cumulative fixed-point weights; its parent is the first particle whose N-fold cumulative weight exceeds it."""
@@ -98,6 +150,88 @@ def _worker(rank, world, port, n_total, out_dir):
                                                              info["n_eff"], float(info["resampled"])]))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _fused_inputs(n_total):
+    rng = np.random.default_rng(7)
+    nrm_p = torch.from_numpy(rng.normal(0, 1, (n_total, 3)).astype(np.float32))
+    nrm_r = torch.from_numpy(rng.normal(0, 1, (n_total, 3)).astype(np.float32))
+    return nrm_p, nrm_r, ("predict", [3.0, -1.0, 0.1], [0.8, 0.7, 0.3])
+
+
+def _fused_worker(rank, world, port, n_total, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from laser_slam_amd import pf
+    nrm_p, nrm_r, predict = _fused_inputs(n_total)
+    f = pf.FusedParticleFilter(n_total, NumpyFusedPrims(), resample_threshold=0.9, roughen_K=0.2)
+    sl = slice(f.first, f.first + f.count)
+    mine = torch.zeros(f.count, 3)
+    new, info = f.step(mine, 0.37, predict=predict, normals_predict=nrm_p[sl].contiguous(), normals_roughen=nrm_r[sl].contiguous())
+    assert new.shape[0] == f.count
+    allnew = pf.gather_concat(new)
+    sent = pf.gather_concat(torch.tensor([f.bytes_sent], dtype=torch.int64))
+    if rank == 0:
+        np.save(os.path.join(out_dir, "poses.npy"), allnew.numpy())
+        np.save(os.path.join(out_dir, "sent.npy"), sent.numpy())
+        np.save(os.path.join(out_dir, "info.npy"), np.array([info["best_score"], info["best_index"], info["weight_sum"], info["n_eff"],
+                                                             float(info["resampled"])] + list(info["best_pose"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 1000), (3, 4099), (3, 1001)])
+def test_fused_pf_step_equals_single_process(world, n_total, tmp_path):
+    """The fused step (one key and one record all-gathered, surplus exchange, one all-reduce of the extremes) over 2 and 3
+    gloo ranks gives exactly the single-process step - prediction, best particle, resampled set, roughening - and that is
+    systematic resampling by its definition."""
+    from laser_slam_amd import pf
+    port = 29100 + (os.getpid() % 300) + 13 * world + (n_total % 5)
+    mp.spawn(_fused_worker, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
+    got, info, sent = np.load(tmp_path / "poses.npy"), np.load(tmp_path / "info.npy"), np.load(tmp_path / "sent.npy")
+    nrm_p, nrm_r, predict = _fused_inputs(n_total)
+    f = pf.FusedParticleFilter(n_total, NumpyFusedPrims(), resample_threshold=0.9, roughen_K=0.2)
+    cur = torch.zeros(n_total, 3)
+    ref, ref_info = f.step(cur, 0.37, predict=predict, normals_predict=nrm_p, normals_roughen=nrm_r)
+    assert ref_info["resampled"] and info[4] == 1.0
+    assert np.array_equal(got, ref.numpy())
+    assert info[0] == ref_info["best_score"] and info[1] == ref_info["best_index"]
+    assert np.array_equal(info[5:8].astype(np.float32), np.asarray(ref_info["best_pose"], np.float32))
+    assert np.array_equal(cur.numpy()[ref_info["best_index"]], np.asarray(ref_info["best_pose"], np.float32))
+    assert abs(info[2] - ref_info["weight_sum"]) < 1e-9 * ref_info["weight_sum"] and abs(info[3] - ref_info["n_eff"]) < 1e-9 * ref_info["n_eff"]
+    # the definition: predicted poses -> weights -> parents -> roughening with the extremes of the new set
+    w_all = torch.exp(_scores(cur) - np.float32(ref_info["best_score"])).float()
+    parent = _reference_resample(w_all, n_total, 0.37)
+    res = cur.numpy()[parent]
+    rootq = (res.max(0).astype(np.float64) - res.min(0).astype(np.float64)) * (0.2 * float(n_total) ** (-1.0 / 3.0))
+    assert np.array_equal(ref.numpy(), (res.astype(np.float64) + nrm_r.numpy().astype(np.float64) * rootq).astype(np.float32))
+    per_rank = -(-n_total // world)
+    assert sent.max() <= 12 * per_rank + 96 * world and sent.sum() > 0
+
+
+def test_exchange_plan_host_arithmetic():
+    """lsa_pf_exchange_plan (host side of the C ABI) against pf.exchange_plan for 2, 3 and 8 ranks and skewed weights:
+    counts add up, own parts agree, what one rank sends to another is what that one expects from it."""
+    from laser_slam_amd import capi, pf
+    rng = np.random.default_rng(3)
+    for world in (1, 2, 3, 8):
+        for trial in range(6):
+            n_total = int(rng.integers(world, 200000))
+            sums = rng.integers(1, 1 << 40, world)
+            if trial % 2:
+                sums[rng.integers(0, world)] <<= 12          # one shard holds nearly all the weight
+            if trial == 5 and world > 2:
+                sums[1] = 0                                  # a shard without weight produces nothing
+            W, U0, bounds = capi.pf_plan([int(v) for v in sums], n_total, float(rng.random()))
+            plans = [capi.pf_exchange_plan(bounds, n_total, r, world) for r in range(world)]
+            for r in range(world):
+                send, recv = plans[r]
+                assert (send, recv) == tuple(pf.exchange_plan(bounds, n_total, r, world))
+                assert sum(send) == bounds[r + 1] - bounds[r] and sum(recv) == pf.shard_bounds(n_total, r, world)[1]
+                assert send[r] == recv[r]
+                for q in range(world):
+                    assert send[q] == plans[q][1][r]
 
 
 @pytest.mark.parametrize("world,n_total", [(2, 1000), (2, 1001), (3, 1000), (3, 4099)])

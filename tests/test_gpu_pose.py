@@ -310,6 +310,110 @@ def test_valid_poses_and_global_search(world):
     assert np.all(np.diff(sc) <= 0) and want[idx].all()
 
 
+def _fused_case(world, P, seed):
+    torch = world["torch"]
+    rng = np.random.default_rng(seed)
+    n = 361
+    ang = np.linspace(-np.pi / 2, np.pi / 2, n)
+    d_x = torch.from_numpy((3.0 * np.cos(ang)).astype(np.float32)).cuda(); d_y = torch.from_numpy((3.0 * np.sin(ang)).astype(np.float32)).cuda()
+    poses = np.stack([rng.uniform(1, 12, P), rng.uniform(1, 9, P), rng.uniform(-3, 3, P)], 1).astype(np.float32)
+    nrm_p = rng.normal(0, 1, (P, 3)).astype(np.float32); nrm_r = rng.normal(0, 1, (P, 3)).astype(np.float32)
+    return n, d_x, d_y, poses, nrm_p, nrm_r
+
+
+@pytest.mark.parametrize("P", [1, 777, 20000, 300000])
+def test_fused_step_equals_call_by_call_step(world, P):
+    """The fused step (lsa_pf_filter_*: four launches, one read-back) against the call-by-call entry points it replaces in
+    the loop - lsa_pf_predict, lsa_score_poses, lsa_pose_argmax, lsa_pf_weights, the fixed-point resampling pieces,
+    lsa_pf_roughen - bit for bit: predicted poses, scores, best particle, new particle set; N_eff sums to rounding."""
+    torch, capi, ctx, fld = world["torch"], world["capi"], world["ctx"], world["fld"]
+    from laser_slam_amd import pf
+    n, d_x, d_y, poses, nrm_p, nrm_r = _fused_case(world, P, 50 + P % 7)
+    mean, sigma, u0, K = [6.5, 5.0, 0.2], [2.0, 1.5, 1.0], 0.6180339, 0.2
+    d_np, d_nr = torch.from_numpy(nrm_p).cuda(), torch.from_numpy(nrm_r).cuda()
+    # call by call
+    a = torch.from_numpy(poses).cuda(); torch.cuda.synchronize()
+    capi.pf_predict(ctx, P, mean, sigma, d_np, a)
+    prims = pf.DevicePrims(ctx, fld, d_x, d_y, n, 3)
+    flt = pf.ShardedParticleFilter(P, prims, resample_threshold=2.0, device="cuda")
+    s_a = prims.score(a); ctx.sync()
+    new_a, info_a = flt.step(a, u0)
+    capi.pf_roughen(ctx, P, K, d_nr, new_a); ctx.sync()
+    # fused, phase by phase over torch (world 1) ...
+    b = torch.from_numpy(poses).cuda(); torch.cuda.synchronize()
+    fp = pf.FusedDevicePrims(ctx, fld, P, d_x, d_y, n, 3)
+    ff = pf.FusedParticleFilter(P, fp, resample_threshold=2.0, roughen_K=K)
+    new_b, info_b = ff.step(b, u0, predict=("predict", mean, sigma), normals_predict=d_np, normals_roughen=d_nr)
+    ctx.sync()
+    assert np.array_equal(b.cpu().numpy(), a.cpu().numpy())                          # predicted poses
+    s_b = torch.as_tensor(pf._DeviceView(fp.flt.d_score, P, "<f4"), device="cuda")
+    assert np.array_equal(s_b.cpu().numpy(), s_a.cpu().numpy())
+    assert info_b["resampled"] and info_b["best_score"] == info_a["best_score"] and info_b["best_index"] == info_a["best_index"]
+    assert np.array_equal(np.asarray(info_b["best_pose"], np.float32), a.cpu().numpy()[info_b["best_index"]])
+    assert abs(info_b["weight_sum"] - info_a["weight_sum"]) < 1e-9 * info_a["weight_sum"] and abs(info_b["n_eff"] - info_a["n_eff"]) < 1e-9 * info_a["n_eff"]
+    assert np.array_equal(new_b.cpu().numpy(), new_a.cpu().numpy())
+    # ... and as the one call of the C ABI
+    c = torch.from_numpy(poses).cuda(); c_out = torch.zeros(P, 3, device="cuda"); torch.cuda.synchronize()
+    info_c = fp.flt.step(d_x, d_y, n, 3, c, c_out, P, P, u0, resample_threshold=2.0, roughen_K=K, d_normals_roughen=d_nr,
+                         predict=("predict", mean, sigma), d_normals_predict=d_np)
+    ctx.sync()
+    assert info_c["resampled"] and info_c["best_index"] == info_a["best_index"] and info_c["n_eff"] == info_b["n_eff"]
+    assert np.array_equal(c_out.cpu().numpy(), new_a.cpu().numpy())
+    # below the threshold nothing is resampled and the output buffer stays untouched
+    c_out.zero_(); torch.cuda.synchronize()
+    info_d = fp.flt.step(d_x, d_y, n, 3, c, c_out, P, P, u0, resample_threshold=0.0)
+    ctx.sync()
+    assert not info_d["resampled"] and float(c_out.abs().sum()) == 0.0
+    fp.close()
+
+
+def test_fused_step_virtual_shards_equal_whole_set(world):
+    """Three virtual shards on one GPU (keys and records concatenated by hand where the ranks would all-gather them): every
+    shard's offspring range resolved from its own cumulative sums = the matching slice of the single-shard result, the
+    motion-model prediction included."""
+    torch, capi, ctx, fld = world["torch"], world["capi"], world["ctx"], world["fld"]
+    from laser_slam_amd import pf
+    P = 50001
+    n, d_x, d_y, poses, nrm_p, nrm_r = _fused_case(world, P, 91)
+    delta, sigma, u0 = [0.05, -0.02, 0.03], [0.05, 0.05, 0.02], 0.123
+    d_np = torch.from_numpy(nrm_p).cuda()
+    whole = torch.from_numpy(poses).cuda(); whole_out = torch.zeros(P, 3, device="cuda"); torch.cuda.synchronize()
+    f0 = capi.PfFilter(fld, P)
+    info0 = f0.step(d_x, d_y, n, 3, whole, whole_out, P, P, u0, resample_threshold=2.0, predict=("motion", delta, sigma), d_normals_predict=d_np)
+    ctx.sync()
+    th = whole.cpu().numpy()[:, 2]
+    assert th.max() <= np.pi and th.min() > -np.pi
+    world_n = 3
+    parts, filts, keys, recs = [], [], [], []
+    for r in range(world_n):
+        first, cnt = pf.shard_bounds(P, r, world_n)
+        part = torch.from_numpy(poses[first:first + cnt]).cuda(); torch.cuda.synchronize()
+        f = capi.PfFilter(fld, cnt)
+        f.score(d_x, d_y, n, 3, part, cnt, first, predict=("motion", delta, sigma), d_normals=d_np[first:first + cnt].contiguous())
+        ctx.sync()
+        keys.append(torch.as_tensor(pf._DeviceView(f.d_key, 1, "<i8"), device="cuda").clone())
+        parts.append(part); filts.append(f)
+    d_keys = torch.cat(keys); torch.cuda.synchronize()
+    for r in range(world_n):
+        filts[r].weights(parts[r], d_keys, world_n); ctx.sync()
+        recs.append(torch.as_tensor(pf._DeviceView(filts[r].d_record, 6, "<i8"), device="cuda").clone())
+    d_recs = torch.cat(recs); torch.cuda.synchronize()
+    info, sums = filts[0].read(P, d_recs, world_n)
+    assert info["best_index"] == info0["best_index"] and info["best_score"] == info0["best_score"]
+    assert abs(info["n_eff"] - info0["n_eff"]) < 1e-9 * info0["n_eff"]
+    assert np.array_equal(np.asarray(info["best_pose"], np.float32), np.asarray(info0["best_pose"], np.float32))
+    W, U0, bounds = capi.pf_plan(sums, P, u0)
+    got = []
+    for r in range(world_n):
+        lo, cnt = int(bounds[r]), int(bounds[r + 1] - bounds[r])
+        out = torch.zeros(max(cnt, 1), 3, device="cuda"); torch.cuda.synchronize()
+        filts[r].offspring(sum(sums[:r]), P, U0, W, lo, cnt, parts[r], out); ctx.sync()
+        got.append(out.cpu().numpy()[:cnt])
+    assert np.array_equal(np.concatenate(got), whole_out.cpu().numpy())
+    for f in filts + [f0]:
+        f.close()
+
+
 def test_full_size_filter_step_properties(world):
     """BASELINE config 4's size: one particle-filter step over 1 000 000 particles (likelihood-field scores, best
     pose, weights and N_eff, the reference's standard resampler with one uniform per offspring, gather, estimate of
