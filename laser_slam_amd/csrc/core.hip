@@ -1045,7 +1045,7 @@ int lsa_field_create(lsa_field** out, lsa_ctx* c, int sx, int sy, int cx, int cy
     if ((e = hipMalloc((void**)&f->d_lik, f->cells * 4)) != hipSuccess ||
         (e = hipMalloc((void**)&f->d_loglik, f->cells * 4)) != hipSuccess ||
         (e = hipMalloc((void**)&f->d_col, f->cells * 2)) != hipSuccess ||
-        (e = hipMalloc((void**)&f->d_tab, ((size_t)sx + 8) * ((size_t)sy + 8) * 4)) != hipSuccess) {
+        (e = hipMalloc((void**)&f->d_tab, (size_t)((sx + 8 + 3) / 4) * (size_t)((sy + 8 + 7) / 8) * 128)) != hipSuccess) {
         lsa_field_destroy(f);
         return fail(LSA_E_NOMEM, "hipMalloc(field)", e);
     }
@@ -1071,6 +1071,7 @@ static lsa::PfField pf_field(const lsa_field* f)
     const double need = (double)((f->F.size_x > f->F.size_y ? f->F.size_x : f->F.size_y) + 8);
     while (fb > 4 && need * (double)(1u << fb) >= 4294967296.0) --fb;
     F.fb = fb;
+    F.tile_row = 32u * (unsigned)((f->F.size_y + 8 + 7) / 8);
     const double s = (double)(1u << fb);
     F.inv_s = s / f->F.res;
     F.cx_s = ((double)f->F.center_x + 4.0) * s + 0.0005 * F.inv_s; F.cy_s = ((double)f->F.center_y + 4.0) * s + 0.0005 * F.inv_s;
@@ -1114,12 +1115,12 @@ int lsa_field_download(lsa_field* f, int what, float* h_out)
 
 static int pf_lanes(int n_poses, int nb)
 {
-    // lanes per pose: enough of them that a small set still fills the chip, as few as that allows for a large one
+    // lanes per pose: neighbouring lanes take neighbouring beams, which end in the same or a neighbouring 128-byte tile
     const char* e = getenv("LSA_PF_LANES");               // (experiments: tools/pf_probe.py)
     const int forced = e ? atoi(e) : 0;
     if (forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
-    if (nb < 64) return 8;
-    return n_poses >= (1 << 19) ? 16 : 32;
+    (void)n_poses;
+    return nb < 64 ? 8 : 16;              // (measured at 2^17 and 2^20 poses x 361 beams: 8 and 16 within 2 %, 32 and 64 behind by 9-14 %)
 }
 
 // scores of n poses with the lanes-over-beams kernel (also behind lsa_score_poses / lsa_score_poses_std)
@@ -1129,9 +1130,9 @@ static int pf_score(lsa_field* f, bool std_frame, const float* d_scan_x, const f
 {
     const int nb = (n_points + decimation - 1) / decimation;
     if (nb * 8 > 60 * 1024) return fail(LSA_E_ARG, "too many scan points for the LDS stage");
-    if (((size_t)f->F.size_x + 8) * ((size_t)f->F.size_y + 8) >= (1ull << 32)) return fail(LSA_E_ARG, "field too large for 32-bit cell offsets");
-    const int L = pf_lanes(P, nb), G = 256 / L;
-    const int blocks = blocks_for((size_t)P, G, 2048);
+    if (((size_t)f->F.size_x + 12) * ((size_t)f->F.size_y + 16) >= (1ull << 32)) return fail(LSA_E_ARG, "field too large for 32-bit cell offsets");
+    const int L = pf_lanes(P, nb);
+    const int blocks = blocks_for((size_t)P, lsa::PF_BATCH, 2048);
     const lsa::PfField F = pf_field(f);
     const size_t lds = (size_t)nb * 8;
     hipStream_t st = f->c->stream;

@@ -32,6 +32,7 @@ struct PfField {
     double cx_s, cy_s;        // (center + 4 + 0.0005 / res) * 2^fb
     float lo_x, hi_x, lo_y, hi_y;   // clamp of r - off: 2.5 cells beyond either edge (such a beam is outside the map wherever it is)
     int fb;
+    unsigned tile_row;        // floats per row of tiles: 32 * ceil((size_y + 8) / 8)
     float log_min;            // (float) log(minimum likelihood): the field's value outside the map
 };
 
@@ -55,10 +56,20 @@ __device__ __noinline__ int pf_cell_exact(float d, int center, double res)
     return (int)((double)center + ((double)d + 0.0005) / res);
 }
 
-// The table the scorer gathers from: the field's log-likelihoods with an apron of four cells on every side,
-// tab[cx + 4][cy + 4].  Everything the reference treats as outside the map (index < 0 or >= size - 1, VPmap.cpp:388-392)
-// holds log_min, and row / column 3 repeat row / column 4: (int) truncates towards zero, so v in (-1, 0) is cell 0.  With
-// r - off clamped to 2.5 cells beyond the edges the gather needs neither a bounds test nor a select.
+// The table the scorer gathers from: the field's log-likelihoods with an apron of four cells on every side, cell
+// (cx + 4, cy + 4) = (jx, jy), stored in tiles of 4 x 8 cells = one 128-byte line each:
+//     offset(jx, jy) = ((jx >> 2) * tiles_y + (jy >> 3)) * 32 + (jx & 3) * 8 + (jy & 7).
+// Neighbouring beams of a scan end a cell or two apart along a wall of any direction; in a row-major table they share a
+// line only when the wall runs along y (0.88 tag look-ups and 0.51 L2 requests per lane and beam, the L2 -> L1 path at its
+// limit: profiles/r03_pmc_score_poses.json), in tiles a run of 16 beams crosses about six lines.
+// Everything the reference treats as outside the map (index < 0 or >= size - 1, VPmap.cpp:388-392) holds log_min, and
+// row / column 3 repeat row / column 4: (int) truncates towards zero, so v in (-1, 0) is cell 0.  With r - off clamped to
+// 2.5 cells beyond the edges the gather needs neither a bounds test nor a select.
+__device__ __forceinline__ unsigned pf_tile_offset(unsigned jx, unsigned jy, unsigned tile_row)
+{
+    return (jx >> 2) * tile_row + ((jy >> 3) << 5) + ((jx & 3u) << 3) + (jy & 7u);
+}
+
 __global__ __launch_bounds__(256) void pf_table_kernel(PfField F, const float* __restrict__ loglik, float* __restrict__ tab)
 {
     const int px = F.size_x + 8, py = F.size_y + 8;
@@ -67,7 +78,7 @@ __global__ __launch_bounds__(256) void pf_table_kernel(PfField F, const float* _
         const int jx = (int)(c / py), jy = (int)(c - (size_t)jx * py);
         const int cx = jx == 3 ? 0 : jx - 4, cy = jy == 3 ? 0 : jy - 4;
         const bool in = cx >= 0 && cx < F.size_x - 1 && cy >= 0 && cy < F.size_y - 1;
-        tab[c] = in ? loglik[(size_t)cx * F.size_y + cy] : F.log_min;
+        tab[pf_tile_offset((unsigned)jx, (unsigned)jy, F.tile_row)] = in ? loglik[(size_t)cx * F.size_y + cy] : F.log_min;
     }
 }
 
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(256) void pf_table_kernel(PfField F, const float* _
 // the sum.  TAIL: beams past the scan add 0.
 template <bool STD, int L, bool TAIL>
 __device__ __forceinline__ double pf_four_beams(const PfField& F, const float* __restrict__ tab, const float2* pts, int k0, int nb,
-                                                float cs, float sn, float x, float y, unsigned pitch, unsigned fmask)
+                                                float cs, float sn, float x, float y, unsigned fmask)
 {
     unsigned cell[4];
     bool redo = false;
@@ -93,14 +104,18 @@ __device__ __forceinline__ double pf_four_beams(const PfField& F, const float* _
         const unsigned ux = (unsigned)__builtin_fma((double)dxc, F.inv_s, F.cx_s);
         const unsigned uy = (unsigned)__builtin_fma((double)dyc, F.inv_s, F.cy_s);
         redo |= min((ux + 2u) & fmask, (uy + 2u) & fmask) < 4u;
-        cell[u] = (ux >> F.fb) * pitch + (uy >> F.fb);
+        // the tile offset straight from the fixed-point values: jy << 2 and jx << 3 carry the line's bits in place, the bits
+        // below them are replaced (v_bfi) by jy & 7 and jx & 3
+        const unsigned a = uy >> (F.fb - 2), jy = uy >> F.fb, sx3 = ux >> (F.fb - 3), hi = ux >> (F.fb + 2);
+        const unsigned low = (sx3 & 0x18u) | (((jy & 7u) | (a & ~7u)) & ~0x18u);
+        cell[u] = hi * F.tile_row + low;
     }
     if (__builtin_expect(__any(redo), 0)) {
         #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int cx = pf_cell_exact(dxs[u], F.center_x, F.res), cy = pf_cell_exact(dys[u], F.center_y, F.res);
             const bool oob = (unsigned)cx >= (unsigned)(F.size_x - 1) || (unsigned)cy >= (unsigned)(F.size_y - 1) || !(dxs[u] == dxs[u]) || !(dys[u] == dys[u]);
-            cell[u] = oob ? 0u : ((unsigned)cx + 4u) * pitch + (unsigned)cy + 4u;
+            cell[u] = oob ? 0u : pf_tile_offset((unsigned)cx + 4u, (unsigned)cy + 4u, F.tile_row);
         }
     }
     float v[4];
@@ -116,8 +131,12 @@ __device__ __forceinline__ double pf_four_beams(const PfField& F, const float* _
     return acc;
 }
 
-// L lanes share a pose and take every L-th beam; the per-lane partial sums are exact in double (every term is a float
-// in (-8, -2^-5], a multiple of 2^-28), so the score does not depend on L or on the order of the additions.
+// A workgroup takes 64 poses at a time: one wave prepares them, one pose per lane (prediction, heading, cos / sin - once per
+// pose, not once per lane that works on it), then L lanes share a pose and take every L-th beam.  The per-lane partial
+// sums are exact in double (every term is a float in (-8, -2^-5], a multiple of 2^-28), so the score does not depend on L
+// or on the order of the additions.
+constexpr int PF_BATCH = 64;
+
 template <bool STD, int L>
 __global__ __launch_bounds__(256) void pf_score_kernel(
     PfField F, const float* __restrict__ tab, const float* __restrict__ sx, const float* __restrict__ sy, int n_points,
@@ -127,51 +146,60 @@ __global__ __launch_bounds__(256) void pf_score_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* pts = (float2*)smem;
     __shared__ unsigned long long wbest[4];
+    __shared__ float4 prep[PF_BATCH];                 // x, y, cos, sin of the batch's poses
     const int nb = (n_points + decim - 1) / decim;
     for (int k = threadIdx.x; k < nb; k += blockDim.x) pts[k] = make_float2(sx[k * decim], sy[k * decim]);
-    __syncthreads();
-    constexpr int G = 256 / L;                       // poses per trip of the workgroup
+    constexpr int G = 256 / L;                        // poses per trip of the workgroup
     const int sub = (int)threadIdx.x % L, grp = (int)threadIdx.x / L;
-    const unsigned pitch = (unsigned)F.size_y + 8u;
     const unsigned fmask = (1u << F.fb) - 1u;
     unsigned long long best = 0;
-    for (long long p0 = (long long)blockIdx.x * G; p0 < P; p0 += (long long)gridDim.x * G) {
-        const int p = (int)p0 + grp;
-        const bool live = p < P;
-        const int pc = live ? p : P - 1;
-        float x = poses[3 * (size_t)pc], y = poses[3 * (size_t)pc + 1], t = poses[3 * (size_t)pc + 2];
-        if (pr.mode == 1) {
-            x = (float)(pr.m[0] + (double)normals[3 * (size_t)pc] * pr.s[0]);
-            y = (float)(pr.m[1] + (double)normals[3 * (size_t)pc + 1] * pr.s[1]);
-            t = (float)(pr.m[2] + (double)normals[3 * (size_t)pc + 2] * pr.s[2]);
-        } else if (pr.mode == 2) {
-            const double c = (double)cosf_(t), s = (double)sinf_(t);
-            const double ix = pr.m[0] + (double)normals[3 * (size_t)pc] * pr.s[0], iy = pr.m[1] + (double)normals[3 * (size_t)pc + 1] * pr.s[1];
-            double nt = (double)t + (pr.m[2] + (double)normals[3 * (size_t)pc + 2] * pr.s[2]);
-            nt = nt - 6.28318530717958647692 * floor((nt + 3.14159265358979323846) / 6.28318530717958647692);
-            if (nt <= -3.14159265358979323846) nt += 6.28318530717958647692;          // (-pi, pi]
-            x = (float)((double)x + (ix * c - iy * s));
-            y = (float)((double)y + (ix * s + iy * c));
-            t = (float)nt;
+    for (long long p0 = (long long)blockIdx.x * PF_BATCH; p0 < P; p0 += (long long)gridDim.x * PF_BATCH) {
+        __syncthreads();                              // (the scan points the first time; the previous batch's poses after that)
+        if (threadIdx.x < PF_BATCH) {
+            const long long p = p0 + threadIdx.x;
+            const size_t pc = (size_t)(p < P ? p : P - 1);
+            float x = poses[3 * pc], y = poses[3 * pc + 1], t = poses[3 * pc + 2];
+            if (pr.mode == 1) {
+                x = (float)(pr.m[0] + (double)normals[3 * pc] * pr.s[0]);
+                y = (float)(pr.m[1] + (double)normals[3 * pc + 1] * pr.s[1]);
+                t = (float)(pr.m[2] + (double)normals[3 * pc + 2] * pr.s[2]);
+            } else if (pr.mode == 2) {
+                const double c = (double)cosf_(t), s = (double)sinf_(t);
+                const double ix = pr.m[0] + (double)normals[3 * pc] * pr.s[0], iy = pr.m[1] + (double)normals[3 * pc + 1] * pr.s[1];
+                double nt = (double)t + (pr.m[2] + (double)normals[3 * pc + 2] * pr.s[2]);
+                nt = nt - 6.28318530717958647692 * floor((nt + 3.14159265358979323846) / 6.28318530717958647692);
+                if (nt <= -3.14159265358979323846) nt += 6.28318530717958647692;          // (-pi, pi]
+                x = (float)((double)x + (ix * c - iy * s));
+                y = (float)((double)y + (ix * s + iy * c));
+                t = (float)nt;
+            }
+            if (pr.mode != 0 && p < P) { poses[3 * pc] = x; poses[3 * pc + 1] = y; poses[3 * pc + 2] = t; }
+            // th = normAngle(theta - M_PI/2, -M_PI), VPmap.cpp:366 (M_PI is PolarParameter.h's 3.141592654 there, normAngle wraps by the true 2 pi)
+            double th = STD ? (double)t : (double)t - LSA_ZPI / 2.0;
+            while (th >= -LSA_ZPI + 6.28318530717958647692) th -= 6.28318530717958647692;
+            while (th < -LSA_ZPI) th += 6.28318530717958647692;
+            float cs, sn;
+            sincosf_fast((float)th, sn, cs);
+            prep[threadIdx.x] = make_float4(x, y, cs, sn);
         }
-        if (pr.mode != 0 && live && sub == 0) { poses[3 * (size_t)p] = x; poses[3 * (size_t)p + 1] = y; poses[3 * (size_t)p + 2] = t; }
-        // th = normAngle(theta - M_PI/2, -M_PI), VPmap.cpp:366 (M_PI is PolarParameter.h's 3.141592654 there, normAngle wraps by the true 2 pi)
-        double th = STD ? (double)t : (double)t - LSA_ZPI / 2.0;
-        while (th >= -LSA_ZPI + 6.28318530717958647692) th -= 6.28318530717958647692;
-        while (th < -LSA_ZPI) th += 6.28318530717958647692;
-        float cs, sn;
-        sincosf_fast((float)th, sn, cs);
-        double acc = 0.0;
-        int k0 = sub;
-        for (; k0 + 3 * L < nb; k0 += 4 * L) acc += pf_four_beams<STD, L, false>(F, tab, pts, k0, nb, cs, sn, x, y, pitch, fmask);
-        if (k0 < nb) acc += pf_four_beams<STD, L, true>(F, tab, pts, k0, nb, cs, sn, x, y, pitch, fmask);
-        #pragma unroll
-        for (int off = L / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-        const float sc = (float)acc;
-        if (live && sub == 0) {
-            score[p] = sc;
-            const unsigned long long key = ((unsigned long long)f_ord(sc) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(first_index + p));
-            best = key > best ? key : best;
+        __syncthreads();
+        #pragma unroll 1
+        for (int slot = grp; slot < PF_BATCH; slot += G) {
+            const long long p = p0 + slot;
+            if (p >= P) break;                        // (slots are taken in order: the whole group leaves together)
+            const float4 q = prep[slot];
+            double acc = 0.0;
+            int k0 = sub;
+            for (; k0 + 3 * L < nb; k0 += 4 * L) acc += pf_four_beams<STD, L, false>(F, tab, pts, k0, nb, q.z, q.w, q.x, q.y, fmask);
+            if (k0 < nb) acc += pf_four_beams<STD, L, true>(F, tab, pts, k0, nb, q.z, q.w, q.x, q.y, fmask);
+            #pragma unroll
+            for (int off = L / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+            if (sub == 0) {
+                const float sc = (float)acc;
+                score[p] = sc;
+                const unsigned long long key = ((unsigned long long)f_ord(sc) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(first_index + p));
+                best = key > best ? key : best;
+            }
         }
     }
     if (best_key) {
@@ -196,7 +224,9 @@ struct PfRecord {
     uint32_t has_best;            // ... flag
 };
 
-constexpr int PFW_ITEMS = 4, PFW_SPAN = 256 * PFW_ITEMS;     // particles per workgroup of the weights pass
+// particles per workgroup of the weights pass: same-address atomics take some 50 ns each on this chip whoever issues them, so
+// the ticket of the last-workgroup pattern costs that per workgroup - few, long workgroups
+constexpr int PFW_ITEMS = 16, PFW_SPAN = 256 * PFW_ITEMS;
 
 __device__ __forceinline__ unsigned long long pf_quantise(float wv)
 {
@@ -225,11 +255,22 @@ __global__ __launch_bounds__(256) void pf_weights_kernel(
     const int base = ((int)blockIdx.x * 256 + (int)threadIdx.x) * PFW_ITEMS;
     unsigned long long v[PFW_ITEMS], run = 0;
     double s = 0, s2 = 0;
+    float sc[PFW_ITEMS];
+    if (base + PFW_ITEMS <= P) {
+        #pragma unroll
+        for (int k = 0; k < PFW_ITEMS; k += 4) {
+            const float4 t = *(const float4*)(score + base + k);
+            sc[k] = t.x; sc[k + 1] = t.y; sc[k + 2] = t.z; sc[k + 3] = t.w;
+        }
+    } else {
+        #pragma unroll
+        for (int k = 0; k < PFW_ITEMS; ++k) sc[k] = base + k < P ? score[base + k] : 0.0f;
+    }
     #pragma unroll
     for (int k = 0; k < PFW_ITEMS; ++k) {
         unsigned long long q = 0;
         if (base + k < P) {
-            const float wv = expf(score[base + k] - gmax);
+            const float wv = expf(sc[k] - gmax);
             if (w_out) w_out[base + k] = wv;
             s += (double)wv; s2 += (double)wv * (double)wv;
             q = pf_quantise(wv);
@@ -342,13 +383,17 @@ __global__ __launch_bounds__(256) void pf_offspring_kernel(
         }
     }
     if (!mm) return;
+    // one value per workgroup and slot, and only a workgroup that can still raise a slot adds to the queue of its atomics
+    __shared__ int red[4][6];
     #pragma unroll
     for (int e = 0; e < 3; ++e) {
         for (int off = 32; off >= 1; off >>= 1) { lo[e] = max(lo[e], __shfl_xor(lo[e], off)); hi[e] = max(hi[e], __shfl_xor(hi[e], off)); }
-        if (lane_id() == 0) {
-            if (lo[e] != (int)0x80000000) atomicMax(&mm[e], lo[e]);
-            if (hi[e] != (int)0x80000000) atomicMax(&mm[3 + e], hi[e]);
-        }
+        if (lane_id() == 0) { red[threadIdx.x >> 6][e] = lo[e]; red[threadIdx.x >> 6][3 + e] = hi[e]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int v = max(max(red[0][threadIdx.x], red[1][threadIdx.x]), max(red[2][threadIdx.x], red[3][threadIdx.x]));
+        if (v != (int)0x80000000 && v > __hip_atomic_load(&mm[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&mm[threadIdx.x], v);
     }
 }
 

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ s
         const unsigned long long o = __shfl_xor(best, off);
         best = o > best ? o : best;
     }
-    if (lane_id() == 0) atomicMax(key, best);
+    // same-address atomics queue up (some 50 ns each): a wave adds to the queue only if it can still raise the slot
+    if (lane_id() == 0 && best > __hip_atomic_load(key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(key, best);
 }
 
 // w = exp(score - max); block partial sums of w and w^2 (double) -> sums[2*block]
@@ -384,7 +385,10 @@ __global__ __launch_bounds__(256) void pf_minmax_kernel(int n, const float* __re
             const uint32_t a = __shfl_xor(lo[d], o), b = __shfl_xor(hi[d], o);
             lo[d] = a < lo[d] ? a : lo[d]; hi[d] = b > hi[d] ? b : hi[d];
         }
-        if ((threadIdx.x & 63) == 0) { atomicMin(&mm[d], lo[d]); atomicMax(&mm[3 + d], hi[d]); }
+        if ((threadIdx.x & 63) == 0) {                       // (filtered like argmax_kernel's)
+            if (lo[d] < __hip_atomic_load(&mm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&mm[d], lo[d]);
+            if (hi[d] > __hip_atomic_load(&mm[3 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&mm[3 + d], hi[d]);
+        }
     }
 }
 

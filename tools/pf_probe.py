@@ -16,11 +16,15 @@ stream = torch.cuda.Stream(); torch.cuda.set_stream(stream); ctx.set_stream(stre
 grid, fld, d_sx, d_sy, n = bench.pf_world(torch, capi, ctx, raw, p)
 
 def timed(fn, reps=20):
+    """median over `reps` of 5 back-to-back calls each (one slow call - an allocation, a page fault - does not show)"""
     fn(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps): fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps * 1e3
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for _ in range(5): fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / 5 * 1e3)
+    return float(np.median(ts))
 
 for P in (1 << 20, 1 << 17):
     rng = np.random.default_rng(1)
