@@ -110,7 +110,8 @@ int lsa_ctx_sync(lsa_ctx* c);
 void lsa_ctx_destroy(lsa_ctx* c);
 
 /* ---- device memory helpers (for C/C++ hosts without their own allocator) --- */
-int lsa_malloc(void** d_ptr, uint64_t bytes);
+int lsa_malloc(void** d_ptr, uint64_t bytes);                    /* on the calling thread's current device */
+int lsa_ctx_malloc(lsa_ctx* c, void** d_ptr, uint64_t bytes);     /* on the context's device (what a host with LSA_DEVICE != 0 or several threads wants) */
 int lsa_free(void* d_ptr);
 int lsa_memcpy_h2d(lsa_ctx* c, void* d_dst, const void* h_src, uint64_t bytes);
 int lsa_memcpy_d2h(lsa_ctx* c, void* h_dst, const void* d_src, uint64_t bytes);

@@ -418,6 +418,12 @@ int lsa_malloc(void** d, uint64_t bytes)
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? LSA_E_NOMEM : LSA_E_HIP, "hipMalloc", e);
     return LSA_OK;
 }
+int lsa_ctx_malloc(lsa_ctx* c, void** d, uint64_t bytes)
+{
+    if (!c) return fail(LSA_E_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    return lsa_malloc(d, bytes);
+}
 int lsa_free(void* d) { HIP_TRY(hipFree(d)); return LSA_OK; }
 int lsa_memcpy_h2d(lsa_ctx* c, void* d, const void* h, uint64_t bytes)
 {

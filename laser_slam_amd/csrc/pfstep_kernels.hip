@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void pf_score_kernel(
                 const double c = (double)cosf_(t), s = (double)sinf_(t);
                 const double ix = pr.m[0] + (double)normals[3 * pc] * pr.s[0], iy = pr.m[1] + (double)normals[3 * pc + 1] * pr.s[1];
                 double nt = (double)t + (pr.m[2] + (double)normals[3 * pc + 2] * pr.s[2]);
-                nt = nt - 6.28318530717958647692 * floor((nt + 3.14159265358979323846) / 6.28318530717958647692);
-                if (nt <= -3.14159265358979323846) nt += 6.28318530717958647692;          // (-pi, pi]
+                while (nt > 3.14159265358979323846) nt -= 6.28318530717958647692;           // (-pi, pi], the true pi
+                while (nt <= -3.14159265358979323846) nt += 6.28318530717958647692;
                 x = (float)((double)x + (ix * c - iy * s));
                 y = (float)((double)y + (ix * s + iy * c));
                 t = (float)nt;
@@ -176,8 +176,9 @@ __global__ __launch_bounds__(256) void pf_score_kernel(
             if (pr.mode != 0 && p < P) { poses[3 * pc] = x; poses[3 * pc + 1] = y; poses[3 * pc + 2] = t; }
             // th = normAngle(theta - M_PI/2, -M_PI), VPmap.cpp:366 (M_PI is PolarParameter.h's 3.141592654 there, normAngle wraps by the true 2 pi)
             double th = STD ? (double)t : (double)t - LSA_ZPI / 2.0;
-            while (th >= -LSA_ZPI + 6.28318530717958647692) th -= 6.28318530717958647692;
-            while (th < -LSA_ZPI) th += 6.28318530717958647692;
+            const double th_lo = STD ? -3.14159265358979323846 : -LSA_ZPI;       // (the plain frame has no business with the reference's pi)
+            while (th >= th_lo + 6.28318530717958647692) th -= 6.28318530717958647692;
+            while (th < th_lo) th += 6.28318530717958647692;
             float cs, sn;
             sincosf_fast((float)th, sn, cs);
             prep[threadIdx.x] = make_float4(x, y, cs, sn);

@@ -364,7 +364,8 @@ __global__ __launch_bounds__(256) void pf_motion_kernel(int n, double dx, double
         const double ix = dx + (double)normals[3 * (size_t)i] * sx, iy = dy + (double)normals[3 * (size_t)i + 1] * sy;
         const double it = dth + (double)normals[3 * (size_t)i + 2] * sth;
         double nt = (double)th + it;
-        if (nt > LSA_ZPI) nt -= 2.0 * LSA_ZPI; else if (nt <= -LSA_ZPI) nt += 2.0 * LSA_ZPI;
+        while (nt > 3.14159265358979323846) nt -= 6.28318530717958647692;           // (-pi, pi]: MRPT-style callers compare with the true pi
+        while (nt <= -3.14159265358979323846) nt += 6.28318530717958647692;
         poses[3 * (size_t)i]     = (float)((double)poses[3 * (size_t)i] + (ix * c - iy * s));
         poses[3 * (size_t)i + 1] = (float)((double)poses[3 * (size_t)i + 1] + (ix * s + iy * c));
         poses[3 * (size_t)i + 2] = (float)nt;

@@ -87,12 +87,12 @@ void CPMap::flushPending()
     const size_t pts = S * (size_t)m_qstride;
     if (m_dcap_pts < pts) {
         if (m_dx) { lsa_free(m_dx); lsa_free(m_dy); m_dx = m_dy = 0; m_dcap_pts = 0; }
-        must(lsa_malloc(&m_dx, pts * 4), "lsa_malloc"); must(lsa_malloc(&m_dy, pts * 4), "lsa_malloc");
+        must(lsa_ctx_malloc(m_ctx, &m_dx, pts * 4), "lsa_malloc"); must(lsa_ctx_malloc(m_ctx, &m_dy, pts * 4), "lsa_malloc");
         m_dcap_pts = pts;
     }
     if (m_dcap_scans < S) {
         if (m_drob) { lsa_free(m_drob); lsa_free(m_dn); m_drob = m_dn = 0; m_dcap_scans = 0; }
-        must(lsa_malloc(&m_drob, S * 8), "lsa_malloc"); must(lsa_malloc(&m_dn, S * 4), "lsa_malloc");
+        must(lsa_ctx_malloc(m_ctx, &m_drob, S * 8), "lsa_malloc"); must(lsa_ctx_malloc(m_ctx, &m_dn, S * 4), "lsa_malloc");
         m_dcap_scans = S;
     }
     must(lsa_memcpy_h2d(m_ctx, m_dx, m_qx.data(), pts * 4), "h2d"); must(lsa_memcpy_h2d(m_ctx, m_dy, m_qy.data(), pts * 4), "h2d");
@@ -109,11 +109,11 @@ void CPMap::updateMapBatch(const float* gx, const float* gy, int n_scans, int n_
     flushPending();
     const size_t pts = (size_t)n_scans * n_beams;
     void *dx = 0, *dy = 0, *dr = 0, *dn = 0;
-    must(lsa_malloc(&dx, pts * 4), "lsa_malloc"); must(lsa_malloc(&dy, pts * 4), "lsa_malloc");
-    must(lsa_malloc(&dr, (size_t)n_scans * 8), "lsa_malloc");
+    must(lsa_ctx_malloc(m_ctx, &dx, pts * 4), "lsa_malloc"); must(lsa_ctx_malloc(m_ctx, &dy, pts * 4), "lsa_malloc");
+    must(lsa_ctx_malloc(m_ctx, &dr, (size_t)n_scans * 8), "lsa_malloc");
     must(lsa_memcpy_h2d(m_ctx, dx, gx, pts * 4), "h2d"); must(lsa_memcpy_h2d(m_ctx, dy, gy, pts * 4), "h2d");
     must(lsa_memcpy_h2d(m_ctx, dr, robot_xy, (size_t)n_scans * 8), "h2d");
-    if (n_valid) { must(lsa_malloc(&dn, (size_t)n_scans * 4), "lsa_malloc"); must(lsa_memcpy_h2d(m_ctx, dn, n_valid, (size_t)n_scans * 4), "h2d"); }
+    if (n_valid) { must(lsa_ctx_malloc(m_ctx, &dn, (size_t)n_scans * 4), "lsa_malloc"); must(lsa_memcpy_h2d(m_ctx, dn, n_valid, (size_t)n_scans * 4), "h2d"); }
     must(lsa_grid_update_batch(m_grid, n_scans, n_beams, (float*)dx, (float*)dy, (float*)dr, (int32_t*)dn), "lsa_grid_update_batch");
     must(lsa_ctx_sync(m_ctx), "sync");
     lsa_free(dx); lsa_free(dy); lsa_free(dr); if (dn) lsa_free(dn);

@@ -629,7 +629,7 @@ lsa_gridmap_impl* COccupancyGridMap2D::device() const
     lsa_ctx* c = device_ctx();
     m_dev = new lsa_gridmap_impl;
     lsa_ok(lsa_field_create(&m_dev->field, c, (int)m_sx, (int)m_sy, 0, 0, m_xmin, m_ymin, (double)m_res), "lsa_field_create");
-    lsa_ok(lsa_malloc((void**)&m_dev->d_prob, sizeof(float) * m_occ.size()), "lsa_malloc");
+    lsa_ok(lsa_ctx_malloc(c, (void**)&m_dev->d_prob, sizeof(float) * m_occ.size()), "lsa_malloc");
     lsa_ok(lsa_memcpy_h2d(c, m_dev->d_prob, m_occ.data(), sizeof(float) * m_occ.size()), "lsa_memcpy_h2d");
     lsa_ok(lsa_field_build(m_dev->field, m_dev->d_prob, 1.0f, 0.3f, 0.5f), "lsa_field_build");
     return m_dev;
@@ -698,10 +698,11 @@ struct lsa_mcl_impl {
         release();
         n = m;
         const size_t b3 = sizeof(float) * 3 * n, b1 = sizeof(float) * n;
-        lsa_ok(lsa_malloc((void**)&d_poses, b3), "lsa_malloc"); lsa_ok(lsa_malloc((void**)&d_tmp, b3), "lsa_malloc");
-        lsa_ok(lsa_malloc((void**)&d_normals, b3), "lsa_malloc"); lsa_ok(lsa_malloc((void**)&d_score, b1), "lsa_malloc");
-        lsa_ok(lsa_malloc((void**)&d_logw, b1), "lsa_malloc"); lsa_ok(lsa_malloc((void**)&d_w, b1), "lsa_malloc");
-        lsa_ok(lsa_malloc((void**)&d_parent, sizeof(int32_t) * n), "lsa_malloc");
+        lsa_ctx* c = device_ctx();          // (the buffers have to live on the device the context launches on, whatever the thread's current one is)
+        lsa_ok(lsa_ctx_malloc(c, (void**)&d_poses, b3), "lsa_malloc"); lsa_ok(lsa_ctx_malloc(c, (void**)&d_tmp, b3), "lsa_malloc");
+        lsa_ok(lsa_ctx_malloc(c, (void**)&d_normals, b3), "lsa_malloc"); lsa_ok(lsa_ctx_malloc(c, (void**)&d_score, b1), "lsa_malloc");
+        lsa_ok(lsa_ctx_malloc(c, (void**)&d_logw, b1), "lsa_malloc"); lsa_ok(lsa_ctx_malloc(c, (void**)&d_w, b1), "lsa_malloc");
+        lsa_ok(lsa_ctx_malloc(c, (void**)&d_parent, sizeof(int32_t) * n), "lsa_malloc");
         h_poses.assign(3 * n, 0.0f); h_logw.assign(n, 0.0f); h_score.assign(n, 0.0f); h_normals.assign(3 * n, 0.0f);
     }
     void upload_poses()
@@ -865,8 +866,8 @@ void CParticleFilter::executeOn(CMonteCarloLocalization2D& pdf, const CActionCol
                 if (I.d_sx) lsa_free(I.d_sx);
                 if (I.d_sy) lsa_free(I.d_sy);
                 I.scan_cap = sx.size() + 64;
-                lsa_ok(lsa_malloc((void**)&I.d_sx, sizeof(float) * I.scan_cap), "lsa_malloc");
-                lsa_ok(lsa_malloc((void**)&I.d_sy, sizeof(float) * I.scan_cap), "lsa_malloc");
+                lsa_ok(lsa_ctx_malloc(c, (void**)&I.d_sx, sizeof(float) * I.scan_cap), "lsa_malloc");
+                lsa_ok(lsa_ctx_malloc(c, (void**)&I.d_sy, sizeof(float) * I.scan_cap), "lsa_malloc");
             }
             lsa_ok(lsa_memcpy_h2d(c, I.d_sx, sx.data(), sizeof(float) * sx.size()), "lsa_memcpy_h2d");
             lsa_ok(lsa_memcpy_h2d(c, I.d_sy, sy.data(), sizeof(float) * sy.size()), "lsa_memcpy_h2d");

@@ -61,8 +61,9 @@ static void score_poses(int std_frame, const float* lik, int sx, int sy, int cx0
     for (int p = 0; p < P; ++p) {
         const double px = poses[3 * p], py = poses[3 * p + 1];
         double th = std_frame ? (double)poses[3 * p + 2] : (double)poses[3 * p + 2] - Z_PI / 2.0;            /* :366 */
-        while (th >= -Z_PI + 2 * 3.14159265358979323846) th -= 2 * 3.14159265358979323846;
-        while (th < -Z_PI) th += 2 * 3.14159265358979323846;
+        const double th_lo = std_frame ? -3.14159265358979323846 : -Z_PI;
+        while (th >= th_lo + 2 * 3.14159265358979323846) th -= 2 * 3.14159265358979323846;
+        while (th < th_lo) th += 2 * 3.14159265358979323846;
         const float cs = cosf((float)th), sn = sinf((float)th);
         double acc = 0;
         for (int j = 0; j < n_points; j += decim) {

@@ -178,7 +178,8 @@ void orc_pf_motion(int n, const double delta[3], const double sigma[3], const fl
         const double ix = delta[0] + (double)normals[3 * i] * sigma[0], iy = delta[1] + (double)normals[3 * i + 1] * sigma[1];
         const double it = delta[2] + (double)normals[3 * i + 2] * sigma[2];
         double nt = (double)th + it;
-        if (nt > PI) nt -= 2.0 * PI; else if (nt <= -PI) nt += 2.0 * PI;
+        while (nt > PI) nt -= 2.0 * PI;
+        while (nt <= -PI) nt += 2.0 * PI;
         poses[3 * i]     = (float)((double)poses[3 * i] + (ix * c - iy * s));
         poses[3 * i + 1] = (float)((double)poses[3 * i + 1] + (ix * s + iy * c));
         poses[3 * i + 2] = (float)nt;
