@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spe
 # waves of a SIMD are ready (MI355X_MICROARCH.md: `v_fma_f32` 2 cyc, one wave alone 4; transcendentals 8), at 2.4 GHz
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0
 FP32_PEAK_TFLOPS = 157.3
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 N_BASE, SEEDS = 200, 8
 
 
@@ -193,7 +193,13 @@ def pmc_per_unit(kernel):
         units = rec.get("units_per_launch")
         if units:
             out["valu_instr_per_unit"] = rec["SQ_INSTS_VALU"] / units
-        out["valu_busy_frac"] = rec["SQ_ACTIVE_INST_VALU"] / (rec["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0)
+        # share of the SIMDs' time with a vector instruction in flight: SQ_ACTIVE_INST_VALU (quad-cycles, summed over the SIMDs)
+        # over the quad-cycles the SIMDs had while the kernel's waves were resident (SQ_BUSY_CYCLES: per shader engine, all
+        # of whose SIMDs tick together - the GRBM counter round 2 divided by also ticks between dispatches and on idle XCDs)
+        if rec.get("SQ_BUSY_CU_CYCLES"):
+            out["valu_busy_frac"] = min(1.0, rec["SQ_ACTIVE_INST_VALU"] / (rec["SQ_BUSY_CU_CYCLES"] * 4.0))
+        if rec.get("SQ_WAVE_CYCLES") and rec.get("SQ_WAIT_ANY") is not None:
+            out["wave_wait_frac"] = rec["SQ_WAIT_ANY"] / rec["SQ_WAVE_CYCLES"]
         if rec.get("SQ_THREAD_CYCLES_VALU") and rec.get("SQ_INSTS_VALU"):
             out["valu_lane_util"] = rec["SQ_THREAD_CYCLES_VALU"] / (rec["SQ_INSTS_VALU"] * 64.0)
     if hbm and key in hbm:
@@ -214,16 +220,16 @@ def valu_roofline(kernel, units_per_s, kernel_ms, units_per_launch, alg_bytes_pe
          "frac": ipu * units_per_s / 1e9 / VALU_PEAK_GINSTR if ipu else None,
          "traffic": pm["hbm_bytes_per_unit"] * units_per_launch if "hbm_bytes_per_unit" in pm else None,
          "kernel": kernel, "kernel_ms": kernel_ms, "valu_instr_per_unit": ipu, "valu_busy_frac": pm.get("valu_busy_frac"),
-         "valu_lane_util": pm.get("valu_lane_util"),
+         "valu_lane_util": pm.get("valu_lane_util"), "wave_wait_frac": pm.get("wave_wait_frac"),
          "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                  "bytes_per_unit": alg_bytes_per_unit},
          "note": "vector-instruction-issue bound (DESIGN.md 4.1): achieved = wave64 VALU instructions per unit (rocprofv3 "
                  "SQ_INSTS_VALU, profiles/%s_pmc_sq_counters.json) x units/s measured here; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 "
                  "cycles per single-precision instruction (the mix here also holds double-precision and transcendental "
-                 "instructions that take 4 and 8, and a lone ready wave issues every 4); valu_busy_frac = rocprof's VALUBusy, "
-                 "SQ_ACTIVE_INST_VALU quad-cycles over the SIMDs' quad-cycles at the clock the chip held; valu_lane_util = active "
-                 "lanes per vector instruction / 64 (SQ_THREAD_CYCLES_VALU); hbm = algorithmic "
-                 "bytes of SURVEY 8d" % PROFILE_ROUND}
+                 "instructions that take 4 and 8, and a lone ready wave issues every 4); valu_busy_frac = SQ_ACTIVE_INST_VALU / "
+                 "(4 SIMDs x SQ_BUSY_CU_CYCLES), the share of the busy CUs' SIMD time with a vector instruction in flight (<= 1); "
+                 "wave_wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES; valu_lane_util = active lanes per vector instruction / 64 "
+                 "(SQ_THREAD_CYCLES_VALU); hbm = algorithmic bytes of SURVEY 8d" % PROFILE_ROUND}
     if extra:
         r.update(extra)
     return r
@@ -413,6 +419,7 @@ def main():
             if world == 1:
                 sec.update(secondary_grid(torch, capi, ctx, raw, p))
                 sec.update(secondary_logs(torch, capi))
+                sec.update(secondary_latency(torch, capi, raw))
     if watchdog is not None:
         watchdog.cancel()
     if rank == 0:
@@ -456,15 +463,17 @@ def secondary_matchers(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, which
     other = capi.MATCH_PSM if which == capi.MATCH_ICP else capi.MATCH_ICP
     oname = "psm" if other == capi.MATCH_PSM else "icp"
     pose = torch.zeros(B, 3, device="cuda")
-    ms = timed(torch, lambda: ctx.match_batch(other, B, d_r, d_bad, d_seg, d_ri, d_ai, pose), reps=1)
+    ms = timed(torch, lambda: ctx.match_batch(other, B, d_r, d_bad, d_seg, d_ri, d_ai, pose), reps=3)
     res["pm_%s" % oname] = {"value": B / (ms * 1e-3), "unit": "scan-matches/s", "pairs": B,
                             "roofline": valu_roofline("%s_kernel" % oname, B / (ms * 1e-3), ms, B, BYTES_PER_PAIR)}
-    # point-to-line ICP (CCanonicalMatcher / zhcsm's matcher), raw scans, 8192 pairs
-    Bp = 8192
+    # point-to-line ICP (CCanonicalMatcher / zhcsm's matcher), raw scans, 2^17 pairs: a pair that restarts from six
+    # perturbed poses runs seven loops, and a small batch waits for its slowest pair (8192 pairs took 17.9 ms in round 2,
+    # 9 of them the tail of one such pair)
+    Bp = min(B, 1 << 17)
     d_raw = torch.from_numpy(raw).cuda()
     d_o8 = torch.zeros(Bp, 8, dtype=torch.float64, device="cuda")
     ri, ai = d_ri[:Bp].contiguous(), d_ai[:Bp].contiguous()
-    ms = timed(torch, lambda: capi.plicp_batch(ctx, Bp, d_raw, ri, ai, d_o8), reps=1)
+    ms = timed(torch, lambda: capi.plicp_batch(ctx, Bp, d_raw, ri, ai, d_o8), reps=3)
     res["plicp"] = {"value": Bp / (ms * 1e-3), "unit": "scan-matches/s", "pairs": Bp, "mean_iterations": float(d_o8[:, 5].mean().item()),
                     "roofline": valu_roofline("plicp_kernel", Bp / (ms * 1e-3), ms, Bp, BYTES_PER_PAIR,
                                               {"note": "double-precision point-to-line ICP (parity unpinned: CSM absent); "
@@ -473,29 +482,57 @@ def secondary_matchers(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, which
     Sp = 16384                                              # batched preprocessing (one lane per scan from 4096 scans on)
     big = np.tile(raw, ((Sp + S - 1) // S, 1))[:Sp]
     r2 = torch.from_numpy(big).cuda(); b2 = torch.zeros(Sp, n, dtype=torch.uint8, device="cuda"); s2 = torch.zeros(Sp, n, dtype=torch.int16, device="cuda")
-    ms = timed(torch, lambda: ctx.preprocess_batch(Sp, r2, b2, s2), reps=1)
+    ms = timed(torch, lambda: ctx.preprocess_batch(Sp, r2, b2, s2), reps=3)
     res["preprocess"] = {"value": Sp / (ms * 1e-3), "unit": "scans/s", "scans": Sp,
                          "roofline": hbm_roofline("preprocess_lanes_kernel", Sp * n * 12.0, ms, Sp,
                                                   "12 B per beam: ranges read and written, flags read and written, segments written")}
     return res
 
 
+def p2p_problems(x_cm, y_cm, ok, pairs, count):
+    """Concatenated clouds (metres) and offsets of `count` CICPWarpper problems: the given (reference, current) scan pairs
+    of a log head, repeated."""
+    clouds = [(x_cm[k][ok[k]] * 0.01, y_cm[k][ok[k]] * 0.01) for k in range(len(x_cm))]
+    sel = [pairs[i % len(pairs)] for i in range(count)]
+    rx = np.concatenate([clouds[a][0] for a, _ in sel]).astype(np.float32); ry = np.concatenate([clouds[a][1] for a, _ in sel]).astype(np.float32)
+    cx = np.concatenate([clouds[b][0] for _, b in sel]).astype(np.float32); cy = np.concatenate([clouds[b][1] for _, b in sel]).astype(np.float32)
+    ro = np.concatenate([[0], np.cumsum([len(clouds[a][0]) for a, _ in sel])]).astype(np.int32)
+    co = np.concatenate([[0], np.cumsum([len(clouds[b][0]) for _, b in sel])]).astype(np.int32)
+    return rx, ry, ro, cx, cy, co
+
+
+def p2p_entry(torch, capi, ctx, prob, count, what):
+    rx, ry, ro, cx, cy, co = prob
+    d = [torch.from_numpy(a).cuda() for a in (rx, ry, ro, cx, cy, co)]
+    init = torch.zeros(count, 3, dtype=torch.float64, device="cuda"); out = torch.zeros(count, 16, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    ms = timed(torch, lambda: capi.p2p_icp_batch(ctx, count, d[0], d[1], d[2], d[3], d[4], d[5], len(rx), len(cx), init, out), reps=3)
+    pts = (len(rx) + len(cx)) / count
+    return {"value": count / (ms * 1e-3), "unit": "scan-matches/s", "problems": count, "points_per_problem": pts, "what": what,
+            "mean_iterations": float(out[:, 5].mean().item()), "mean_goodness": float(out[:, 3].mean().item()),
+            "roofline": valu_roofline("p2p_icp_kernel", count / (ms * 1e-3), ms, count, pts * 8.0 + 24 + 128,
+                                      {"note": "CICPWarpper's point-to-point ICP (MRPT icpClassic restated, parity unpinned): "
+                                               "sorted-slab nearest neighbour in LDS, closed-form 2D fit in double; instruction bound"})}
+
+
 def secondary_logs(torch, capi, pairs=1 << 17):
-    """Both matchers on the heads of the reference's own logs (tests/golden/*_head.log, consecutive scans, zero prior),
-    each head's pairs repeated to `pairs` per launch: real scans need more iterations than the synthetic set and have a
-    third to a half of its beams."""
+    """All four matchers on the heads of the reference's own logs (tests/golden/*_head.*: the three CARMEN logs and the
+    in-house LMS151 log, consecutive scans, zero prior), each head's pairs repeated to `pairs` per launch (2^14 problems
+    for the point-to-point ICP): real scans need more iterations than the synthetic set and have a sixth to a half of
+    its beams.  The zhicp entries are BASELINE configs 1 and 2 (CICPWarpper on fr079 / intel-lab)."""
     res = {}
     for name, preset, fname, tag in (("fr079", "LMS511", "fr079_head.log", "ROBOTLASER1"), ("intel", "LMS211", "intel_head.log", "ROBOTLASER1"),
-                                     ("mit", "LMS511", "mit_head.log", "ROBOTLASER1")):
+                                     ("mit", "LMS511", "mit_head.log", "ROBOTLASER1"), ("indoor", "LMS151", "indoor_head.txt", "LMS151")):
         path = os.path.join(ROOT, "tests", "golden", fname)
         if not os.path.exists(path):
             continue
         p = capi.param_preset(preset)
-        r, _, _, bad, _ = capi.carmen_read(p, path, tag)
+        r, x, y, bad, _ = capi.carmen_read(p, path, tag)
         S, n = r.shape
         ctx = capi.Context(p)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)        # (so that torch's events bracket the kernels)
-        d_r = torch.from_numpy(r).cuda(); d_bad = torch.from_numpy(bad.astype(np.uint8)).cuda()
+        d_raw = torch.from_numpy(r).cuda()
+        d_r = d_raw.clone(); d_bad = torch.from_numpy(bad.astype(np.uint8)).cuda()
         d_seg = torch.zeros(S, n, dtype=torch.int16, device="cuda")
         torch.cuda.synchronize()
         ctx.preprocess_batch(S, d_r, d_bad, d_seg)
@@ -504,13 +541,82 @@ def secondary_logs(torch, capi, pairs=1 << 17):
         pose = torch.zeros(pairs, 3, device="cuda"); st = torch.zeros(pairs, dtype=torch.int32, device="cuda")
         it = torch.zeros(pairs, dtype=torch.int32, device="cuda")
         entry = {"beams": n, "scans": S, "pairs": pairs}
-        for which, nm in ((capi.MATCH_ICP, "pm_icp"), (capi.MATCH_PSM, "pm_psm")):
-            ms = timed(torch, lambda: ctx.match_batch(which, pairs, d_r, d_bad, d_seg, d_ri, d_ai, pose, d_status=st, d_iters=it), reps=1)
-            entry[nm] = {"value": pairs / (ms * 1e-3), "unit": "scan-matches/s", "mean_iterations": float(it.float().mean().item()),
-                         "failed_fraction": float((st != 0).float().mean().item())}
+        bytes_pair = 2 * n * 4 + 12 + 20
+        for which, nm, kn in ((capi.MATCH_ICP, "pm_icp", "icp_kernel<%d>" % n), (capi.MATCH_PSM, "pm_psm", "psm_kernel<%d>" % n)):
+            ms = timed(torch, lambda: ctx.match_batch(which, pairs, d_r, d_bad, d_seg, d_ri, d_ai, pose, d_status=st, d_iters=it), reps=3)
+            mi = float(it.float().mean().item())
+            entry[nm] = {"value": pairs / (ms * 1e-3), "unit": "scan-matches/s", "mean_iterations": mi,
+                         "failed_fraction": float((st != 0).float().mean().item()), "beam_iterations_per_s": pairs / (ms * 1e-3) * mi * n,
+                         "roofline": valu_roofline(kn, pairs / (ms * 1e-3), ms, pairs, bytes_pair)}
+        d_o8 = torch.zeros(pairs, 8, dtype=torch.float64, device="cuda")
+        ms = timed(torch, lambda: capi.plicp_batch(ctx, pairs, d_raw, d_ri, d_ai, d_o8), reps=3)
+        entry["plicp"] = {"value": pairs / (ms * 1e-3), "unit": "scan-matches/s", "mean_iterations": float(d_o8[:, 5].mean().item()),
+                          "valid_fraction": float(d_o8[:, 3].mean().item())}
+        if name in ("fr079", "intel"):
+            ok = (bad == 0) & (r < float(p.max_range))
+            cnt = 1 << 14
+            entry["zhicp_p2p"] = p2p_entry(torch, capi, ctx, p2p_problems(x, y, ok, [(k, k + 1) for k in range(S - 1)], cnt), cnt,
+                                           "CICPWarpper::ICPMatch on consecutive scans of the head (reader's points, readings at the maximum range dropped), zero prior")
         ctx.close()
         res["logs_" + name] = entry
+    # the reference's own map-node clouds (src/zhicp/data, the loop-closure use of CICPWarpper: MapNode.cpp:625-656)
+    zd = os.path.join(ROOT, "tests", "golden", "zhicp")
+    try:
+        rows = np.loadtxt(os.path.join(zd, "matched_nodes.log"))
+        ids = sorted({int(v) for row in rows for v in row[:2] if os.path.exists(os.path.join(zd, "%d.log" % int(v)))})
+        cl = {i: np.loadtxt(os.path.join(zd, "%d.log" % i), dtype=np.float32) for i in ids}
+        prs = [(ids.index(int(a)), ids.index(int(b))) for a, b, *_ in rows if int(a) in cl and int(b) in cl]
+        if prs:
+            xs = [cl[i][:, 0] * 100.0 for i in ids]; ys = [cl[i][:, 1] * 100.0 for i in ids]
+            oks = [np.ones(len(v), bool) for v in xs]
+            ctx = capi.Context(capi.param_preset("LMS211")); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            cnt = 1 << 12
+            res["zhicp_node_clouds"] = p2p_entry(torch, capi, ctx, p2p_problems(xs, ys, oks, prs, cnt), cnt,
+                                                 "CICPWarpper::ICPMatch on the reference's map-node clouds (src/zhicp/data), zero prior")
+            ctx.close()
+    except OSError:
+        pass
     return res
+
+
+def secondary_latency(torch, capi, raw1081):
+    """Single-call latency of the drop-in matchers' C-ABI entry points - the call pattern of src/slam (one FMatch per scan
+    under a mutex, threadLocal1.cpp:198-220): lsa_fmatch_host (CPolarMatch::FMatch: preprocessing of the new scan + pm_icp +
+    pm_error_index2 through the pinned staging block) and lsa_plicp_host (CCanonicalMatcher::FMatch) over consecutive scans
+    of the logs' heads and of the synthetic 1081-beam set.  Host buffers in, host results out: PCIe and the ctypes call
+    (a few microseconds) are inside the figures."""
+    from laser_slam_amd import synth
+    res = {}
+    cases = [("fr079", "LMS511", "fr079_head.log", "ROBOTLASER1"), ("intel", "LMS211", "intel_head.log", "ROBOTLASER1"),
+             ("indoor", "LMS151", "indoor_head.txt", "LMS151"), ("syn1081", None, None, None)]
+    for name, preset, fname, tag in cases:
+        if preset is None:
+            p = capi.param_make(**synth.SYN1081); r = raw1081[:60]; bad = np.zeros(r.shape, np.int32)
+        else:
+            path = os.path.join(ROOT, "tests", "golden", fname)
+            if not os.path.exists(path):
+                continue
+            p = capi.param_preset(preset)
+            r, _, _, bad, _ = capi.carmen_read(p, path, tag)
+        S, n = r.shape
+        ctx = capi.Context(p)
+        z = np.zeros(n, np.int32)
+        _, _, _, cur = ctx.fmatch_host([r[0].copy(), bad[0].astype(np.int32), z.copy()], [r[1].copy(), bad[1].astype(np.int32), z.copy()], True)
+        tf, tp = [], []
+        for k in range(2, min(S, 60)):
+            t0 = time.perf_counter()
+            _, _, _, cur = ctx.fmatch_host(cur, [r[k].copy(), bad[k].astype(np.int32), z.copy()], False)
+            tf.append(time.perf_counter() - t0)
+        capi.plicp_host(ctx, r[0], r[1])
+        its = []
+        for k in range(2, min(S, 60)):
+            t0 = time.perf_counter()
+            o = capi.plicp_host(ctx, r[k - 1], r[k])
+            tp.append(time.perf_counter() - t0); its.append(o[5])
+        ctx.close()
+        q = lambda v: {"median_us": float(np.median(v)) * 1e6, "p95_us": float(np.percentile(v, 95)) * 1e6, "max_us": float(np.max(v)) * 1e6}
+        res[name] = {"beams": n, "calls": len(tf), "CPolarMatch_FMatch": q(tf), "CCanonicalMatcher_FMatch": dict(q(tp), mean_iterations=float(np.mean(its)))}
+    return {"fmatch_latency": res}
 
 
 def secondary_grid(torch, capi, ctx, raw, p):
@@ -535,10 +641,26 @@ def secondary_grid(torch, capi, ctx, raw, p):
                                                    "EFFECTIVE: SURVEY 8d's algorithmic read-modify-write bytes N (L 8 + 16) per scan over the "
                                                    "whole batch update (prep + binning + walk); the walk accumulates in LDS tiles, so the bytes "
                                                    "that reach HBM (`traffic`, PMC) are far fewer")}
-    ms = timed(torch, lambda: grid.compute_prob(), reps=3)
+    ms = timed(torch, lambda: grid.compute_prob(), reps=5)
+    res["grid_prob_cached"] = {"value": 4096 * 4096 / (ms * 1e-3), "unit": "cells/s",
+                               "roofline": {"bound": "infinity-cache", "achieved": 12.0 * 4096 * 4096 / (ms * 1e-3) / 1e9, "peak": None, "unit": "GB/s",
+                                            "frac": None, "traffic": None, "kernel": "grid_prob_kernel", "kernel_ms": ms,
+                                            "note": "12 B per cell; back-to-back launches: the 201 MB working set stays in the 256 MiB Infinity "
+                                                    "Cache, so this is a cache figure and is not priced against HBM"}}
+    # cold: a 1 GiB buffer is written between the launches, which evicts the layers from the Infinity Cache (and L2)
+    flush = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    cold = []
+    for _ in range(4):
+        flush.fill_(1.0)
+        a.record(); grid.compute_prob(); b.record(); torch.cuda.synchronize()
+        cold.append(a.elapsed_time(b))
+    ms = float(np.median(cold[1:]))
+    del flush
     res["grid_prob"] = {"value": 4096 * 4096 / (ms * 1e-3), "unit": "cells/s",
                         "roofline": hbm_roofline("grid_prob_kernel", 12.0 * 4096 * 4096, ms, 1,
-                                                 "12 B per cell; the 201 MB working set is Infinity-Cache resident between launches")}
+                                                 "12 B per cell (two u32 count layers read, the f32 probability layer written), layers evicted "
+                                                 "from the Infinity Cache before every timed launch: the HBM figure")}
     grid.close()
     return res
 

@@ -576,6 +576,13 @@ def plicp_host(ctx, ref_r, cur_r):
     return out
 
 
+def p2p_icp_batch(ctx, B, d_ref_x, d_ref_y, d_ref_off, d_cur_x, d_cur_y, d_cur_off, n_ref_total, n_cur_total, d_init_pose, d_out16):
+    """CICPWarpper::ICPMatch for B problems: clouds concatenated (metres, device), offsets int32 [B + 1], init poses
+    float64 [B][3], d_out16 float64 [B][16]; returns after the batch has finished."""
+    check(lib().lsa_p2p_icp_batch(ctx.h, int(B), _dp(d_ref_x), _dp(d_ref_y), _dp(d_ref_off), _dp(d_cur_x), _dp(d_cur_y), _dp(d_cur_off),
+                                  int(n_ref_total), int(n_cur_total), _dp(d_init_pose), None, _dp(d_out16)), "lsa_p2p_icp_batch")
+
+
 def p2p_icp_host(ctx, ref_x, ref_y, cur_x, cur_y, init_pose):
     """CICPWarpper::ICPMatch with the reference's options; returns the 16-double result record."""
     rx, ry = np.ascontiguousarray(ref_x, np.float32), np.ascontiguousarray(ref_y, np.float32)

@@ -1564,8 +1564,19 @@ static int plicp_launch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const float
 #ifndef LSA_PLICP_LDS_PAD
 #define LSA_PLICP_LDS_PAD 0        // occupancy experiments only (tools/README.md)
 #endif
-    hipLaunchKernelGGL((lsa::plicp_kernel<WG, COV>), dim3(B), dim3(lsa::PLICP_THREADS), lsa::plicp_lds_bytes(P.n) + LSA_PLICP_LDS_PAD, c->stream, P, B, d_r,
-                       d_ref_idx, d_act_idx, c->d_trig, d_out8, sigma, d_cov9);
+    const int lds = lsa::plicp_lds_bytes(P.n) + LSA_PLICP_LDS_PAD;
+    static std::atomic<int> occ_cache[64];                // workgroups per CU by device (the instance's registers and this laser's LDS)
+    static std::atomic<int> occ_lds[64];
+    int occ = occ_cache[c->device & 63].load();
+    if (!occ || occ_lds[c->device & 63].load() != lds) {
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lsa::plicp_kernel<WG, COV>, lsa::PLICP_THREADS, lds));
+        if (occ < 1) occ = 1;
+        occ_cache[c->device & 63].store(occ); occ_lds[c->device & 63].store(lds);
+    }
+    const long long resident = (long long)occ * c->n_cu;
+    HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL((lsa::plicp_kernel<WG, COV>), dim3((unsigned)(B < resident ? B : resident)), dim3(lsa::PLICP_THREADS), lds, c->stream, P, B, d_r,
+                       d_ref_idx, d_act_idx, c->d_trig, d_out8, sigma, d_cov9, c->d_queue);
     HIP_TRY(hipGetLastError());
     return LSA_OK;
 }

@@ -27,6 +27,15 @@ struct PlicpParam {
 };
 
 constexpr int PLICP_THREADS = 256;
+// 31^-256 mod 2^32 (31 is odd, hence a unit): inverse by Newton's iteration x <- x (2 - 31 x), then eight squarings
+constexpr uint32_t plicp_inv31_256()
+{
+    uint32_t x = 31;                                       // 31 * 31 = 1 mod 8: three correct bits, doubled per step
+    for (int k = 0; k < 5; ++k) x *= 2u - 31u * x;
+    for (int k = 0; k < 8; ++k) x *= x;
+    return x;
+}
+constexpr uint32_t PLICP_INV31_256 = plicp_inv31_256();
 #ifdef LSA_PLICP_STAMPS      // diagnostic build only: cycles per phase, summed over workgroups by thread 0
 __device__ unsigned long long lsa_plicp_cycles[8];
 #define PSTAMP(slot) do { if (threadIdx.x == 0) { unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&lsa_plicp_cycles[slot], t_ - pt_); pt_ = t_; } } while (0)
@@ -118,11 +127,25 @@ __device__ void plicp_select2(const double* dist, int n, int k0, int k1, int* hi
         // the bin where the running count passes k (exactly one thread per rank)
         #pragma unroll
         for (int q = 0; q < 2; ++q)
-            if (k[q] < incl[q] && k[q] >= incl[q] - c[q]) { hist[264 * q + 260] = (int)threadIdx.x; hist[264 * q + 261] = incl[q] - c[q]; }
+            if (k[q] < incl[q] && k[q] >= incl[q] - c[q]) { hist[264 * q + 260] = (int)threadIdx.x; hist[264 * q + 261] = incl[q] - c[q]; hist[264 * q + 262] = c[q]; }
         __syncthreads();
         #pragma unroll
         for (int q = 0; q < 2; ++q) { prefix[q] |= (unsigned long long)hist[264 * q + 260] << sh; k[q] -= hist[264 * q + 261]; }
         decided |= 255ull << sh;
+        // both ranks alone in their bins: the elements are identified, their remaining digits need no more rounds (the
+        // distances of a scan share sign and exponent, so the first rounds separate nothing and the next two nearly everything)
+        if (sh > 0 && hist[262] == 1 && hist[264 + 262] == 1) {
+            #pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                if (key[u] == ~0ull) continue;
+                if ((key[u] & decided) == prefix[0]) { hist[256] = (int)(uint32_t)key[u]; hist[257] = (int)(uint32_t)(key[u] >> 32); }
+                if ((key[u] & decided) == prefix[1]) { hist[264 + 256] = (int)(uint32_t)key[u]; hist[264 + 257] = (int)(uint32_t)(key[u] >> 32); }
+            }
+            __syncthreads();
+            prefix[0] = (unsigned long long)(uint32_t)hist[256] | ((unsigned long long)(uint32_t)hist[257] << 32);
+            prefix[1] = (unsigned long long)(uint32_t)hist[264 + 256] | ((unsigned long long)(uint32_t)hist[264 + 257] << 32);
+            break;
+        }
     }
     v0 = __longlong_as_double((long long)prefix[0]);
     v1 = __longlong_as_double((long long)prefix[1]);
@@ -269,7 +292,8 @@ __device__ __forceinline__ int plicp_correspondences(const PlicpParam& P, const 
                     }
                 }
                 const float tq = sqrtf((float)bound) * 1.0001f / rho_f;
-                const int M = tq < 1.0f ? (int)((tq + 0.5708f * tq * tq * tq) / P.dfi) + 5 : n;      // asin t <= t + (pi/2 - 1) t^3
+                // asin t <= t + (pi/2 - 1) t^3; the bearing index is within 0.5 of c0f and the truncation loses less than 1: + 2 covers both
+                const int M = tq < 1.0f ? (int)((tq + 0.5708f * tq * tq * tq) / P.dfi) + 2 : n;
                 fast = M + 8 <= range_min;
                 lo0 = c0f - M > 0 ? c0f - M : 0; hi0 = c0f + M < n - 1 ? c0f + M : n - 1;
                 // (Scanning in rings outwards from the bearing with a half width that shrinks as closer points
@@ -467,12 +491,13 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
         const double del0 = cs * dxw + sn * dyw, del1 = -sn * dxw + cs * dyw;
         // loop detection on the correspondence set (one lane, the recurrence of the oracle)
         // hash = sum v_i 31^(n-1-i) mod 2^32 (the oracle's recurrence hash = hash * 31 + v_i, summed in parallel)
-        uint32_t hpart = 0;
+        // (one power per thread: 31^(n-1-tid); the thread's next point is 256 places further, 31^-256 mod 2^32 = 0x3e5a9801... computed below)
+        uint32_t hpart = 0, pw = 1;
+        if (tid < n) { uint32_t bs = 31; for (int e = n - 1 - tid; e; e >>= 1) { if (e & 1) pw *= bs; bs *= bs; } }
         for (int i = tid; i < n; i += PLICP_THREADS) {
             const uint32_t v = (uint32_t)(L.corr[i] >= 0 ? (L.corr[i] & 0xffff) + 1000 * (L.corr[i] >> 16) : -1);
-            uint32_t pw = 1, bs = 31;
-            for (int e = n - 1 - i; e; e >>= 1) { if (e & 1) pw *= bs; bs *= bs; }
             hpart += v * pw;
+            pw *= PLICP_INV31_256;
         }
         for (int o = 32; o; o >>= 1) hpart += __shfl_xor(hpart, o);
         __syncthreads();
@@ -608,7 +633,7 @@ template <int WG, bool COV>
 __global__ __launch_bounds__(PLICP_THREADS, WG) void plicp_kernel(PlicpParam P, int B, const float* __restrict__ g_r,
                                                               const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
                                                               const double* __restrict__ trig, double* __restrict__ out8,
-                                                              double sigma, double* __restrict__ cov9)
+                                                              double sigma, double* __restrict__ cov9, unsigned int* __restrict__ queue)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = P.n, Np = (n + 63) & ~63, tid = threadIdx.x;
@@ -622,8 +647,16 @@ __global__ __launch_bounds__(PLICP_THREADS, WG) void plicp_kernel(PlicpParam P, 
     L.red = (double*)(smem + (size_t)Np * (4 * 8 + 4 + 4 + 4));
     L.hist = (int*)(smem + (size_t)Np * (4 * 8 + 4 + 4 + 4) + 1024);
     const double min_reading = P.min_range_cm / 100., max_reading = P.max_range_cm / 100.;
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    // as many workgroups as the chip holds, pairs claimed from the batch's counter (what the compiler parks in scratch at
+    // kernel entry is written once per workgroup, not once per pair; a pair that restarts six times does not hold a
+    // queue of others behind it); every workgroup leaves at its first claim past the batch
+    int* const claim = (int*)L.red + 21;                // (beside the loop flag: the dynamic block is the only LDS of this kernel)
+    for (;;) {
         __syncthreads();
+        if (tid == 0) *claim = (int)atomicAdd(queue, 1u);
+        __syncthreads();
+        const int b = *claim;
+        if (b >= B) break;
         for (int i = tid; i < n; i += PLICP_THREADS) {                   // fromPMScan2LDP (:191-227) + ld_compute_cartesian
             const double cth = trig[i], sth = trig[n + i];             // cos | sin of float(fi_min + dfi i), from the host's libm
             for (int w = 0; w < 2; ++w) {
