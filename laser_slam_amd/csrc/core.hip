@@ -84,7 +84,7 @@ static lsa::DevParam dev_param(const lsa_ctx* c)
 #ifndef LSA_ICP_LDS_PAD
 #define LSA_ICP_LDS_PAD 0          // occupancy experiments only (tools/README.md)
 #endif
-static int icp_lds(int n, bool ref_global) { return lsa::icp_lds_bytes(n, ref_global) + LSA_ICP_LDS_PAD; }
+static int icp_lds(int n, bool ref_global, int threads) { return lsa::icp_lds_bytes(n, ref_global, threads) + LSA_ICP_LDS_PAD; }
 static int psm_lds(int n) { return lsa::psm_lds_bytes(n); }
 static int pre_lds(int n) { int Np = (n + 63) & ~63; return 12 * Np; }
 
@@ -505,7 +505,8 @@ int lsa_match_batch(lsa_ctx* c, int which, int B,
     if (which == LSA_MATCH_ICP) {
 #define LSA_LAUNCH_ICP(NC) do { \
         const bool refg = lsa::icp_ref_global(NC); \
-        if (!c->occ_icp) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_icp, lsa::icp_kernel<NC>, lsa::ICP_THREADS, icp_lds(P.n, refg))); \
+        constexpr int TH = lsa::icp_threads(NC); \
+        if (!c->occ_icp) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_icp, lsa::icp_kernel<NC>, TH, icp_lds(P.n, refg, TH))); \
         const long long resident = (long long)(c->occ_icp > 0 ? c->occ_icp : 1) * c->n_cu; \
         const unsigned grid = (unsigned)(B < resident ? B : resident); \
         const size_t need = lsa::icp_ref_slot_bytes(P.n, refg) * grid; \
@@ -516,7 +517,7 @@ int lsa_match_batch(lsa_ctx* c, int which, int B,
             HIP_TRY(hipMalloc((void**)&c->d_icp_ref, lsa::icp_ref_slot_bytes(P.n, refg) * (size_t)resident)); \
             c->icp_ref_cap = lsa::icp_ref_slot_bytes(P.n, refg) * (size_t)resident; \
         } \
-        hipLaunchKernelGGL(lsa::icp_kernel<NC>, dim3(grid), dim3(lsa::ICP_THREADS), icp_lds(P.n, refg), c->stream, P, B, d_r, \
+        hipLaunchKernelGGL(lsa::icp_kernel<NC>, dim3(grid), dim3(TH), icp_lds(P.n, refg, TH), c->stream, P, B, d_r, \
                            d_bad, d_seg, d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters, c->d_queue, \
                            (float2*)c->d_icp_ref); } while (0)
         switch (P.n) {          // the reference's presets (PolarParameter.h:75-83) and the 1081-beam benchmark sensor

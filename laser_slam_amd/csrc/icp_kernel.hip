@@ -23,7 +23,14 @@
 // Last iteration's match per beam (the NN seed) lives in registers: a thread always handles the
 // same beams.
 
-constexpr int ICP_THREADS = 256;
+constexpr int ICP_THREADS = 256;     // the largest workgroup (1081 beams, the size-generic instance)
+// Threads per pair by sensor size: the order-free phases cover a scan 64 x waves beams at a time, the order-bound ones run
+// on one wave while the pair's other waves wait - so a workgroup should not be wider than the scan needs.  181 beams (LMS211)
+// get ONE wave (three trips, no workgroup barrier at all: 3.66 -> 5.93 M matches/s on intel-lab's head), 361 (LMS511) two
+// waves (2.02 -> 2.43 M on fr079's), everything larger four (541 beams on two waves measured 2 % slower than on four).
+// Constraints: the dropped fifth of the matches must fit one thread each ((int)(0.2 n) <= T) and a thread keeps the last
+// matches of at most six beams in registers (n <= 6 T).
+__host__ __device__ constexpr int icp_threads(int nc) { return nc == 181 ? 64 : nc == 361 ? 128 : 256; }
 
 // ---- diagnostics (the only conditional code in this file) ------------------------------------------------
 // -DLSA_PHASE_STAMPS: thread 0 of every workgroup adds the cycles it spent per phase to lsa_phase_cycles[]
@@ -52,22 +59,22 @@ __device__ unsigned int lsa_bad_index[4];
 // ------------------------------------------------------------------------------------------------------------
 constexpr float NN_CAP = 10001.0f;     // matches with d^2 >= 100^2 are rejected anyway (:1811)
 
-constexpr int TRIM_CHUNK = 256;        // records consumed per step of the partial bubble sort
+// (records consumed per step of the partial bubble sort = threads of the workgroup, T)
 
 // floats per ordered list in the D region (ix | iy): the kept pairs, a multiple of 4 (ordered_sum reads 128 bits at a
 // time and runs a few quads ahead: whatever lies behind a list inside the workgroup's LDS may be read, never used)
 __host__ __device__ inline int icp_list_floats(int n) { return (n - (int)((double)n * 0.2) + 2 + 3) & ~3; }
 // A thread takes the match records and owners of its (at most 4) pairs to registers before the lists replace the
 // match list and the owner array.  Longer lists (more than 1278 beams) get arrays of their own instead.
-__host__ __device__ inline bool icp_lists_separate(int n) { return n - (int)((double)n * 0.2) + 2 > 4 * ICP_THREADS; }
+__host__ __device__ inline bool icp_lists_separate(int n, int T) { return n - (int)((double)n * 0.2) + 2 > 4 * T; }
 // D region: max of { pr,pf of the projection | ix,iy lists + the first `drop` pairs' beams | trim pools + scratch }
-__host__ __device__ inline int icp_d_bytes(int n)
+__host__ __device__ inline int icp_d_bytes(int n, int T)
 {
     int Np = (n + 63) & ~63;
     int kmax = (int)((double)n * 0.2) + 1;
     int vb = 8 * icp_list_floats(n) + 4 * kmax;
     if (vb < 8 * Np) vb = 8 * Np;
-    int tb = 2 * kmax * 8 + TRIM_CHUNK * (8 + 3 * 4);   // two pools, eviction slots, three float rows
+    int tb = 2 * kmax * 8 + T * (8 + 3 * 4);            // two pools, eviction slots, three float rows
     if (vb < tb) vb = tb;
     return (vb + 63) & ~63;
 }
@@ -81,16 +88,16 @@ __host__ __device__ inline int icp_mask_bytes(int n)
 // the nearest-neighbour search and the interpolation: at 1081 beams that costs 3.4 % at equal occupancy and buys seven
 // workgroups per CU instead of six (+6.6 %; 3 / 4 / 5 / 6 per CU run at 0.61 / 0.77 / 0.90 / 1.00 of six).  The
 // size-generic instance (NC = 0) always uses the slot, so that the address space is fixed at compile time.
-__host__ __device__ inline int icp_lds_bytes(int n, bool ref_global)
+__host__ __device__ inline int icp_lds_bytes(int n, bool ref_global, int T)
 {
     int Np = (n + 63) & ~63;
-    return (ref_global ? 12 : 20) * Np + icp_d_bytes(n) + (icp_lists_separate(n) ? 12 * Np : 0) + 256 + 2 * icp_mask_bytes(n);
+    return (ref_global ? 12 : 20) * Np + icp_d_bytes(n, T) + (icp_lists_separate(n, T) ? 12 * Np : 0) + 256 + 2 * icp_mask_bytes(n);
 }
 __host__ __device__ constexpr bool icp_ref_global(int nc) { return nc == 0 || nc > 541; }
 // bytes of one workgroup's slot in the global scratch
 __host__ __device__ inline size_t icp_ref_slot_bytes(int n, bool ref_global) { return ref_global ? (size_t)8 * ((n + 63) & ~63) : 0; }
 
-__device__ __forceinline__ Lds carve_icp(char* base, int n, bool ref_global, float2* g_ref_slot)
+__device__ __forceinline__ Lds carve_icp(char* base, int n, bool ref_global, float2* g_ref_slot, int T)
 {
     const int Np = (n + 63) & ~63;
     Lds L = {};
@@ -110,14 +117,14 @@ __device__ __forceinline__ Lds carve_icp(char* base, int n, bool ref_global, flo
     const int kmax = (int)((double)n * 0.2) + 1;
     L.poolA = (unsigned long long*)d;               // trim pools + scratch alias the D region
     L.poolB = L.poolA + kmax;
-    L.evict = L.poolB + kmax;                       // TRIM_CHUNK records, then 3 x TRIM_CHUNK floats
-    L.pool_d = (float*)(L.evict + TRIM_CHUNK);
+    L.evict = L.poolB + kmax;                       // T records, then 3 x T floats
+    L.pool_d = (float*)(L.evict + T);
     L.vd = (float*)d;                               // ix | iy
     L.first_ij = (uint32_t*)(d + 8 * icp_list_floats(n));
-    char* f = d + icp_d_bytes(n);
+    char* f = d + icp_d_bytes(n, T);
     L.owner = (uint32_t*)d;
     L.vk = (float*)L.key;                           // nx | ny (Np floats each)
-    if (icp_lists_separate(n)) { L.owner = (uint32_t*)f; L.vk = (float*)(f + 4 * Np); f += 12 * Np; }
+    if (icp_lists_separate(n, T)) { L.owner = (uint32_t*)f; L.vk = (float*)(f + 4 * Np); f += 12 * Np; }
     L.misc = (float*)f;
     L.good = (uint32_t*)(f + 256);
     L.pair_mask = (uint32_t*)(f + 256 + icp_mask_bytes(n));
@@ -399,14 +406,21 @@ __device__ __forceinline__ int nn_store(const Lds& L, int N, int i, const NnBeam
 // index of this thread's flag among the set flags of the workgroup (thread order), and the total.
 // One barrier per call: consecutive calls alternate between two sets of per-wave slots, and a
 // slot set is rewritten only two calls (hence at least one barrier) after it was last read.
+template <int T>
 __device__ __forceinline__ int block_rank(bool flag, int& total, int* wcnt, int& phase)
 {
     const unsigned long long mask = __ballot(flag);
+    if (T == 64) { total = __popcll(mask); return prefix_popc(mask); }      // one wave: the ballot is the whole answer
     const int wave = threadIdx.x >> 6;
     int* slot = wcnt + 4 * (phase & 1);
     phase++;
     if (lane_id() == 0) slot[wave] = __popcll(mask);
     __syncthreads();
+    if (T == 128) {
+        const int c0 = slot[0], c1 = slot[1];
+        total = c0 + c1;
+        return (wave > 0 ? c0 : 0) + prefix_popc(mask);
+    }
     const int c0 = slot[0], c1 = slot[1], c2 = slot[2], c3 = slot[3];
     total = c0 + c1 + c2 + c3;
     const int off = (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
@@ -472,6 +486,7 @@ __device__ __forceinline__ int count_ge_from(const float* row, int cnt, float d,
     return c;
 }
 
+template <int T>
 __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt STAMP_ARGS)
 {
     // (opaque copy of the thread index: what is derived from it - LDS addresses of a dozen arrays - is formed again every
@@ -482,10 +497,10 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt STAMP_ARGS)
     unsigned long long* Pc = L.poolA;
     unsigned long long* Pn = L.poolB;
     float* cd = L.pool_d;                            // candidates' distances (arrival order)
-    float* ce = L.pool_d + TRIM_CHUNK;               // entering records' distances (arrival order)
-    float* se = L.pool_d + 2 * TRIM_CHUNK;           // entering records' distances, descending
+    float* ce = L.pool_d + T;                        // entering records' distances (arrival order)
+    float* se = L.pool_d + 2 * T;                    // entering records' distances, descending
     int phase = 0;
-    // the first k records (k <= TRIM_CHUNK, host-checked): rank sort, descending by (distance, later
+    // the first k records (k <= T: icp_threads): rank sort, descending by (distance, later
     // arrival first among equals).  Each wave ranks its own 64 records by counting, publishes them
     // as a sorted run, and ranks against the other waves' runs by binary search.
     {
@@ -521,7 +536,7 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt STAMP_ARGS)
         __syncthreads();
         SUBSTAMP(13, 0.0f);
     }
-    for (int t0 = k; t0 < n; t0 += TRIM_CHUNK) {
+    for (int t0 = k; t0 < n; t0 += T) {
         const int t = t0 + tid;
         const bool valid = t < n;
         const unsigned long long rec = valid ? A[t] : 0ull;
@@ -529,7 +544,7 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt STAMP_ARGS)
         const float theta = rec_d(Pc[k - 1]);
         const bool cand = valid && d >= theta;
         int q;
-        const int cpos = block_rank(cand, q, wcnt, phase);
+        const int cpos = block_rank<T>(cand, q, wcnt, phase);
         SUBSTAMP(14, (float)cpos);
         if (q == 0) { if (valid) A[t - k] = rec; continue; }
         if (cand) cd[cpos] = d;
@@ -549,7 +564,7 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt STAMP_ARGS)
         int g2 = cand ? count_split(cd, cpos, d, cpos) : 0;
         const bool ent = cand && (g1 + g2 < k);
         int E;
-        const int epos = block_rank(ent, E, wcnt, phase);
+        const int epos = block_rank<T>(ent, E, wcnt, phase);
         SUBSTAMP(8, (float)epos);
         if (valid && !ent) A[t - k] = rec;           // passes straight through
         if (E == 0) continue;
@@ -623,9 +638,10 @@ __device__ __noinline__ void icp_error_tail(DevParam P, const float* g_ref_row, 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (NC > 0) P.n = NC;
     const int N = P.n;
-    Lds L = carve_icp(smem, N, icp_ref_global(NC), nullptr);
+    constexpr int T = icp_threads(NC);
+    Lds L = carve_icp(smem, N, icp_ref_global(NC), nullptr, T);
     L.g_act_r = g_act_row; L.g_ref_r = g_ref_row;
-    if (L.ref_r) for (int i = threadIdx.x; i < N; i += ICP_THREADS) L.ref_r[i] = g_ref_row[i];      // ref_xy is no longer needed
+    if (L.ref_r) for (int i = threadIdx.x; i < N; i += T) L.ref_r[i] = g_ref_row[i];      // ref_xy is no longer needed
     __syncthreads();
     scan_project(P, L, ex, ey, eth);
     error_index2_tail(P, L, exy, n_assoc);
@@ -641,10 +657,16 @@ __device__ __noinline__ void icp_error_tail(DevParam P, const float* g_ref_row, 
 #ifndef LSA_ICP_WG_PER_CU_SMALL
 #define LSA_ICP_WG_PER_CU_SMALL 8
 #endif
+// (__launch_bounds__' second argument is waves per SIMD in HIP.)  The narrow instances: the LDS admits 26 x 6.1 KB workgroups of
+// one wave at 181 beams and 13 x 11.8 KB of two at 361 - 6.5 waves per SIMD either way, i.e. a budget of 7 (72 registers)
+__host__ __device__ constexpr int icp_wg_per_cu(int nc)
+{
+    return nc == 181 || nc == 361 ? 7 : (nc > 0 && nc <= 541) ? (LSA_ICP_WG_PER_CU_SMALL) : (LSA_ICP_WG_PER_CU);
+}
 // NC > 0: the beam count as a compile-time constant (the sensors' usual sizes), so that the LDS
 // layout and the trip counts are immediates instead of scalar registers; NC = 0: any size.
 template <int NC>
-__global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PER_CU_SMALL) : (LSA_ICP_WG_PER_CU)) void icp_kernel(
+__global__ __launch_bounds__(icp_threads(NC), icp_wg_per_cu(NC)) void icp_kernel(
     DevParam P_, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
     const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
     const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
@@ -655,7 +677,8 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
     DevParam P = P_;
     if (NC > 0) P.n = NC;
     const int N = P.n, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    Lds L = carve_icp(smem, N, icp_ref_global(NC), icp_ref_global(NC) ? ref_scratch + (size_t)blockIdx.x * ((N + 63) & ~63) : nullptr);
+    constexpr int NT = icp_threads(NC);              // threads of this instance's workgroup
+    Lds L = carve_icp(smem, N, icp_ref_global(NC), icp_ref_global(NC) ? ref_scratch + (size_t)blockIdx.x * ((N + 63) & ~63) : nullptr, NT);
     int* imisc = (int*)L.misc;              // [0] n
     float* fmisc = L.misc + 8;      // [0..3] means  [4..7] covariances
     // ordered value lists (SoA): nx | ny in the K region, ix | iy in the D region, later the four product lists
@@ -675,7 +698,7 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
         const size_t ro = (size_t)ref_idx[b] * N, ao = (size_t)act_idx[b] * N;
         L.g_act_r = g_r + ao;
         L.g_ref_r = g_r + ro;
-        for (int i = tid; i < N; i += ICP_THREADS) {
+        for (int i = tid; i < N; i += NT) {
             float rr = g_r[ro + i];
             const uint8_t rb = g_bad[ro + i];
             L.act_r[i] = g_r[ao + i];
@@ -735,7 +758,7 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
                 const float inv_dfi = 1.0f / P.dfi;
                 const float T = 6.2831853f * inv_dfi;                 // one turn in rays
                 const float co = fmisc[PS_CO], si = fmisc[PS_SI], ax = fmisc[PS_AX], ay = fmisc[PS_AY];
-                for (int base = wave * WAVE, trip = 0; base < N; base += ICP_THREADS, ++trip) {
+                for (int base = wave * WAVE, trip = 0; base < N; base += NT, ++trip) {
                     const int i0 = base + lane;
                     const bool lv0 = i0 < N && key_bad(L.key[i0 < N ? i0 : 0]) == 0;
                     const float2 p0 = cur_point(P, L.act_r, i0 < N ? i0 : N - 1, co, si, ax, ay);
@@ -778,26 +801,26 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
 #ifdef LSA_PHASE_STAMPS
             t_sub = __builtin_readcyclecounter();
 #endif
-            trim_worst(L, n, drop, imisc + 40 STAMP_PASS);                               // :1839-1857
+            trim_worst<NT>(L, n, drop, imisc + 40 STAMP_PASS);                               // :1839-1857
             __syncthreads();
             STAMP(3);
 
             // ---- interpolation of the reference side, :1867-1926 ---------------------
             // ix/iy are indexed by the reference beam and later pairs overwrite earlier
             // ones: the pair with the largest list position owns the beam.
-            for (int i = tid; i < N; i += ICP_THREADS) L.owner[i] = 0;                   // (aliases the D region)
+            for (int i = tid; i < N; i += NT) L.owner[i] = 0;                   // (aliases the D region)
             __syncthreads();
-            for (int k = tid; k < keep; k += ICP_THREADS)
+            for (int k = tid; k < keep; k += NT)
                 atomicMax(&L.owner[(uint32_t)(L.key[k] >> 32) >> 16], (uint32_t)(k + 1));
             __syncthreads();
-            for (int k0 = 0; k0 < keep; k0 += 4 * ICP_THREADS) {
+            for (int k0 = 0; k0 < keep; k0 += 4 * NT) {
                 // this thread's pairs (beams i -> j) and the beams of the pairs that own their reference beams go to
                 // registers before the value lists replace the match list and the owner array
                 uint32_t ijs[4];
                 int ios[4];
                 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int k = k0 + u * ICP_THREADS + tid;
+                    const int k = k0 + u * NT + tid;
                     ijs[u] = 0; ios[u] = 0;
                     if (k < keep) {
                         ijs[u] = (uint32_t)(L.key[k] >> 32);
@@ -809,7 +832,7 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
                 const float co = fmisc[PS_CO], si = fmisc[PS_SI], ax = fmisc[PS_AX], ay = fmisc[PS_AY];
                 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int k = k0 + u * ICP_THREADS + tid;
+                    const int k = k0 + u * NT + tid;
                     if (k < keep) {
                         const int i = ijs[u] & 0xffff, j = ijs[u] >> 16, io = ios[u];
                         const float2 p = cur_point(P, L.act_r, i, co, si, ax, ay);
@@ -828,7 +851,7 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
             __syncthreads();
             STAMP(5);
             const float mpx = fmisc[0], mpy = fmisc[1], mqx = fmisc[2], mqy = fmisc[3];
-            for (int k = tid; k < keep; k += ICP_THREADS) {
+            for (int k = tid; k < keep; k += NT) {
                 const float a = Lnx[k] - mpx, c = Lny[k] - mpy, e = Lix[k] - mqx, f = Liy[k] - mqy;
                 Lnx[k] = a * e; Lny[k] = a * f; Lix[k] = c * e; Liy[k] = c * f;   // sxx sxy syx syy
             }
@@ -863,7 +886,7 @@ __global__ __launch_bounds__(ICP_THREADS, (NC > 0 && NC <= 541) ? (LSA_ICP_WG_PE
         // kept pairs of the last iteration, each against its own candidate point.
         if (status == LSA_ST_OK) {
             float* resid = Lnx;                 // (the lists are dead by now)
-            for (int k = tid; k < drop; k += ICP_THREADS) {
+            for (int k = tid; k < drop; k += NT) {
                 const uint32_t ij = L.first_ij[k];
                 const float2 p = cur_point(P, L.act_r, ij & 0xffff, fmisc[PS_PCO], fmisc[PS_PSI], fmisc[PS_PAX], fmisc[PS_PAY]);
                 const float2 c = interp_candidate(P, L, N, p, ij >> 16);

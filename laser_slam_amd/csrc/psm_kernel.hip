@@ -108,10 +108,16 @@ __device__ __forceinline__ void orient_quad(float& e, const packed4f a, const LS
 __device__ __forceinline__ int orient_count(const uint32_t* newm, const uint32_t* refm, int nw, int k)
 {
     int c = 0;
+    // (four words at a time: unrolled completely - a constant dozen or so words in the 361- and 541-beam instances - all the
+    //  loads are issued ahead of the first use and the words that do not fit the 64 registers go through scratch memory)
+    #pragma unroll 4
     for (int w = 0; w < nw; ++w) {
         const int j = 32 * w + k;
         c += __popc(newm[w] & __builtin_amdgcn_alignbit(refm[(j >> 5) + 1], refm[j >> 5], (uint32_t)j & 31u));
     }
+    // (the count is finished here: left to the scheduler, the popcounts sink to the count's first use behind the sum of the
+    //  shift, and the mask words wait for them in registers the sum needs)
+    asm volatile("" : "+v"(c));
     return c;
 }
 
@@ -363,8 +369,10 @@ __device__ __forceinline__ void load_pair_psm(const DevParam& P, Lds& L, const f
 #define LSA_PSM_PAIRED false
 #endif
 // NC > 0: the beam count as a compile-time constant (see icp_kernel)
+// eight waves per SIMD (64 registers; 17.9 KiB of LDS at 1081 beams).  What does not fit is parked in scratch memory in the
+// prologue, once per persistent workgroup: tests/test_isa_invariants.py holds every instance to "no scratch store behind the
+// first loop header" (round 2's 361-beam instance wrote 27-41 KB of scratch per pair from inside the iteration loop).
 template <int NC>
-// eight workgroups per CU (64 registers; 17.9 KiB of LDS at 1081 beams)
 __global__ __launch_bounds__(PSM_THREADS, LSA_PSM_WG_PER_CU) void psm_kernel(
     DevParam P_, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
     const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
@@ -412,14 +420,19 @@ __global__ __launch_bounds__(PSM_THREADS, LSA_PSM_WG_PER_CU) void psm_kernel(
                 float dth = 0.0f;
                 status = orientation_search(P, L, dth, bc);
                 if (status) break;
-                if (tid == 0) { bc[PS_ATH] += dth; bc[PS_DTH] = dth; }
+                // (the pose slots are read again here, through a volatile pointer: otherwise the values scan_project took at the
+                //  top of the iteration stay live - in scratch memory, at 64 registers - until this update)
+                if (tid == 0) { volatile LSA_LDS float* vb = (volatile LSA_LDS float*)bc; vb[PS_ATH] = vb[PS_ATH] + dth; vb[PS_DTH] = dth; }
                 __syncthreads();
                 continue;
             }
             float dx = 0.0f, dy = 0.0f, avg = 0.0f;
             status = translation_estimation(P, L, C, dx, dy, avg, bc);
             if (status) break;
-            if (tid == 0) { bc[PS_AX] += dx; bc[PS_AY] += dy; bc[PS_DX] = dx; bc[PS_DY] = dy; bc[PS_AVG] = avg; }
+            if (tid == 0) {
+                volatile LSA_LDS float* vb = (volatile LSA_LDS float*)bc;
+                vb[PS_AX] = vb[PS_AX] + dx; vb[PS_AY] = vb[PS_AY] + dy; vb[PS_DX] = dx; vb[PS_DY] = dy; vb[PS_AVG] = avg;
+            }
             __syncthreads();
         }
 

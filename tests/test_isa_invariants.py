@@ -28,3 +28,25 @@ def test_parked_scalars_are_handled_soundly(device_asm, prefix):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sgpr_spill_check.py"), device_asm, prefix], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "lane carriers" in res.stdout
+
+
+def _kernel_bodies(asm, prefix):
+    lines = open(asm).read().split("\n")
+    for i, l in enumerate(lines):
+        if l.startswith(prefix) and ":" in l.split(";")[0]:
+            e = next(j for j in range(i, len(lines)) if lines[j].startswith(".Lfunc_end"))
+            yield l.split(":")[0], lines[i:e]
+
+
+@pytest.mark.parametrize("prefix", ["_ZN3lsa10psm_kernelILi"])
+def test_no_scratch_store_inside_the_loops(device_asm, prefix):
+    """What a matcher instance parks in scratch memory it parks in its prologue - once per persistent workgroup - and never
+    from inside the pair or iteration loops (round 2: psm_kernel<361> spilled pose slots and mask words per iteration,
+    27-41 KB of scratch writes per pair)."""
+    n = 0
+    for name, body in _kernel_bodies(device_asm, prefix):
+        first_loop = next((i for i, l in enumerate(body) if "Loop Header: Depth=1" in l), len(body))
+        late = [i for i, l in enumerate(body) if "scratch_store" in l and i > first_loop]
+        assert not late, (name, late[:8])
+        n += 1
+    assert n >= 5
