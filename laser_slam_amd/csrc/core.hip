@@ -532,9 +532,10 @@ int lsa_match_batch(lsa_ctx* c, int which, int B,
     {
 #define LSA_LAUNCH_PSM(NC) do { \
         const int lds = lsa::psm_compact_lds_bytes(P.n, P.window); \
-        if (!c->occ_psm) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_psm, lsa::psm_kernel<NC>, lsa::PSM_THREADS, lds)); \
+        constexpr int TH = lsa::psm_threads(NC); \
+        if (!c->occ_psm) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_psm, lsa::psm_kernel<NC>, TH, lds)); \
         const long long resident = (long long)(c->occ_psm > 0 ? c->occ_psm : 1) * c->n_cu; \
-        hipLaunchKernelGGL(lsa::psm_kernel<NC>, dim3((unsigned)(B < resident ? B : resident)), dim3(lsa::PSM_THREADS), lds, c->stream, P, B, \
+        hipLaunchKernelGGL(lsa::psm_kernel<NC>, dim3((unsigned)(B < resident ? B : resident)), dim3(TH), lds, c->stream, P, B, \
                            d_r, d_bad, d_seg, d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters, c->d_queue); } while (0)
         switch (P.n) {
         case 181:  LSA_LAUNCH_PSM(181); break;

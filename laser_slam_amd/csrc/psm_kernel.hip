@@ -20,6 +20,11 @@
 //   scan once per projection, the reference scan once per search / translation step).
 
 constexpr int PSM_THREADS = 256;
+// Threads per pair by sensor size (every phase steps through a scan blockDim.x beams at a time, the search hands one block
+// of 64 shifts to a wave): one wave per pair up to 361 beams, two at 541, four beyond - measured on the logs' heads and the
+// synthetic set: 181 beams 21.7 -> 33.9 M matches/s, 361 beams 7.7 -> 10.2 M (fr079) / 11.1 -> 14.8 M (mit), 541 beams
+// 16.9 -> 21.2 M (two waves; one wave 18.5 M), 1081 beams 4.0 M on four waves against 3.4 M on two.
+__host__ __device__ constexpr int psm_threads(int nc) { return nc == 181 || nc == 361 ? 64 : nc == 541 ? 128 : PSM_THREADS; }
 
 // validity bit masks of the orientation search: new scan (Np/32 + 1 words), padded reference row
 // (2 Np / 32 + 4 words; the window satisfies 2W + 1 <= Np)
@@ -373,7 +378,7 @@ __device__ __forceinline__ void load_pair_psm(const DevParam& P, Lds& L, const f
 // prologue, once per persistent workgroup: tests/test_isa_invariants.py holds every instance to "no scratch store behind the
 // first loop header" (round 2's 361-beam instance wrote 27-41 KB of scratch per pair from inside the iteration loop).
 template <int NC>
-__global__ __launch_bounds__(PSM_THREADS, LSA_PSM_WG_PER_CU) void psm_kernel(
+__global__ __launch_bounds__(psm_threads(NC), LSA_PSM_WG_PER_CU) void psm_kernel(
     DevParam P_, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
     const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
     const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
@@ -413,8 +418,12 @@ __global__ __launch_bounds__(PSM_THREADS, LSA_PSM_WG_PER_CU) void psm_kernel(
 
         int iter = -1;
         while (++iter < LSA_ITER_PSM && small < 3) {
-            if ((double)(fabsf_(bc[PS_DX]) + fabsf_(bc[PS_DY]) + fabsf_(bc[PS_DTH])) < LSA_STOP_PSM) small++; else small = 0;   // :933
-            scan_project<LSA_PSM_PAIRED>(P, L, bc[PS_AX], bc[PS_AY], bc[PS_ATH]);
+            // (pose slots through a volatile pointer, here and at the updates below: what an iteration reads of them is used at
+            //  once and dies - otherwise, in the one-wave instances without a barrier in between, the values stay live across
+            //  the search and the estimation, in scratch memory at 64 registers)
+            volatile LSA_LDS float* vbc = (volatile LSA_LDS float*)bc;
+            if ((double)(fabsf_(vbc[PS_DX]) + fabsf_(vbc[PS_DY]) + fabsf_(vbc[PS_DTH])) < LSA_STOP_PSM) small++; else small = 0;   // :933
+            scan_project<LSA_PSM_PAIRED>(P, L, vbc[PS_AX], vbc[PS_AY], vbc[PS_ATH]);
             unpack_projection(P, L);
             if ((iter & 1) == 0) {
                 float dth = 0.0f;
