@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 BYTES_PER_PAIR = 2 * 1081 * 4 + 12 + 20      # 8 680 B per 1081-beam pair
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec
+L2_PEAK_GBS = 34500.0                        # MI355X_MICROARCH.md: 4 MiB per XCD, ~34.5 TB/s aggregate
 # wave64 vector instructions/s: 256 CUs x 4 SIMD-32 units, a single-precision instruction every 2 cycles when at least two
 # waves of a SIMD are ready (MI355X_MICROARCH.md: `v_fma_f32` 2 cyc, one wave alone 4; transcendentals 8), at 2.4 GHz
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0
@@ -360,7 +361,7 @@ def main():
     value = total_pairs / elapsed
 
     out = None
-    kern = "%s_kernel" % args.matcher
+    kern = "%s_kernel<1081>" % args.matcher
     if rank == 0:
         W = p.window
         flops_pair = mean_iters * (n * 2 * W * 6 + 60 * n) if which == capi.MATCH_ICP else \
@@ -465,7 +466,7 @@ def secondary_matchers(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, which
     pose = torch.zeros(B, 3, device="cuda")
     ms = timed(torch, lambda: ctx.match_batch(other, B, d_r, d_bad, d_seg, d_ri, d_ai, pose), reps=3)
     res["pm_%s" % oname] = {"value": B / (ms * 1e-3), "unit": "scan-matches/s", "pairs": B,
-                            "roofline": valu_roofline("%s_kernel" % oname, B / (ms * 1e-3), ms, B, BYTES_PER_PAIR)}
+                            "roofline": valu_roofline("%s_kernel<1081>" % oname, B / (ms * 1e-3), ms, B, BYTES_PER_PAIR)}
     # point-to-line ICP (CCanonicalMatcher / zhcsm's matcher), raw scans, 2^17 pairs: a pair that restarts from six
     # perturbed poses runs seven loops, and a small batch waits for its slowest pair (8192 pairs took 17.9 ms in round 2,
     # 9 of them the tail of one such pair)
@@ -475,7 +476,7 @@ def secondary_matchers(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, which
     ri, ai = d_ri[:Bp].contiguous(), d_ai[:Bp].contiguous()
     ms = timed(torch, lambda: capi.plicp_batch(ctx, Bp, d_raw, ri, ai, d_o8), reps=3)
     res["plicp"] = {"value": Bp / (ms * 1e-3), "unit": "scan-matches/s", "pairs": Bp, "mean_iterations": float(d_o8[:, 5].mean().item()),
-                    "roofline": valu_roofline("plicp_kernel", Bp / (ms * 1e-3), ms, Bp, BYTES_PER_PAIR,
+                    "roofline": valu_roofline("plicp_kernel<3, false>", Bp / (ms * 1e-3), ms, Bp, BYTES_PER_PAIR,
                                               {"note": "double-precision point-to-line ICP (parity unpinned: CSM absent); "
                                                        "instruction-issue and latency bound, DESIGN.md 4.7"})}
     S = raw.shape[0]
@@ -715,12 +716,21 @@ def secondary_pf(torch, capi, ctx, dist, rank, world, raw, p, coll_dev):
         d_p = pf_cloud(torch, P, 1); d_sc = torch.zeros(P, device="cuda")
         torch.cuda.synchronize()
         ms = timed(torch, lambda: fld.score_poses(d_sx, d_sy, n, 3, d_p, P, d_sc), reps=5)
+        sp = load_profile("pmc_score_poses") or {}
+        rq = sp.get("l2_requests_per_lane_beam")
+        l2_gbs = rq * P * nbm * 128.0 / (ms * 1e-3) / 1e9 if rq else None
         res["score_poses"] = {"value": P / (ms * 1e-3), "unit": "poses/s", "poses": P, "beams_per_pose": nbm,
-                              "roofline": {"bound": "cache-gather", "achieved": P * nbm * 4 / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                           "frac": P * nbm * 4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "pf_score_kernel",
-                                           "kernel_ms": ms,
-                                           "note": "gathered bytes (P x beams x 4) of the 64 MiB likelihood field, served by L2 / Infinity "
-                                                   "Cache; peak = the HBM figure for scale, the gather itself is not an HBM stream"}}
+                              "roofline": {"bound": "l2", "achieved": l2_gbs, "peak": L2_PEAK_GBS, "unit": "GB/s",
+                                           "frac": l2_gbs / L2_PEAK_GBS if l2_gbs else None, "traffic": None, "kernel": "pf_score_kernel<false, 16>",
+                                           "kernel_ms": ms, "l2_requests_per_lane_beam": rq, "tcp_hit_rate": sp.get("tcp_hit_rate"),
+                                           "tcc_hit_rate": sp.get("tcc_hit_rate"), "valu_busy_frac": sp.get("valu_busy_frac"),
+                                           "wave_wait_frac": sp.get("wave_wait_frac"),
+                                           "gathered_gbs": P * nbm * 4 / (ms * 1e-3) / 1e9,
+                                           "note": "a gather from the 64 MiB likelihood table (4 x 8-cell tiles of 128 B), served by the XCDs' L2s "
+                                                   "(TCC hit rate ~1: nothing of it is an HBM stream); achieved = L1 -> L2 requests per lane and beam "
+                                                   "(rocprofv3 TCP_TCC_READ_REQ, profiles/%s_pmc_score_poses.json) x 128 B x lane-beams/s measured "
+                                                   "here, against the 34.5 TB/s the guide measures for the L2s; gathered_gbs = the 4 useful bytes per "
+                                                   "lane and beam" % PROFILE_ROUND}}
 
     def run(n_total, reps):
         """fused step over this process's ranks: (ms per step max over ranks, info, bytes rank 0 sent per step)"""
