@@ -1551,7 +1551,7 @@ int lsa_plicp_options_default(lsa_plicp_options* o)                  // ZHCanoni
 }
 
 extern "C++" {
-template <int WG, bool COV>
+template <int T, int WG, bool COV>
 static int plicp_launch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
                         double* d_out8, double sigma, double* d_cov9)
 {
@@ -1559,7 +1559,7 @@ static int plicp_launch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const float
         static std::atomic<unsigned long long> done{0};
         const unsigned long long bit = 1ull << (c->device & 63);
         if (!(done.load(std::memory_order_acquire) & bit)) {
-            HIP_TRY(hipFuncSetAttribute((const void*)lsa::plicp_kernel<WG, COV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_TRY(hipFuncSetAttribute((const void*)lsa::plicp_kernel<T, WG, COV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             done.fetch_or(bit, std::memory_order_release);
         }
     }
@@ -1571,16 +1571,32 @@ static int plicp_launch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const float
     static std::atomic<int> occ_lds[64];
     int occ = occ_cache[c->device & 63].load();
     if (!occ || occ_lds[c->device & 63].load() != lds) {
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lsa::plicp_kernel<WG, COV>, lsa::PLICP_THREADS, lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lsa::plicp_kernel<T, WG, COV>, T, lds));
         if (occ < 1) occ = 1;
         occ_cache[c->device & 63].store(occ); occ_lds[c->device & 63].store(lds);
     }
     const long long resident = (long long)occ * c->n_cu;
     HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL((lsa::plicp_kernel<WG, COV>), dim3((unsigned)(B < resident ? B : resident)), dim3(lsa::PLICP_THREADS), lds, c->stream, P, B, d_r,
+    hipLaunchKernelGGL((lsa::plicp_kernel<T, WG, COV>), dim3((unsigned)(B < resident ? B : resident)), dim3(T), lds, c->stream, P, B, d_r,
                        d_ref_idx, d_act_idx, c->d_trig, d_out8, sigma, d_cov9, c->d_queue);
     HIP_TRY(hipGetLastError());
     return LSA_OK;
+}
+// workgroup width by scan size (plicp_threads), register budget by what the LDS lets a CU hold: four waves per SIMD (128
+// registers) when at least sixteen waves fit, three (168) otherwise
+template <bool COV>
+static int plicp_dispatch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
+                          double* d_out8, double sigma, double* d_cov9)
+{
+    const int T = lsa::plicp_threads(P.n);
+    const int wgs = (160 * 1024) / lsa::plicp_lds_bytes(P.n);
+    const bool four = wgs * (T / 64) >= 16;
+#define LSA_PLICP_GO(TT, WW) return plicp_launch<TT, WW, COV>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9)
+    if (T == 64) { if (four) LSA_PLICP_GO(64, 4); LSA_PLICP_GO(64, 3); }
+    if (T == 128) { if (four) LSA_PLICP_GO(128, 4); LSA_PLICP_GO(128, 3); }
+    if (four) LSA_PLICP_GO(256, 4);
+    LSA_PLICP_GO(256, 3);
+#undef LSA_PLICP_GO
 }
 }   // extern "C++"
 
@@ -1610,15 +1626,8 @@ int lsa_plicp_batch_cov(lsa_ctx* c, int B, const float* d_r, const int32_t* d_re
         HIP_TRY(hipMalloc((void**)&c->d_trig, sizeof(double) * t.size()));
         HIP_TRY(hipMemcpy(c->d_trig, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
     }
-    // four workgroups per CU fit while 4 x LDS <= 160 KB; larger scans get the instance budgeted for fewer
-#ifndef LSA_PLICP_WG_BIG
-#define LSA_PLICP_WG_BIG 3
-#endif
-    const bool four = 4 * (size_t)lsa::plicp_lds_bytes(P.n) <= 160 * 1024;
-    if (d_cov9) return four ? plicp_launch<4, true>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9)
-                            : plicp_launch<LSA_PLICP_WG_BIG, true>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9);
-    return four ? plicp_launch<4, false>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, 0.0, nullptr)
-                : plicp_launch<LSA_PLICP_WG_BIG, false>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, 0.0, nullptr);
+    if (d_cov9) return plicp_dispatch<true>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9);
+    return plicp_dispatch<false>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, 0.0, nullptr);
 }
 
 int lsa_plicp_batch(lsa_ctx* c, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,

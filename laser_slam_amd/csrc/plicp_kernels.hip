@@ -26,16 +26,19 @@ struct PlicpParam {
     int outliers_remove_doubles;
 };
 
-constexpr int PLICP_THREADS = 256;
-// 31^-256 mod 2^32 (31 is odd, hence a unit): inverse by Newton's iteration x <- x (2 - 31 x), then eight squarings
-constexpr uint32_t plicp_inv31_256()
+constexpr int PLICP_THREADS = 256;     // the widest workgroup
+// Threads per pair by scan size: the phases step through a scan T beams at a time and meet at some twenty-five barriers per
+// iteration, whose cost does not shrink with the scan - one wave up to 320 beams, two up to 640, four beyond (the radix
+// select keeps at most five keys per thread).
+__host__ __device__ constexpr int plicp_threads(int n) { return n <= 320 ? 64 : n <= 640 ? 128 : 256; }
+// 31^-T mod 2^32 (31 is odd, hence a unit): inverse by Newton's iteration x <- x (2 - 31 x), then log2(T) squarings
+constexpr uint32_t plicp_inv31_pow(int T)
 {
     uint32_t x = 31;                                       // 31 * 31 = 1 mod 8: three correct bits, doubled per step
     for (int k = 0; k < 5; ++k) x *= 2u - 31u * x;
-    for (int k = 0; k < 8; ++k) x *= x;
+    for (int t = T; t > 1; t >>= 1) x *= x;
     return x;
 }
-constexpr uint32_t PLICP_INV31_256 = plicp_inv31_256();
 #ifdef LSA_PLICP_STAMPS      // diagnostic build only: cycles per phase, summed over workgroups by thread 0
 __device__ unsigned long long lsa_plicp_cycles[8];
 #define PSTAMP(slot) do { if (threadIdx.x == 0) { unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&lsa_plicp_cycles[slot], t_ - pt_); pt_ = t_; } } while (0)
@@ -59,23 +62,27 @@ struct PlicpLds {
     int* hist;                                             // 2 x 264 ints of the radix select
 };
 
+template <int T>
 __device__ __forceinline__ double plicp_block_sum(double v, double* red)
 {
     for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    if (T == 64) return v;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
+    if (T == 128) return red[0] + red[1];
     return red[0] + red[1] + red[2] + red[3];
 }
 
 __device__ __forceinline__ double plicp_dist2(double ax, double ay, double bx, double by) { return (ax - bx) * (ax - bx) + (ay - by) * (ay - by); }
 
 // the same fixed-order tree for K values at once (two barriers instead of 2 K)
-template <int K>
+template <int K, int T>
 __device__ __forceinline__ void plicp_block_sums(double (&v)[K], double* red)
 {
     #pragma unroll
     for (int q = 0; q < K; ++q) for (int o = 32; o; o >>= 1) v[q] += __shfl_xor(v[q], o);
+    if (T == 64) return;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) {
         #pragma unroll
@@ -83,19 +90,24 @@ __device__ __forceinline__ void plicp_block_sums(double (&v)[K], double* red)
     }
     __syncthreads();
     #pragma unroll
-    for (int q = 0; q < K; ++q) v[q] = red[24 + q] + red[24 + K + q] + red[24 + 2 * K + q] + red[24 + 3 * K + q];
+    for (int q = 0; q < K; ++q) {
+        if (T == 128) v[q] = red[24 + q] + red[24 + K + q];
+        else v[q] = red[24 + q] + red[24 + K + q] + red[24 + 2 * K + q] + red[24 + 3 * K + q];
+    }
 }
 
 // values of ascending ranks k0 and k1 among the non-negative entries of dist[0..n) (negative = absent):
 // radix select on the bit patterns, 8 bits per round, one 256-bin LDS histogram per rank (one bin per
 // thread), the thread's own keys kept in registers.  Exact: the results are bit patterns of elements.
-// `hist` = 2 * (256 + 8) ints of scratch.  n <= 5 * PLICP_THREADS.
+// `hist` = 2 * (256 + 8) ints of scratch.  n <= 5 T (plicp_threads).
+template <int T>
 __device__ void plicp_select2(const double* dist, int n, int k0, int k1, int* hist, double& v0, double& v1)
 {
+    constexpr int BPT = 256 / T;                         // histogram bins per thread
     unsigned long long key[5];
     #pragma unroll
     for (int u = 0; u < 5; ++u) {
-        const int i = threadIdx.x + u * PLICP_THREADS;
+        const int i = threadIdx.x + u * T;
         const double d = i < n ? dist[i] : -1.0;
         key[u] = d < 0 ? ~0ull : (unsigned long long)__double_as_longlong(d);
     }
@@ -104,7 +116,8 @@ __device__ void plicp_select2(const double* dist, int n, int k0, int k1, int* hi
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int sh = 56; sh >= 0; sh -= 8) {
         __syncthreads();
-        hist[threadIdx.x] = 0; hist[264 + threadIdx.x] = 0;
+        #pragma unroll
+        for (int b = 0; b < BPT; ++b) { hist[BPT * threadIdx.x + b] = 0; hist[264 + BPT * threadIdx.x + b] = 0; }
         __syncthreads();
         #pragma unroll
         for (int u = 0; u < 5; ++u) {
@@ -114,20 +127,31 @@ __device__ void plicp_select2(const double* dist, int n, int k0, int k1, int* hi
             if ((key[u] & decided) == prefix[1]) atomicAdd(&hist[264 + bin], 1);
         }
         __syncthreads();
-        // inclusive prefix over the 256 bins of either histogram: shuffles inside the wave, 4 slots across
-        int c[2] = {hist[threadIdx.x], hist[264 + threadIdx.x]}, incl[2] = {c[0], c[1]};
+        // inclusive prefix over the 256 bins of either histogram: a thread's BPT bins, shuffles inside the wave, slots across
+        int cb[2][BPT], c[2] = {0, 0};
+        #pragma unroll
+        for (int b = 0; b < BPT; ++b) { cb[0][b] = hist[BPT * threadIdx.x + b]; cb[1][b] = hist[264 + BPT * threadIdx.x + b]; c[0] += cb[0][b]; c[1] += cb[1][b]; }
+        int incl[2] = {c[0], c[1]};
         #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int a0 = __shfl_up(incl[0], o), a1 = __shfl_up(incl[1], o);
             if (lane >= o) { incl[0] += a0; incl[1] += a1; }
         }
-        if (lane == 63) { hist[256 + wave] = incl[0]; hist[264 + 256 + wave] = incl[1]; }
-        __syncthreads();
-        for (int w = 0; w < wave; ++w) { incl[0] += hist[256 + w]; incl[1] += hist[264 + 256 + w]; }
-        // the bin where the running count passes k (exactly one thread per rank)
+        if (T > 64) {
+            if (lane == 63) { hist[256 + wave] = incl[0]; hist[264 + 256 + wave] = incl[1]; }
+            __syncthreads();
+            for (int w = 0; w < wave; ++w) { incl[0] += hist[256 + w]; incl[1] += hist[264 + 256 + w]; }
+        }
+        // the bin where the running count passes k (exactly one bin per rank)
         #pragma unroll
-        for (int q = 0; q < 2; ++q)
-            if (k[q] < incl[q] && k[q] >= incl[q] - c[q]) { hist[264 * q + 260] = (int)threadIdx.x; hist[264 * q + 261] = incl[q] - c[q]; hist[264 * q + 262] = c[q]; }
+        for (int q = 0; q < 2; ++q) {
+            int run = incl[q] - c[q];
+            #pragma unroll
+            for (int b = 0; b < BPT; ++b) {
+                if (k[q] >= run && k[q] < run + cb[q][b]) { hist[264 * q + 260] = BPT * (int)threadIdx.x + b; hist[264 * q + 261] = run; hist[264 * q + 262] = cb[q][b]; }
+                run += cb[q][b];
+            }
+        }
         __syncthreads();
         #pragma unroll
         for (int q = 0; q < 2; ++q) { prefix[q] |= (unsigned long long)hist[264 * q + 260] << sh; k[q] -= hist[264 * q + 261]; }
@@ -236,6 +260,7 @@ __device__ __forceinline__ void plicp_sens_point(const PlicpLds& L, int n, int i
 // reference point inside the reference's window and within the correspondence limit (j1), and the nearer of the
 // adjacent valid reference rays (j2); L.corr[i] = j1 | j2 << 16 or -1, L.d2[i] = the squared distance.  Last call's
 // L.corr seeds the pruned scan.  Returns this thread's number of correspondences.
+template <int T>
 __device__ __forceinline__ int plicp_correspondences(const PlicpParam& P, const PlicpLds& L, const double x_old[3], double cs, double sn)
 {
     const int n = P.n, tid = threadIdx.x;
@@ -246,7 +271,7 @@ __device__ __forceinline__ int plicp_correspondences(const PlicpParam& P, const 
     unsigned long long pt_ = __builtin_readcyclecounter();
 #endif
     int mine = 0;
-    for (int i = tid; i < n; i += PLICP_THREADS) {
+    for (int i = tid; i < n; i += T) {
         int rec = -1;
         double best = 0;
         if (L.sr[i] >= 0.0f) {
@@ -319,13 +344,13 @@ __device__ __forceinline__ int plicp_correspondences(const PlicpParam& P, const 
                 if (sb < rho) {
                     const double tq = sb / rho;                                      // asin t <= t + (pi/2 - 1) t^3 on [0, 1]
                     const int M = (int)((tq + 0.5708 * tq * tq * tq) / (double)P.dfi) + 3;   // bearings are float(fi_min + dfi j): margin
-                    const int T = (int)rint(2 * PI / (double)P.dfi);
+                    const int TR = (int)rint(2 * PI / (double)P.dfi);                // one turn in rays
                     const int c0 = (int)rint((phi - min_theta) / (double)P.dfi);
-                    // images c0 - T, c0, c0 + T in increasing order, each clipped to [from, to] and past the previous one
+                    // images c0 - TR, c0, c0 + TR in increasing order, each clipped to [from, to] and past the previous one
                     int done = from - 1;
-                    lo0 = c0 - T - M > done + 1 ? c0 - T - M : done + 1; hi0 = c0 - T + M < to ? c0 - T + M : to; if (hi0 > done) done = hi0;
+                    lo0 = c0 - TR - M > done + 1 ? c0 - TR - M : done + 1; hi0 = c0 - TR + M < to ? c0 - TR + M : to; if (hi0 > done) done = hi0;
                     lo1 = c0 - M > done + 1 ? c0 - M : done + 1;         hi1 = c0 + M < to ? c0 + M : to;         if (hi1 > done) done = hi1;
-                    lo2 = c0 + T - M > done + 1 ? c0 + T - M : done + 1; hi2 = c0 + T + M < to ? c0 + T + M : to;
+                    lo2 = c0 + TR - M > done + 1 ? c0 + TR - M : done + 1; hi2 = c0 + TR + M < to ? c0 + TR + M : to;
                     nseg = 3;
                 }
             }
@@ -363,6 +388,7 @@ __device__ __forceinline__ int plicp_correspondences(const PlicpParam& P, const 
 }
 
 // one icp_loop from q0; returns ok, x_new, total error, kept correspondences, iterations (all uniform)
+template <int T>
 __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double q0[3], double x_new[3], double& total_error,
                            int& nvalid, int& iterations)
 {
@@ -377,25 +403,25 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
 #endif
     for (it = 0; it < P.max_iterations; ++it) {
         const double cs = cos(x_old[2]), sn = sin(x_old[2]);
-        int mine = plicp_correspondences(P, L, x_old, cs, sn);
-        const int num = (int)plicp_block_sum((double)mine, L.red);
+        int mine = plicp_correspondences<T>(P, L, x_old, cs, sn);
+        const int num = (int)plicp_block_sum<T>((double)mine, L.red);
         PSTAMP(0);
         const double fail_perc = 0.05;
         if (num < fail_perc * n) { ok = false; break; }
         if (P.outliers_remove_doubles) {                    // keep the points within 3x the best distance of their reference point
-            for (int j = tid; j < n; j += PLICP_THREADS) L.dj[j] = (unsigned long long)__double_as_longlong(1000000.0);
+            for (int j = tid; j < n; j += T) L.dj[j] = (unsigned long long)__double_as_longlong(1000000.0);
             __syncthreads();
-            for (int i = tid; i < n; i += PLICP_THREADS)
+            for (int i = tid; i < n; i += T)
                 if (L.corr[i] >= 0) atomicMin(&L.dj[L.corr[i] & 0xffff], (unsigned long long)__double_as_longlong(L.d2[i]));   // d2 >= 0
             __syncthreads();
-            for (int i = tid; i < n; i += PLICP_THREADS)
+            for (int i = tid; i < n; i += T)
                 if (L.corr[i] >= 0 && L.d2[i] > 9.0 * __longlong_as_double((long long)L.dj[L.corr[i] & 0xffff])) L.corr[i] = -1;
             __syncthreads();
         }
         PSTAMP(1);
         // trimming: segment distances, their order statistics
         mine = 0;
-        for (int i = tid; i < n; i += PLICP_THREADS) {
+        for (int i = tid; i < n; i += T) {
             double d = -1.0;
             if (L.corr[i] >= 0) {
                 const int j1 = L.corr[i] & 0xffff, j2 = L.corr[i] >> 16;
@@ -406,13 +432,13 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
             }
             L.dist[i] = d;                                  // -1 = no correspondence
         }
-        const int k = (int)plicp_block_sum((double)mine, L.red);
+        const int k = (int)plicp_block_sum<T>((double)mine, L.red);
         total_error = 0; nvalid = 0;
         if (k > 0) {
             int order = (int)floor(k * P.outliers_maxPerc), order2 = (int)floor(k * P.outliers_adaptive_order);
             order = order < 0 ? 0 : (order > k - 1 ? k - 1 : order); order2 = order2 < 0 ? 0 : (order2 > k - 1 ? k - 1 : order2);
             double limit1, limit2;
-            plicp_select2(L.dist, n, order, order2, L.hist, limit1, limit2);
+            plicp_select2<T>(L.dist, n, order, order2, L.hist, limit1, limit2);
             limit2 *= P.outliers_adaptive_mult;
             const double limit = limit1 < limit2 ? limit1 : limit2;
 #ifdef LSA_PLICP_TRACE
@@ -420,19 +446,19 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
 #endif
             double err = 0;
             mine = 0;
-            for (int i = tid; i < n; i += PLICP_THREADS) {
+            for (int i = tid; i < n; i += T) {
                 const double d = L.dist[i];
                 if (d < 0) continue;
                 if (d > limit) L.corr[i] = -1; else { mine++; err += d; }
             }
-            nvalid = (int)plicp_block_sum((double)mine, L.red);
-            total_error = plicp_block_sum(err, L.red);
+            nvalid = (int)plicp_block_sum<T>((double)mine, L.red);
+            total_error = plicp_block_sum<T>(err, L.red);
         }
         PSTAMP(2);
         if (nvalid < fail_perc * n) { ok = false; break; }
         // closed-form point-to-line step
         double s[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // M upper triangle (10), g (4)
-        for (int i = tid; i < n; i += PLICP_THREADS) {
+        for (int i = tid; i < n; i += T) {
             if (L.corr[i] < 0) continue;
             const int j1 = L.corr[i] & 0xffff, j2 = L.corr[i] >> 16;
             double px, py;
@@ -447,7 +473,7 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
             for (int r = 0; r < 4; ++r) for (int c = r; c < 4; ++c) s[q++] += a[r] * a[c];
             for (int r = 0; r < 4; ++r) s[10 + r] += a[r] * b;
         }
-        plicp_block_sums<14>(s, L.red);
+        plicp_block_sums<14, T>(s, L.red);
         PSTAMP(3);
         // (every lane works the same step out; letting one wave do it and publish the result was measured: no gain)
         bool solved = nvalid >= 2;
@@ -494,10 +520,10 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
         // (one power per thread: 31^(n-1-tid); the thread's next point is 256 places further, 31^-256 mod 2^32 = 0x3e5a9801... computed below)
         uint32_t hpart = 0, pw = 1;
         if (tid < n) { uint32_t bs = 31; for (int e = n - 1 - tid; e; e >>= 1) { if (e & 1) pw *= bs; bs *= bs; } }
-        for (int i = tid; i < n; i += PLICP_THREADS) {
+        for (int i = tid; i < n; i += T) {
             const uint32_t v = (uint32_t)(L.corr[i] >= 0 ? (L.corr[i] & 0xffff) + 1000 * (L.corr[i] >> 16) : -1);
             hpart += v * pw;
-            pw *= PLICP_INV31_256;
+            pw *= plicp_inv31_pow(T);
         }
         for (int o = 32; o; o >>= 1) hpart += __shfl_xor(hpart, o);
         __syncthreads();
@@ -505,7 +531,8 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
         __syncthreads();
         if (tid == 0) {
             const uint32_t* hp = (const uint32_t*)L.red + 44;
-            const uint32_t hash = hp[0] + hp[1] + hp[2] + hp[3];
+            uint32_t hash = hp[0];
+            for (int w = 1; w < T / 64; ++w) hash += hp[w];
             int loop = 0;
             for (int a = 0; a < it && a < 64; ++a) if (hashes[a] == hash) loop = 1;
             if (it < 64) hashes[it] = hash;
@@ -558,6 +585,7 @@ __device__ __forceinline__ double plicp_quad(const double u[2], const double C[3
 // to a reference ray (as j1 or as j2): three LDS rows, accumulated with LDS double atomics, that take the place of the
 // reference points (rx, ry) and of d2 - the reference points are recomputed from the ranges in HBM/L2, bit for bit as
 // the set-up formed them.  Everything else is per point and summed with the fixed-order tree.
+template <int T>
 __device__ void plicp_covariance(const PlicpParam& P, const PlicpLds& L, const float* __restrict__ g_ref_r, const double x[3],
                                  double sigma, double* __restrict__ cov9)
 {
@@ -565,10 +593,10 @@ __device__ void plicp_covariance(const PlicpParam& P, const PlicpLds& L, const f
     const double th = x[2], cs = cos(th), sn = sin(th);
     double* a1x = L.rx; double* a1y = L.ry; double* a1t = L.d2;
     __syncthreads();
-    for (int j = tid; j < n; j += PLICP_THREADS) { a1x[j] = 0; a1y[j] = 0; a1t[j] = 0; }
+    for (int j = tid; j < n; j += T) { a1x[j] = 0; a1y[j] = 0; a1t[j] = 0; }
     __syncthreads();
     double s[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};          // H: xx xy xt yy yt tt | A2 A2^T: the same six
-    for (int i = tid; i < n; i += PLICP_THREADS) {
+    for (int i = tid; i < n; i += T) {
         if (L.corr[i] < 0) continue;
         const int j1 = L.corr[i] & 0xffff, j2 = L.corr[i] >> 16;
         double px, py;
@@ -601,11 +629,11 @@ __device__ void plicp_covariance(const PlicpParam& P, const PlicpLds& L, const f
         atomicAdd(&a1t[j2], 2 * plicp_quad(v2, D2, v1));
     }
     __syncthreads();
-    for (int j = tid; j < n; j += PLICP_THREADS) {
+    for (int j = tid; j < n; j += T) {
         const double ax = a1x[j], ay = a1y[j], at = a1t[j];
         s[6] += ax * ax; s[7] += ax * ay; s[8] += ax * at; s[9] += ay * ay; s[10] += ay * at; s[11] += at * at;
     }
-    plicp_block_sums<12>(s, L.red);
+    plicp_block_sums<12, T>(s, L.red);
     if (tid == 0) {
         const double h00 = s[0], h01 = s[1], h02 = s[2], h11 = s[3], h12 = s[4], h22 = s[5];
         const double c00 = h11 * h22 - h12 * h12, c01 = h02 * h12 - h01 * h22, c02 = h01 * h12 - h02 * h11;
@@ -615,9 +643,9 @@ __device__ void plicp_covariance(const PlicpParam& P, const PlicpLds& L, const f
         else {
             const double I[3][3] = {{c00 / det, c01 / det, c02 / det}, {c01 / det, c11 / det, c12 / det}, {c02 / det, c12 / det, c22 / det}};
             const double Sm[3][3] = {{s[6], s[7], s[8]}, {s[7], s[9], s[10]}, {s[8], s[10], s[11]}};
-            double T[3][3];
-            for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) { T[r][k] = 0; for (int m = 0; m < 3; ++m) T[r][k] += I[r][m] * Sm[m][k]; }
-            for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) { double v = 0; for (int m = 0; m < 3; ++m) v += T[r][m] * I[m][k]; cov9[3 * r + k] = sigma * sigma * v; }
+            double IS[3][3];
+            for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) { IS[r][k] = 0; for (int m = 0; m < 3; ++m) IS[r][k] += I[r][m] * Sm[m][k]; }
+            for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) { double v = 0; for (int m = 0; m < 3; ++m) v += IS[r][m] * I[m][k]; cov9[3 * r + k] = sigma * sigma * v; }
         }
     }
     __syncthreads();
@@ -629,8 +657,8 @@ __device__ void plicp_covariance(const PlicpParam& P, const PlicpLds& L, const f
 // WG = workgroups per CU the registers are budgeted for: 4 wherever the LDS allows four (up to 541 beams); beyond that the
 // LDS holds three at most, and the instance budgeted for three (168 registers instead of 128) keeps in registers what the
 // four-per-CU budget spills to scratch (540 B per lane there).  COV: also sm_icp's covariance of the result (d_cov9).
-template <int WG, bool COV>
-__global__ __launch_bounds__(PLICP_THREADS, WG) void plicp_kernel(PlicpParam P, int B, const float* __restrict__ g_r,
+template <int T, int WG, bool COV>
+__global__ __launch_bounds__(T, WG) void plicp_kernel(PlicpParam P, int B, const float* __restrict__ g_r,
                                                               const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
                                                               const double* __restrict__ trig, double* __restrict__ out8,
                                                               double sigma, double* __restrict__ cov9, unsigned int* __restrict__ queue)
@@ -657,7 +685,7 @@ __global__ __launch_bounds__(PLICP_THREADS, WG) void plicp_kernel(PlicpParam P, 
         __syncthreads();
         const int b = *claim;
         if (b >= B) break;
-        for (int i = tid; i < n; i += PLICP_THREADS) {                   // fromPMScan2LDP (:191-227) + ld_compute_cartesian
+        for (int i = tid; i < n; i += T) {                   // fromPMScan2LDP (:191-227) + ld_compute_cartesian
             const double cth = trig[i], sth = trig[n + i];             // cos | sin of float(fi_min + dfi i), from the host's libm
             for (int w = 0; w < 2; ++w) {
                 const double r = (double)g_r[(size_t)(w ? act_idx[b] : ref_idx[b]) * n + i];
@@ -670,14 +698,14 @@ __global__ __launch_bounds__(PLICP_THREADS, WG) void plicp_kernel(PlicpParam P, 
             }
         }
         __syncthreads();
-        for (int j = tid; j < n; j += PLICP_THREADS) {                    // ld_next_valid_up / _down as tables
+        for (int j = tid; j < n; j += T) {                    // ld_next_valid_up / _down as tables
             int up = j + 1, down = j - 1;
             while (up < n && !(L.rx[up] < 1e100)) ++up;
             while (down >= 0 && !(L.rx[down] < 1e100)) --down;
             L.nup[j] = up < n ? (uint16_t)up : (uint16_t)0xffff;
             L.ndown[j] = down >= 0 ? (uint16_t)down : (uint16_t)0xffff;
         }
-        for (int i = tid; i < n; i += PLICP_THREADS) L.corr[i] = -1;      // no previous match to seed the search with
+        for (int i = tid; i < n; i += T) L.corr[i] = -1;      // no previous match to seed the search with
         __syncthreads();
         // sm_icp: one icp_loop from the first guess (0); if its mean error exceeds the threshold, six more from poses
         // perturbed around its result, the lowest total error wins.  One call site for all seven runs (a = -1: the first),
@@ -692,7 +720,7 @@ __global__ __launch_bounds__(PLICP_THREADS, WG) void plicp_kernel(PlicpParam P, 
             double xa[3] = {0, 0, 0}, my_error = 0;
             int my_valid = 0, my_iters = 0;
             __syncthreads();
-            const bool ok = plicp_loop(P, L, start, xa, my_error, my_valid, my_iters);
+            const bool ok = plicp_loop<T>(P, L, start, xa, my_error, my_valid, my_iters);
             if (a < 0) {
                 iters = my_iters;
                 if (!ok) break;
@@ -710,9 +738,9 @@ __global__ __launch_bounds__(PLICP_THREADS, WG) void plicp_kernel(PlicpParam P, 
             if (COV) {
                 if (restarted) {                  // sm_icp recomputes the correspondences at the result after restarts (no outlier rejection)
                     __syncthreads();
-                    plicp_correspondences(P, L, best, cos(best[2]), sin(best[2]));
+                    plicp_correspondences<T>(P, L, best, cos(best[2]), sin(best[2]));
                 }
-                plicp_covariance(P, L, g_r + (size_t)ref_idx[b] * n, best, sigma, cov9 + 9 * (size_t)b);
+                plicp_covariance<T>(P, L, g_r + (size_t)ref_idx[b] * n, best, sigma, cov9 + 9 * (size_t)b);
             }
         } else if (COV) {
             res[5] = iters;
