@@ -1590,7 +1590,10 @@ static int plicp_dispatch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const flo
 {
     const int T = lsa::plicp_threads(P.n);
     const int wgs = (160 * 1024) / lsa::plicp_lds_bytes(P.n);
-    const bool four = wgs * (T / 64) >= 16;
+#ifndef LSA_PLICP_FOUR_MIN
+#define LSA_PLICP_FOUR_MIN 16
+#endif
+    const bool four = wgs * (T / 64) >= LSA_PLICP_FOUR_MIN;
 #define LSA_PLICP_GO(TT, WW) return plicp_launch<TT, WW, COV>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9)
     if (T == 64) { if (four) LSA_PLICP_GO(64, 4); LSA_PLICP_GO(64, 3); }
     if (T == 128) { if (four) LSA_PLICP_GO(128, 4); LSA_PLICP_GO(128, 3); }

@@ -141,3 +141,37 @@ def test_consecutive_log_scans(ctx, name):
         assert np.allclose(got[7:13], want[7:13], rtol=1e-6, atol=1e-12)
         done += got[3] > 0.5
     assert done >= 30                                   # consecutive scans pair up
+
+
+def test_batch_equals_single_problems(ctx):
+    """lsa_p2p_icp_batch (what bench.py's zhicp entries time) over concatenated clouds with offsets = the same problems one
+    by one through lsa_p2p_icp_host, bit for bit - ragged sizes, an empty current cloud and non-zero priors included."""
+    import torch
+    from laser_slam_amd import capi
+    rng = np.random.default_rng(8)
+    probs = []
+    for k in range(9):
+        n_ref, n_cur = int(rng.integers(30, 700)), (0 if k == 4 else int(rng.integers(30, 700)))
+        t = np.sort(rng.uniform(0, 6, n_ref))
+        ref = np.stack([t, 0.3 * np.sin(2 * t) + (t > 3) * 0.8], 1).astype(np.float32)
+        th, tx, ty = rng.uniform(-0.08, 0.08), rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2)
+        u = np.sort(rng.uniform(0, 6, n_cur))
+        cur_w = np.stack([u, 0.3 * np.sin(2 * u) + (u > 3) * 0.8], 1)
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        cur = ((cur_w - [tx, ty]) @ R).astype(np.float32)
+        init = (0.0, 0.0, 0.0) if k % 2 else (tx * 0.5, ty * 0.5, th * 0.5)
+        probs.append((ref, cur, init))
+    rx = np.concatenate([p[0][:, 0] for p in probs]); ry = np.concatenate([p[0][:, 1] for p in probs])
+    cx = np.concatenate([p[1][:, 0] for p in probs]); cy = np.concatenate([p[1][:, 1] for p in probs])
+    ro = np.concatenate([[0], np.cumsum([len(p[0]) for p in probs])]).astype(np.int32)
+    co = np.concatenate([[0], np.cumsum([len(p[1]) for p in probs])]).astype(np.int32)
+    init = np.array([p[2] for p in probs], np.float64)
+    d = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (rx, ry, ro, cx, cy, co, init)]
+    out = torch.zeros(len(probs), 16, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    capi.p2p_icp_batch(ctx, len(probs), d[0], d[1], d[2], d[3], d[4], d[5], len(rx), max(len(cx), 1), d[6], out)
+    got = out.cpu().numpy()
+    for k, (ref, cur, ini) in enumerate(probs):
+        want = capi.p2p_icp_host(ctx, ref[:, 0].copy(), ref[:, 1].copy(), cur[:, 0].copy(), cur[:, 1].copy(), ini)
+        assert np.array_equal(got[k, :13], want[:13]), (k, got[k, :7], want[:7])
+    assert got[4, 3] == 0 and got[4, 6] == 0
