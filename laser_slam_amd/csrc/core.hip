@@ -1330,6 +1330,20 @@ int lsa_pf_roughen(lsa_ctx* c, int n, double K, const float* d_normals, float* d
     return LSA_OK;
 }
 
+// point-to-point ICP launch: workgroup width and LDS by the largest cloud of the launch
+static void p2p_launch(lsa_ctx* c, int max_points, const lsa::P2PParam& P, int B, const float* rx, const float* ry, const int* roff,
+                       const float* cx, const float* cy, const int* coff, const double* init, unsigned long long* owner, int* match,
+                       double* out, int n_cur_shared)
+{
+    const int cap = lsa::p2p_cap_for(max_points);
+    const int T = lsa::p2p_threads(max_points);
+    const size_t lds = (size_t)lsa::p2p_lds_bytes(cap);
+#define LSA_P2P_GO(TT) hipLaunchKernelGGL((lsa::p2p_icp_kernel<TT>), dim3(B), dim3(TT), lds, c->stream, P, B, rx, ry, roff, cx, cy, coff, init, \
+                                          owner, match, out, n_cur_shared, cap)
+    if (T == 64) LSA_P2P_GO(64); else if (T == 128) LSA_P2P_GO(128); else LSA_P2P_GO(256);
+#undef LSA_P2P_GO
+}
+
 static lsa::SimParam sim_param(const lsa_field* f, int n_beams, float fov, float min_angle, float max_range)
 {
     lsa::SimParam S{};
@@ -1429,9 +1443,7 @@ int lsa_icp_goodness_scores(lsa_field* f, const float* d_prob, const float* d_po
                            n_poses, (float*)nullptr, (uint8_t*)nullptr, d_sx, d_sy);
         hipLaunchKernelGGL(lsa::iota_scaled_kernel, dim3((n_poses + 256) / 256), dim3(256), 0, c->stream, n_poses + 1, n_beams, d_off);
         lsa::P2PParam P = {o.max_iterations, o.threshold_dist, o.threshold_ang, o.alfa, o.smallest_threshold_dist};
-        const int cap = lsa::p2p_cap_for(n_beams);
-        hipLaunchKernelGGL(lsa::p2p_icp_kernel, dim3(n_poses), dim3(lsa::P2P_THREADS), lsa::p2p_lds_bytes(cap), c->stream, P, n_poses, d_sx, d_sy, d_off,
-                           d_obs_x, d_obs_y, (const int*)nullptr, d_init, d_owner, d_match, d_out, n_beams, cap);
+        p2p_launch(c, n_beams, P, n_poses, d_sx, d_sy, d_off, d_obs_x, d_obs_y, (const int*)nullptr, d_init, d_owner, d_match, d_out, n_beams);
         hipLaunchKernelGGL(lsa::icp_goodness_extract_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, c->stream, n_poses, d_out,
                            d_weight, d_rel_pose);
         e = hipGetLastError();
@@ -1695,9 +1707,16 @@ int lsa_p2p_icp_batch(lsa_ctx* c, int B, const float* d_ref_x, const float* d_re
     int* d_match = (int*)(d_owner + nro);
     hipError_t e = hipSuccess;
     lsa::P2PParam P = {o.max_iterations, o.threshold_dist, o.threshold_ang, o.alfa, o.smallest_threshold_dist};
-    const int cap = lsa::p2p_cap_for(n_ref_total > n_cur_total ? n_ref_total : n_cur_total);      // (no cloud is larger than the totals)
-    hipLaunchKernelGGL(lsa::p2p_icp_kernel, dim3(B), dim3(lsa::P2P_THREADS), lsa::p2p_lds_bytes(cap), c->stream, P, B, d_ref_x, d_ref_y,
-                       d_ref_off, d_cur_x, d_cur_y, d_cur_off, d_init_pose, d_owner, d_match, d_out16, 0, cap);
+    // the largest cloud of the batch sizes the workgroups (one, two or four waves) and their LDS: a small reduction and a
+    // 4-byte read-back ahead of the launch (the totals alone would size every batch for the worst case)
+    int rc0 = ensure_staging(c); if (rc0) return rc0;
+    int* d_max = (int*)(c->d_small + 24);
+    int h_max = 0;
+    HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(lsa::p2p_max_points_kernel, dim3(blocks_for((size_t)B, 256, 256)), dim3(256), 0, c->stream, B, d_ref_off, d_cur_off, d_max);
+    HIP_TRY(hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    p2p_launch(c, h_max, P, B, d_ref_x, d_ref_y, d_ref_off, d_cur_x, d_cur_y, d_cur_off, d_init_pose, d_owner, d_match, d_out16, 0);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(LSA_E_HIP, "p2p_icp_kernel", e);

@@ -28,6 +28,9 @@ struct P2PParam {
 };
 
 constexpr int P2P_THREADS = 256, P2P_TILE = 2048, P2P_LOCAL = 1024;   // clouds up to P2P_LOCAL points keep their pairing tables in LDS
+// Threads per problem by the largest cloud of the launch: one wave up to 256 points, two up to 512, four beyond.  The sums are
+// formed the same way at every width (p2p_sums), so a problem's result does not depend on what it shares a launch with.
+__host__ __device__ constexpr int p2p_threads(int max_points) { return max_points <= 256 ? 64 : max_points <= 512 ? 128 : 256; }
 
 // LDS of a launch whose largest cloud has `cap` points (a power of two, 64 .. P2P_TILE): the sorted first map, its
 // original indices, and - up to P2P_LOCAL points - the pairing tables.  Sized per launch: at 541 points a workgroup
@@ -36,19 +39,55 @@ __host__ __device__ inline int p2p_local_cap(int cap) { return cap < P2P_LOCAL ?
 __host__ __device__ inline int p2p_lds_bytes(int cap) { return cap * (8 + 2) + p2p_local_cap(cap) * (8 + 4); }
 __host__ inline int p2p_cap_for(int n_max) { int c = 64; while (c < n_max && c < P2P_TILE) c <<= 1; return c; }
 
-// deterministic block sum of `v` (double); result valid in every thread
-__device__ __forceinline__ double block_sum(double v, double* sh)
+// Deterministic sums of K values per element i in [0, n): the additions of a 256-thread workgroup, whatever the real width T.
+// "Virtual wave" v (0..3) owns the elements i = 64 v + lane (mod 256); each of its lanes adds its elements in increasing i,
+// the 64 lanes meet in a shuffle tree, and the four virtual waves' sums are added in order v = 0, 1, 2, 3.  A real wave
+// r of a T-thread workgroup plays the virtual waves r, r + T/64, ...; `term(i, acc)` adds element i's K terms to acc.
+// sh: 4 K doubles.  Result valid in every thread.
+template <int K, int T, typename F>
+__device__ __forceinline__ void p2p_sums(int n, double (&out)[K], double* sh, F term)
 {
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    __syncthreads();
-    if (lane_id() == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return sh[0] + sh[1] + sh[2] + sh[3];
+    constexpr int NW = T / 64;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    if (NW > 1) __syncthreads();                                   // (sh may still be read from the previous call)
+    for (int v = wave; v < 4; v += NW) {
+        double acc[K];
+        #pragma unroll
+        for (int q = 0; q < K; ++q) acc[q] = 0.0;
+        for (int i = 64 * v + lane; i < n; i += 256) term(i, acc);
+        #pragma unroll
+        for (int q = 0; q < K; ++q) for (int off = 32; off >= 1; off >>= 1) acc[q] += __shfl_xor(acc[q], off);
+        if (NW == 1) {
+            #pragma unroll
+            for (int q = 0; q < K; ++q) out[q] = v == 0 ? acc[q] : out[q] + acc[q];
+        } else if (lane == 0) {
+            #pragma unroll
+            for (int q = 0; q < K; ++q) sh[v * K + q] = acc[q];
+        }
+    }
+    if (NW > 1) {
+        __syncthreads();
+        #pragma unroll
+        for (int q = 0; q < K; ++q) out[q] = sh[q] + sh[K + q] + sh[2 * K + q] + sh[3 * K + q];
+    }
+}
+
+// largest cloud of a launch (either map): sizes the workgroups and their LDS
+__global__ __launch_bounds__(256) void p2p_max_points_kernel(int B, const int* __restrict__ ref_off, const int* __restrict__ cur_off, int* __restrict__ out)
+{
+    int m = 0;
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        const int a = ref_off[b + 1] - ref_off[b], c = cur_off ? cur_off[b + 1] - cur_off[b] : 0;
+        m = a > m ? a : m; m = c > m ? c : m;
+    }
+    for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(m, off); m = o > m ? o : m; }
+    if (lane_id() == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
 }
 
 // problem b: ref cloud [ref_off[b], ref_off[b+1]), cur cloud [cur_off[b], cur_off[b+1])
 // out[b*16 ..]: x, y, phi, goodness, quality(mean sq. residual), iterations, n_pairs, cov(xx,xy,xphi,yy,yphi,phiphi)
-__global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
+template <int T>
+__global__ __launch_bounds__(T) void p2p_icp_kernel(
     P2PParam O, int B, const float* __restrict__ ref_x, const float* __restrict__ ref_y, const int* __restrict__ ref_off,
     const float* __restrict__ cur_x, const float* __restrict__ cur_y, const int* __restrict__ cur_off,
     const double* __restrict__ init_pose, unsigned long long* __restrict__ owner, int* __restrict__ match,
@@ -60,7 +99,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
     unsigned long long* lowner = (unsigned long long*)(tile + cap);          // small problems: owner / match tables here instead of in HBM
     int* lmatch = (int*)(lowner + p2p_local_cap(cap));
     uint16_t* sid = (uint16_t*)(lmatch + p2p_local_cap(cap));                // original index of the sorted first-map points
-    __shared__ double sh[8];
+    __shared__ double sh[40];
     const int tid = threadIdx.x;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const int r0 = ref_off[b], n1 = ref_off[b + 1] - r0;
@@ -69,14 +108,14 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
             int npad = 1;
             while (npad < n1) npad <<= 1;
             __syncthreads();
-            for (int k = tid; k < npad; k += P2P_THREADS) {
+            for (int k = tid; k < npad; k += T) {
                 tile[k] = k < n1 ? make_float2(ref_x[r0 + k], ref_y[r0 + k]) : make_float2(__int_as_float(0x7f800000), 0.0f);
                 sid[k] = (uint16_t)k;
             }
             __syncthreads();
             for (int kk = 2; kk <= npad; kk <<= 1)
                 for (int j = kk >> 1; j > 0; j >>= 1) {
-                    for (int t = tid; t < (npad >> 1); t += P2P_THREADS) {
+                    for (int t = tid; t < (npad >> 1); t += T) {
                         const int i0 = ((t / j) * 2 * j) + (t % j), i1 = i0 + j;
                         const float2 a = tile[i0], c = tile[i1];
                         const uint16_t ia = sid[i0], ic = sid[i1];
@@ -95,14 +134,15 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
         double qx = init_pose[3 * b], qy = init_pose[3 * b + 1], qphi = init_pose[3 * b + 2];
         float thr_d = O.thr_dist, thr_a = O.thr_ang;
         int iter = 0, n_pairs = 0;
+        int pk0 = -1, pk1 = -1, pk2 = -1, pk3 = -1;           // sorted positions of last iteration's partners of this thread's points
         double mse = 0.0, cov[6] = {0, 0, 0, 0, 0, 0};
         bool keep = n1 > 0 && n2 > 0;
         while (keep && iter < O.max_iter) {
             const float cphi = (float)cos(qphi), sphi = (float)sin(qphi);
-            for (int j = tid; j < n1; j += P2P_THREADS) own_b[j] = ~0ull;
+            for (int j = tid; j < n1; j += T) own_b[j] = ~0ull;
             __syncthreads();
             // nearest first-map point of every second-map point
-            for (int base = 0; base < n2; base += P2P_THREADS) {
+            for (int base = 0; base < n2; base += T) {
                 const int i = base + tid;
                 float gx = 0, gy = 0, best = 3.0e38f;
                 int bj = -1;
@@ -120,30 +160,41 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
                 if (sorted) {
                     if (i < n2) {
                         best = lim2;                            // only closer points can be paired
-                        int lo = 0, hi = n1;
-                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (tile[mid].x < gx) lo = mid + 1; else hi = mid; }
-                        for (int k = lo; k < n1; ++k) {         // x >= gx, ascending
+                        // Where the scan starts: at last iteration's partner when there is one (its sorted position is kept in
+                        // a register; a thread always takes the same points), else at the insertion point of gx.  From the
+                        // partner the scan is the same exact search with a bound that is already the partner's distance: its
+                        // |x - gx| is within the bound, towards gx the x-distance shrinks, beyond it grows monotonically - a
+                        // handful of candidates instead of the slab of the pairing threshold, and no bisection.
+                        const int trip = base / T;
+                        const int pk = trip < 4 ? (trip == 0 ? pk0 : trip == 1 ? pk1 : trip == 2 ? pk2 : pk3) : -1;
+                        int lo;
+                        if (pk >= 0) lo = pk;
+                        else { lo = 0; int hi = n1; while (lo < hi) { const int mid = (lo + hi) >> 1; if (tile[mid].x < gx) lo = mid + 1; else hi = mid; } }
+                        int bk = -1;
+                        for (int k = lo; k < n1; ++k) {         // upwards
                             const float ex = gx - tile[k].x, ex2 = ex * ex;
-                            if (ex2 > best) break;
+                            if (ex2 > best && tile[k].x >= gx) break;
                             const float ey = gy - tile[k].y;
                             const float d = ex2 + ey * ey;
                             const int oj = sid[k];
-                            if (d < best || (d == best && bj >= 0 && oj < bj)) { best = d; bj = oj; }
+                            if (d < best || (d == best && bj >= 0 && oj < bj)) { best = d; bj = oj; bk = k; }
                         }
-                        for (int k = lo - 1; k >= 0; --k) {     // x < gx, descending
+                        for (int k = lo - 1; k >= 0; --k) {     // downwards
                             const float ex = gx - tile[k].x, ex2 = ex * ex;
-                            if (ex2 > best) break;
+                            if (ex2 > best && tile[k].x <= gx) break;
                             const float ey = gy - tile[k].y;
                             const float d = ex2 + ey * ey;
                             const int oj = sid[k];
-                            if (d < best || (d == best && bj >= 0 && oj < bj)) { best = d; bj = oj; }
+                            if (d < best || (d == best && bj >= 0 && oj < bj)) { best = d; bj = oj; bk = k; }
                         }
+                        const int nk = best < lim2 ? bk : -1;
+                        if (trip == 0) pk0 = nk; else if (trip == 1) pk1 = nk; else if (trip == 2) pk2 = nk; else if (trip == 3) pk3 = nk;
                     }
                 } else
                 for (int t0 = 0; t0 < n1; t0 += cap) {
                     const int tn = n1 - t0 < cap ? n1 - t0 : cap;
                     __syncthreads();
-                    for (int k = tid; k < tn; k += P2P_THREADS) tile[k] = make_float2(ref_x[r0 + t0 + k], ref_y[r0 + t0 + k]);
+                    for (int k = tid; k < tn; k += T) tile[k] = make_float2(ref_x[r0 + t0 + k], ref_y[r0 + t0 + k]);
                     __syncthreads();
                     if (i < n2)
                         for (int k = 0; k < tn; ++k) {
@@ -164,22 +215,19 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
             }
             __syncthreads();
             // sums over the surviving pairs (a = first map, b = second map in its own frame)
-            double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // n, xa, ya, xb, yb, xaxb, yayb, xayb, yaxb
-            double sq = 0;
-            for (int i = tid; i < n2; i += P2P_THREADS) {
+            double s[10];                                    // n, xa, ya, xb, yb, xaxb, yayb, xayb, yaxb, squared residuals
+            p2p_sums<10, T>(n2, s, sh, [&](int i, double (&a)[10]) {
                 const int j = match_b[i];
                 if (j >= 0 && (unsigned)own_b[j] == (unsigned)i) {
                     const double xa = ref_x[r0 + j], ya = ref_y[r0 + j], xb = cur_x[c0 + i], yb = cur_y[c0 + i];
-                    s[0] += 1; s[1] += xa; s[2] += ya; s[3] += xb; s[4] += yb;
-                    s[5] += xa * xb; s[6] += ya * yb; s[7] += xa * yb; s[8] += ya * xb;
-                    sq += (double)u2f((uint32_t)(own_b[j] >> 32));
+                    a[0] += 1; a[1] += xa; a[2] += ya; a[3] += xb; a[4] += yb;
+                    a[5] += xa * xb; a[6] += ya * yb; a[7] += xa * yb; a[8] += ya * xb;
+                    a[9] += (double)u2f((uint32_t)(own_b[j] >> 32));
                 }
-            }
-            for (int k = 0; k < 9; ++k) s[k] = block_sum(s[k], sh);
-            sq = block_sum(sq, sh);
+            });
             n_pairs = (int)s[0];
             if (n_pairs == 0) { keep = false; break; }
-            mse = sq / s[0];
+            mse = s[9] / s[0];
             // closed-form least-squares rigid transformation of the pairs
             const double N = s[0];
             const double Ax = N * (s[5] + s[6]) - s[1] * s[3] - s[2] * s[4];
@@ -200,16 +248,15 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_icp_kernel(
         // J_i = [1 0 -(s xb + c yb); 0 1 (c xb - s yb)]
         if (n_pairs >= 2) {
             const double cc = cos(qphi), ss = sin(qphi);
-            double h[4] = {0, 0, 0, 0};     // sum jx, sum jy, sum (jx^2 + jy^2), (n comes from n_pairs)
-            for (int i = tid; i < n2; i += P2P_THREADS) {
+            double h[3];                    // sum jx, sum jy, sum (jx^2 + jy^2), (n comes from n_pairs)
+            p2p_sums<3, T>(n2, h, sh, [&](int i, double (&a)[3]) {
                 const int j = match_b[i];
                 if (j >= 0 && (unsigned)own_b[j] == (unsigned)i) {
                     const double xb = cur_x[c0 + i], yb = cur_y[c0 + i];
                     const double jx = -(ss * xb + cc * yb), jy = cc * xb - ss * yb;
-                    h[0] += jx; h[1] += jy; h[2] += jx * jx + jy * jy;
+                    a[0] += jx; a[1] += jy; a[2] += jx * jx + jy * jy;
                 }
-            }
-            for (int k = 0; k < 3; ++k) h[k] = block_sum(h[k], sh);
+            });
             // H = [[n,0,a],[0,n,b],[a,b,c]] -> inverse in closed form
             const double n = n_pairs, a = h[0], bb = h[1], c = h[2];
             const double det = n * (n * c - a * a - bb * bb);
