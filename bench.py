@@ -476,7 +476,7 @@ def secondary_matchers(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, which
     ri, ai = d_ri[:Bp].contiguous(), d_ai[:Bp].contiguous()
     ms = timed(torch, lambda: capi.plicp_batch(ctx, Bp, d_raw, ri, ai, d_o8), reps=3)
     res["plicp"] = {"value": Bp / (ms * 1e-3), "unit": "scan-matches/s", "pairs": Bp, "mean_iterations": float(d_o8[:, 5].mean().item()),
-                    "roofline": valu_roofline("plicp_kernel<3, false>", Bp / (ms * 1e-3), ms, Bp, BYTES_PER_PAIR,
+                    "roofline": valu_roofline("plicp_kernel<256, 3, false>", Bp / (ms * 1e-3), ms, Bp, BYTES_PER_PAIR,
                                               {"note": "double-precision point-to-line ICP (parity unpinned: CSM absent); "
                                                        "instruction-issue and latency bound, DESIGN.md 4.7"})}
     S = raw.shape[0]
@@ -511,7 +511,7 @@ def p2p_entry(torch, capi, ctx, prob, count, what):
     pts = (len(rx) + len(cx)) / count
     return {"value": count / (ms * 1e-3), "unit": "scan-matches/s", "problems": count, "points_per_problem": pts, "what": what,
             "mean_iterations": float(out[:, 5].mean().item()), "mean_goodness": float(out[:, 3].mean().item()),
-            "roofline": valu_roofline("p2p_icp_kernel", count / (ms * 1e-3), ms, count, pts * 8.0 + 24 + 128,
+            "roofline": valu_roofline("p2p_icp_kernel<%d>" % (64 if pts / 2 <= 200 else 128 if pts / 2 <= 512 else 256), count / (ms * 1e-3), ms, count, pts * 8.0 + 24 + 128,
                                       {"note": "CICPWarpper's point-to-point ICP (MRPT icpClassic restated, parity unpinned): "
                                                "sorted-slab nearest neighbour in LDS, closed-form 2D fit in double; instruction bound"})}
 

@@ -74,6 +74,15 @@ __device__ __forceinline__ double plicp_block_sum(double v, double* red)
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// a value every lane holds identically, moved to scalar registers (the pair's poses, errors and limits live through whole
+// phases: as vector registers they are the first thing the 128-register instances send to scratch memory)
+__device__ __forceinline__ double plicp_uniform(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __device__ __forceinline__ double plicp_dist2(double ax, double ay, double bx, double by) { return (ax - bx) * (ax - bx) + (ay - by) * (ay - by); }
 
 // the same fixed-order tree for K values at once (two barriers instead of 2 K)
@@ -394,7 +403,7 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
 {
     const int n = P.n, tid = threadIdx.x;
     const double PI = 3.14159265358979323846;
-    double x_old[3] = {q0[0], q0[1], q0[2]};
+    double x_old[3] = {plicp_uniform(q0[0]), plicp_uniform(q0[1]), plicp_uniform(q0[2])};
     uint32_t* hashes = (uint32_t*)(L.red + 96);            // up to 64 remembered correspondence sets (red: 0-3 sums, 10 flag, 12-19 histogram, 22-23 hash parts, 24-79 sums<14>)
     bool ok = true;
     int it;
@@ -402,7 +411,7 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
     unsigned long long pt_ = __builtin_readcyclecounter();
 #endif
     for (it = 0; it < P.max_iterations; ++it) {
-        const double cs = cos(x_old[2]), sn = sin(x_old[2]);
+        const double cs = plicp_uniform(cos(x_old[2])), sn = plicp_uniform(sin(x_old[2]));
         int mine = plicp_correspondences<T>(P, L, x_old, cs, sn);
         const int num = (int)plicp_block_sum<T>((double)mine, L.red);
         PSTAMP(0);
@@ -500,9 +509,9 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
                     solved = fabs(det) > 1e-300;
                     if (solved) {
                         const double cth = (ah0 + l * h0) / det, sth = (ah1 + l * h1) / det;
-                        x_new[0] = Aig0 - (AiB00 * cth + AiB01 * sth);
-                        x_new[1] = Aig1 - (AiB10 * cth + AiB11 * sth);
-                        x_new[2] = atan2(sth, cth);
+                        x_new[0] = plicp_uniform(Aig0 - (AiB00 * cth + AiB01 * sth));
+                        x_new[1] = plicp_uniform(Aig1 - (AiB10 * cth + AiB11 * sth));
+                        x_new[2] = plicp_uniform(atan2(sth, cth));
                         solved = isfinite(x_new[0]) && isfinite(x_new[1]) && isfinite(x_new[2]);
                     }
                 }
@@ -550,7 +559,7 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
         PSTAMP(5);
         if (loop) { it++; break; }
         if (sqrt(del0 * del0 + del1 * del1) < P.epsilon_xy && fabs(dth) < P.epsilon_theta) { it++; break; }
-        x_old[0] = x_new[0]; x_old[1] = x_new[1]; x_old[2] = x_new[2];
+        x_old[0] = plicp_uniform(x_new[0]); x_old[1] = plicp_uniform(x_new[1]); x_old[2] = plicp_uniform(x_new[2]);
     }
     iterations = it < P.max_iterations ? it : P.max_iterations;
     return ok;
@@ -725,12 +734,12 @@ __global__ __launch_bounds__(T, WG) void plicp_kernel(PlicpParam P, int B, const
                 iters = my_iters;
                 if (!ok) break;
                 ok_first = true;
-                x[0] = xa[0]; x[1] = xa[1]; x[2] = xa[2];
-                best[0] = xa[0]; best[1] = xa[1]; best[2] = xa[2]; best_error = my_error; nvalid = my_valid;
+                x[0] = plicp_uniform(xa[0]); x[1] = plicp_uniform(xa[1]); x[2] = plicp_uniform(xa[2]);
+                best[0] = x[0]; best[1] = x[1]; best[2] = x[2]; best_error = plicp_uniform(my_error); nvalid = my_valid;
                 if (P.restart && my_error / my_valid > P.restart_threshold_mean_error) { restarted = true; runs = 7; }
             } else if (ok) {
                 iters += my_iters;
-                if (my_error < best_error) { best_error = my_error; best[0] = xa[0]; best[1] = xa[1]; best[2] = xa[2]; }
+                if (my_error < best_error) { best_error = plicp_uniform(my_error); best[0] = plicp_uniform(xa[0]); best[1] = plicp_uniform(xa[1]); best[2] = plicp_uniform(xa[2]); }
             }
         }
         if (ok_first) {

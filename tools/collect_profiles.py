@@ -7,13 +7,13 @@ sizes run different instances.  Launches of fewer than 64 workgroups are left ou
 calls of bench.py's latency entries would otherwise sit in the same rows as the batches).  `units_per_launch` is what one
 remaining launch of `bench.py --pairs 32768 --steps 1 --warmup 0 --no-cpu` processes (pairs, scans, poses); kernels launched
 with several sizes under one name have none - except p2p_icp_kernel, whose unit is the workgroup (one problem each)."""
-import collections, csv, glob, json, re, shutil, sys
+import collections, csv, glob, json, os, re, shutil, sys
 
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = "gpurun_out/%s" % rnd
-UNITS = {"lsa::icp_kernel<1081>": 32768, "lsa::psm_kernel<1081>": 32768, "lsa::plicp_kernel<3, false>": 32768,
+UNITS = {"lsa::icp_kernel<1081>": 32768, "lsa::psm_kernel<1081>": 32768, "lsa::plicp_kernel<256, 3, false>": 32768,
          "lsa::icp_kernel<361>": 131072, "lsa::psm_kernel<361>": 131072, "lsa::icp_kernel<181>": 131072, "lsa::psm_kernel<181>": 131072,
-         "lsa::icp_kernel<541>": 131072, "lsa::psm_kernel<541>": 131072, "lsa::plicp_kernel<4, false>": 131072,
+         "lsa::icp_kernel<541>": 131072, "lsa::psm_kernel<541>": 131072, "lsa::plicp_kernel<64, 4, false>": 131072, "lsa::plicp_kernel<64, 3, false>": 131072, "lsa::plicp_kernel<128, 4, false>": 131072, "lsa::plicp_kernel<128, 3, false>": 131072,
          "lsa::preprocess_lanes_kernel": 16384, "lsa::grid_binned_kernel": 2048, "lsa::grid_prep_kernel": 2048, "lsa::grid_prob_kernel": 1}
 
 
@@ -23,7 +23,7 @@ def norm(n):
 
 def read(d):
     """{kernel: {counter: [mean per launch, launches, mean workgroups]}} over the launches of >= 64 workgroups"""
-    fs = glob.glob("%s/%s/**/*counter_collection.csv" % (src, d), recursive=True)
+    fs = sorted(glob.glob("%s/%s/**/*counter_collection.csv" % (src, d), recursive=True), key=os.path.getmtime, reverse=True)   # (the newest run)
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0, 0.0]))
     if not fs:
         return {}
@@ -46,7 +46,7 @@ for d, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         if ctr in cs:
             hbm.setdefault(k, {})[ctr + "_KB_per_launch"] = cs[ctr][0]
             hbm[k]["launches"] = cs[ctr][1]
-            if k == "lsa::p2p_icp_kernel":
+            if k.startswith("lsa::p2p_icp_kernel"):
                 hbm[k]["units_per_launch"] = cs[ctr][2]
 for k, u in UNITS.items():
     if k in hbm:
@@ -62,7 +62,7 @@ sq = {}
 for k, cs in read("pmc_sq").items():
     sq[k] = {c: v[0] for c, v in cs.items()}
     sq[k]["launches"] = next(iter(cs.values()))[1]
-    if k == "lsa::p2p_icp_kernel":
+    if k.startswith("lsa::p2p_icp_kernel"):
         sq[k]["units_per_launch"] = next(iter(cs.values()))[2]
 for k, u in UNITS.items():
     if k in sq:
@@ -107,7 +107,7 @@ if sc.get("TCP_GATE_EN1_sum"):
     sc["tcp_pending_stall_frac"] = sc.get("TCP_PENDING_STALL_CYCLES_sum", 0.0) / sc["TCP_GATE_EN1_sum"]
 json.dump(sc, open("profiles/%s_pmc_score_poses.json" % rnd, "w"), indent=1)
 
-st = glob.glob("%s/stats/**/*kernel_stats.csv" % src, recursive=True)
+st = sorted(glob.glob("%s/stats/**/*kernel_stats.csv" % src, recursive=True), key=os.path.getmtime, reverse=True)
 if st:
     shutil.copy(st[0], "profiles/%s_kernel_stats.csv" % rnd)
 for a, b in (("bench_profiled.json", "bench_profiled.json"), ("bench_default.json", "bench_default.json")):
@@ -115,6 +115,6 @@ for a, b in (("bench_profiled.json", "bench_profiled.json"), ("bench_default.jso
         shutil.copy("%s/%s" % (src, a), "profiles/%s_%s" % (rnd, b))
     except OSError:
         pass
-for k in ("lsa::icp_kernel<1081>", "lsa::psm_kernel<1081>", "lsa::plicp_kernel<3, false>", "lsa::icp_kernel<361>", "lsa::psm_kernel<361>", "lsa::icp_kernel<181>"):
+for k in ("lsa::icp_kernel<1081>", "lsa::psm_kernel<1081>", "lsa::plicp_kernel<256, 3, false>", "lsa::plicp_kernel<128, 4, false>", "lsa::p2p_icp_kernel<128>", "lsa::icp_kernel<361>", "lsa::psm_kernel<361>", "lsa::icp_kernel<181>"):
     print(k, {c: "%.4g" % v for c, v in hbm.get(k, {}).items()}, {c: "%.4g" % v for c, v in sq.get(k, {}).items()})
 print("score:", {c: ("%.4g" % v if isinstance(v, float) else v) for c, v in sc.items() if c != "_note"})
