@@ -143,3 +143,64 @@ def test_comm_one_rank_over_rccl(monkeypatch):
     assert np.array_equal(grid.download(0), before[0]) and np.array_equal(grid.download(1), before[1])
     assert before[0].sum() > 0
     grid.close(); comm.close(); ctx.close()
+
+
+def _two_rank_inputs(n_total):
+    rng = np.random.default_rng(21)
+    sx, sy, res = 260, 200, 0.05
+    prob = np.full((sx, sy), 0.1, np.float32)
+    prob[:, :3] = 0.9; prob[:, -3:] = 0.9; prob[:3, :] = 0.9; prob[-3:, :] = 0.9; prob[100:104, 60:140] = 0.95
+    n = 361
+    ang = np.linspace(-np.pi / 2, np.pi / 2, n)
+    scan_x = (3.0 * np.cos(ang)).astype(np.float32); scan_y = (3.0 * np.sin(ang)).astype(np.float32)
+    nrm_p = rng.normal(0, 1, (n_total, 3)).astype(np.float32); nrm_r = rng.normal(0, 1, (n_total, 3)).astype(np.float32)
+    return prob, (sx, sy, res), n, scan_x, scan_y, nrm_p, nrm_r, ("predict", [6.5, 5.0, 0.2], [2.0, 1.5, 1.0])
+
+
+def _two_rank_step(rank, world, n_total, out_dir):
+    import torch
+    from laser_slam_amd import capi, pf
+    prob, (sx, sy, res), n, scan_x, scan_y, nrm_p, nrm_r, predict = _two_rank_inputs(n_total)
+    ctx = capi.Context(capi.param_preset("LMS211"))
+    stream = torch.cuda.Stream(); torch.cuda.set_stream(stream); ctx.set_stream(stream.cuda_stream)
+    fld = capi.Field(ctx, sx, sy, 0, 0, 0.0, 0.0, res)
+    fld.build(torch.from_numpy(prob).cuda(), 1.0, 0.3, 0.5)
+    first, cnt = pf.shard_bounds(n_total, rank, world)
+    d_x, d_y = torch.from_numpy(scan_x).cuda(), torch.from_numpy(scan_y).cuda()
+    fp = pf.FusedDevicePrims(ctx, fld, cnt, d_x, d_y, n, 3)
+    f = pf.FusedParticleFilter(n_total, fp, resample_threshold=2.0, roughen_K=0.2)
+    cur = torch.zeros(cnt, 3, device="cuda")
+    d_np = torch.from_numpy(nrm_p[first:first + cnt].copy()).cuda(); d_nr = torch.from_numpy(nrm_r[first:first + cnt].copy()).cuda()
+    new, info = f.step(cur, 0.37, predict=predict, normals_predict=d_np, normals_roughen=d_nr)
+    torch.cuda.synchronize()
+    allnew = pf.gather_concat(new.cpu())
+    if rank == 0:
+        np.save(os.path.join(out_dir, "poses_w%d.npy" % world), allnew.numpy())
+        np.save(os.path.join(out_dir, "info_w%d.npy" % world), np.array([info["best_score"], info["best_index"], info["n_eff"], f.bytes_sent]))
+    fp.close(); fld.close(); ctx.close()
+
+
+def _two_rank_worker(rank, world, port, n_total, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _two_rank_step(rank, world, n_total, out_dir)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fused_step_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
+    """The fused step's exchange with real device buffers: two processes (gloo, both on this box's one GPU; the collectives
+    move host copies) run pf.FusedParticleFilter over the two halves of 100 001 particles - best keys and records gathered,
+    the offspring that change halves exchanged, the extremes reduced - and the concatenated result equals the step of one
+    process over the whole set bit for bit.  What RCCL would carry instead of gloo are the same tensors."""
+    import torch.multiprocessing as mp
+    n_total = 100001
+    port = 29650 + (os.getpid() % 200)
+    mp.spawn(_two_rank_worker, args=(2, port, n_total, str(tmp_path)), nprocs=2, join=True)
+    _two_rank_step(0, 1, n_total, str(tmp_path))
+    two, one = np.load(tmp_path / "poses_w2.npy"), np.load(tmp_path / "poses_w1.npy")
+    i2, i1 = np.load(tmp_path / "info_w2.npy"), np.load(tmp_path / "info_w1.npy")
+    assert two.shape == (n_total, 3) and np.array_equal(two, one)
+    assert i2[0] == i1[0] and i2[1] == i1[1] and abs(i2[2] - i1[2]) < 1e-9 * i1[2]
+    assert i1[3] == 0 and 0 < i2[3] < 12 * n_total / 4
