@@ -194,11 +194,13 @@ def pmc_per_unit(kernel):
         units = rec.get("units_per_launch")
         if units:
             out["valu_instr_per_unit"] = rec["SQ_INSTS_VALU"] / units
-        # share of the SIMDs' time with a vector instruction in flight: SQ_ACTIVE_INST_VALU (quad-cycles, summed over the SIMDs)
-        # over the quad-cycles the SIMDs had while the kernel's waves were resident (SQ_BUSY_CYCLES: per shader engine, all
-        # of whose SIMDs tick together - the GRBM counter round 2 divided by also ticks between dispatches and on idle XCDs)
+        # share of the busy CUs' SIMD cycles with a vector instruction in flight.  SQ_ACTIVE_INST_VALU counts issue units, not
+        # clock cycles: 1.01 per wave64 instruction for pm_icp's mix, where a full-rate instruction occupies a SIMD-32 for two
+        # cycles (more for double precision and transcendentals, which count more units) - priced at four cycles, as round 2
+        # did, the units exceed the SIMD cycles there are (the 1.077 of its line).  Denominator: SQ_BUSY_CU_CYCLES, in clock
+        # cycles per CU, x 4 SIMDs.
         if rec.get("SQ_BUSY_CU_CYCLES"):
-            out["valu_busy_frac"] = min(1.0, rec["SQ_ACTIVE_INST_VALU"] / (rec["SQ_BUSY_CU_CYCLES"] * 4.0))
+            out["valu_busy_frac"] = min(1.0, 2.0 * rec["SQ_ACTIVE_INST_VALU"] / (4.0 * rec["SQ_BUSY_CU_CYCLES"]))
         if rec.get("SQ_WAVE_CYCLES") and rec.get("SQ_WAIT_ANY") is not None:
             out["wave_wait_frac"] = rec["SQ_WAIT_ANY"] / rec["SQ_WAVE_CYCLES"]
         if rec.get("SQ_THREAD_CYCLES_VALU") and rec.get("SQ_INSTS_VALU"):
@@ -227,8 +229,8 @@ def valu_roofline(kernel, units_per_s, kernel_ms, units_per_launch, alg_bytes_pe
          "note": "vector-instruction-issue bound (DESIGN.md 4.1): achieved = wave64 VALU instructions per unit (rocprofv3 "
                  "SQ_INSTS_VALU, profiles/%s_pmc_sq_counters.json) x units/s measured here; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 "
                  "cycles per single-precision instruction (the mix here also holds double-precision and transcendental "
-                 "instructions that take 4 and 8, and a lone ready wave issues every 4); valu_busy_frac = SQ_ACTIVE_INST_VALU / "
-                 "(4 SIMDs x SQ_BUSY_CU_CYCLES), the share of the busy CUs' SIMD time with a vector instruction in flight (<= 1); "
+                 "instructions that take 4 and 8, and a lone ready wave issues every 4); valu_busy_frac = 2 cycles x SQ_ACTIVE_INST_VALU / "
+                 "(4 SIMDs x SQ_BUSY_CU_CYCLES), the share of the busy CUs' SIMD cycles with a vector instruction in flight; "
                  "wave_wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES; valu_lane_util = active lanes per vector instruction / 64 "
                  "(SQ_THREAD_CYCLES_VALU); hbm = algorithmic bytes of SURVEY 8d" % PROFILE_ROUND}
     if extra:

@@ -71,11 +71,12 @@ for k, e in sq.items():
     if e.get("SQ_WAVE_CYCLES"):
         e["wave_wait_frac"] = e.get("SQ_WAIT_ANY", 0.0) / e["SQ_WAVE_CYCLES"]
     if e.get("SQ_BUSY_CU_CYCLES"):
-        e["valu_busy_frac"] = e.get("SQ_ACTIVE_INST_VALU", 0.0) / (4.0 * e["SQ_BUSY_CU_CYCLES"])
+        e["valu_busy_frac"] = 2.0 * e.get("SQ_ACTIVE_INST_VALU", 0.0) / (4.0 * e["SQ_BUSY_CU_CYCLES"])
 sq["_note"] = ("rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CU_CYCLES "
                "GRBM_GUI_ACTIVE, one pass of `python3 bench.py --pairs 32768 --steps 1 --warmup 0 --no-cpu`; averages per launch over the launches "
-               "of >= 64 workgroups.  wave_wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES; valu_busy_frac = SQ_ACTIVE_INST_VALU / (4 SIMDs x "
-               "SQ_BUSY_CU_CYCLES).  GRBM_GUI_ACTIVE is summed over the 8 XCDs.")
+               "of >= 64 workgroups.  wave_wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES; valu_busy_frac = 2 cycles x SQ_ACTIVE_INST_VALU / (4 SIMDs x "
+               "SQ_BUSY_CU_CYCLES): the counter counts issue units (1.01 per wave64 instruction in pm_icp), a full-rate unit occupies a "
+               "SIMD-32 for two cycles.  GRBM_GUI_ACTIVE is summed over the 8 XCDs.")
 json.dump(sq, open("profiles/%s_pmc_sq_counters.json" % rnd, "w"), indent=1)
 
 # the pose scorer alone (tools/score_probe.py: 2^20 poses x 361 beams per launch)
@@ -102,7 +103,7 @@ if sc.get("SQ_WAVE_CYCLES"):
     sc["wave_wait_frac"] = sc.get("SQ_WAIT_ANY", 0.0) / sc["SQ_WAVE_CYCLES"]
     sc["wave_wait_inst_frac"] = sc.get("SQ_WAIT_INST_ANY", 0.0) / sc["SQ_WAVE_CYCLES"]
 if sc.get("SQ_BUSY_CU_CYCLES"):
-    sc["valu_busy_frac"] = sc.get("SQ_ACTIVE_INST_VALU", 0.0) / (4.0 * sc["SQ_BUSY_CU_CYCLES"])
+    sc["valu_busy_frac"] = 2.0 * sc.get("SQ_ACTIVE_INST_VALU", 0.0) / (4.0 * sc["SQ_BUSY_CU_CYCLES"])
 if sc.get("TCP_GATE_EN1_sum"):
     sc["tcp_pending_stall_frac"] = sc.get("TCP_PENDING_STALL_CYCLES_sum", 0.0) / sc["TCP_GATE_EN1_sum"]
 json.dump(sc, open("profiles/%s_pmc_score_poses.json" % rnd, "w"), indent=1)
