@@ -423,6 +423,7 @@ def main():
                 sec.update(secondary_grid(torch, capi, ctx, raw, p))
                 sec.update(secondary_logs(torch, capi))
                 sec.update(secondary_latency(torch, capi, raw))
+                sec.update(secondary_global(torch, capi, ctx, raw, p))
     if watchdog is not None:
         watchdog.cancel()
     if rank == 0:
@@ -629,7 +630,7 @@ def secondary_grid(torch, capi, ctx, raw, p):
     n = raw.shape[1]
     fi = capi.param_tables(p)[0]
     nb = 2048
-    poses = synth.path_pose(np.arange(nb))
+    poses = synth.path_pose(np.arange(nb) % N_BASE)               # (scan s * N_BASE + k of the set was taken at path_pose(k))
     rr = np.concatenate([raw, raw])[:nb] / 100.0
     gx = (poses[:, 0:1] + rr * np.cos(poses[:, 2:3] + fi[None])).astype(np.float32)
     gy = (poses[:, 1:2] + rr * np.sin(poses[:, 2:3] + fi[None])).astype(np.float32)
@@ -674,9 +675,9 @@ def pf_world(torch, capi, ctx, raw, p):
     from laser_slam_amd import synth
     n = raw.shape[1]
     fi = capi.param_tables(p)[0]
-    nb = 256
-    poses = synth.path_pose(np.arange(nb) * 6)
-    rr = raw[(np.arange(nb) * 6) % N_BASE] / 100.0
+    nb = 256                                                  # (scan s * N_BASE + k of the set was taken at path_pose(k))
+    poses = synth.path_pose(np.arange(nb) % N_BASE)
+    rr = raw[np.arange(nb)] / 100.0
     gx = (poses[:, 0:1] + rr * np.cos(poses[:, 2:3] + fi[None])).astype(np.float32)
     gy = (poses[:, 1:2] + rr * np.sin(poses[:, 2:3] + fi[None])).astype(np.float32)
     G = 4096
@@ -698,6 +699,45 @@ def pf_cloud(torch, P, seed):
     rng = np.random.default_rng(seed)
     pp = np.stack([10 + rng.normal(0, 1.0, P), 7.5 + rng.normal(0, 1.0, P), rng.normal(0, 0.3, P)], 1).astype(np.float32)
     return torch.from_numpy(pp).cuda()
+
+
+def secondary_global(torch, capi, ctx, raw, p):
+    """Global localisation (BASELINE config 3: the brute-force (x, y, theta) pose search on synthetic 1081-beam scans; in the
+    reference threadLocalization::globalization, src/localization/localization.cpp:483-540 - SURVEY.md 0 maps "zhcsm
+    correlative" to it): candidate poses on randomPose's lattice over the 20 m x 15 m room -> CVPmap::isValidPose -> scorer
+    -> topK(60).  Two sizes: 2^20 candidates with the likelihood-field scorer (obsLikelyhood3), and the reference's own
+    10 000 candidates with its default scorer obsLikelyhood (a virtual scan ray-cast per pose, aligned with the observed one
+    by CICPWarpper's ICP)."""
+    from laser_slam_amd import localization, synth
+    res = {}
+    grid, fld, d_sx, d_sy, n = pf_world(torch, capi, ctx, raw, p)
+    d_prob = torch.from_numpy(grid.download(2)).cuda()
+    rng = np.random.default_rng(5)
+    true = synth.path_pose(0).astype(np.float32)
+    for name, P, scorer in (("likelihood_field_2^20", 1 << 20, "likelihood"), ("icp_goodness_10000", 10000, "icp")):
+        poses = localization.random_poses(P, synth.ROOM_W, synth.ROOM_H, rng)
+        poses[0] = true                                        # (the observed scan's own pose is among the candidates)
+        d_poses = torch.from_numpy(poses).cuda()
+        if scorer == "likelihood":                             # the synthetic scan itself, plain pose (+) point frame
+            scan = dict(x=d_sx, y=d_sy, decimation=3, std_frame=True)
+        else:                                                  # what the map shows from the true pose, in CVPmap's scan frame
+            nb = 361
+            r = torch.zeros(1, nb, device="cuda"); bad = torch.zeros(1, nb, dtype=torch.uint8, device="cuda")
+            capi.simulate_scans(fld, d_prob, d_poses[:1].contiguous(), 1, nb, r, bad); ctx.sync()
+            ang = np.float32(-3.141592654 / 4.0) + np.arange(nb, dtype=np.float32) * (np.float32(capi.SIM_FOV) / np.float32(nb - 1))
+            rr = r[0].cpu().numpy()
+            scan = dict(x=torch.from_numpy((rr * np.cos(ang)).astype(np.float32)).cuda(), y=torch.from_numpy((rr * np.sin(ang)).astype(np.float32)).cuda())
+        torch.cuda.synchronize()
+        best, idx, sc = localization.global_search(fld, d_prob, d_poses, scan, scorer=scorer)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            best, idx, sc = localization.global_search(fld, d_prob, d_poses, scan, scorer=scorer)
+        dt = (time.perf_counter() - t0) / reps
+        res[name] = {"value": P / dt, "unit": "candidate poses/s", "candidates": P, "ms_per_search": dt * 1e3, "scorer": scorer,
+                     "best_is_true_pose": bool(int(idx[0]) == 0), "best_pose_error_m": float(np.hypot(best[0] - true[0], best[1] - true[1]))}
+    fld.close(); grid.close()
+    return {"global_search": res}
 
 
 def secondary_pf(torch, capi, ctx, dist, rank, world, raw, p, coll_dev):

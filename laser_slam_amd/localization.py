@@ -25,7 +25,8 @@ def random_poses(n, x_range, y_range, rng):
 
 def global_search(field, d_prob, d_poses, scan, scorer="likelihood", k=N_KEEP, free_thr=0.3, unknown=0.5):
     """d_poses: [P][3] candidates (device).  scan: dict with the observation in the form the scorer needs -
-    "likelihood": field built (field.build / build_from_grid), scan["x"], scan["y"] device floats (scan frame, m);
+    "likelihood": field built (field.build / build_from_grid), scan["x"], scan["y"] device floats (scan frame, m; CVPmap's
+    frame, or the plain pose (+) point frame with scan["std_frame"] = True);
     "beam": scan["r"] (m), scan["bad"] (uint8) device arrays of n beams;
     "icp": scan["x"], scan["y"] device floats of n beams (CVPmap::obsLikelyhood, the reference's choice).
     Returns (best pose[3], indices of the k best among the valid candidates' original positions, their scores)."""
@@ -45,7 +46,8 @@ def global_search(field, d_prob, d_poses, scan, scorer="likelihood", k=N_KEEP, f
     # set with ctx.set_stream might not)
     torch.cuda.current_stream().synchronize()
     if scorer == "likelihood":
-        field.score_poses(scan["x"], scan["y"], scan["x"].numel(), scan.get("decimation", 3), d_cand, M, d_score)
+        field.score_poses(scan["x"], scan["y"], scan["x"].numel(), scan.get("decimation", 3), d_cand, M, d_score,
+                          std_frame=bool(scan.get("std_frame", False)))
     elif scorer == "beam":
         capi.beam_model_scores(field, d_prob, d_cand, M, scan["r"], scan["bad"], scan["r"].numel(), d_score)
     elif scorer == "icp":
