@@ -33,10 +33,10 @@ constexpr int P2P_THREADS = 256, P2P_TILE = 2048, P2P_LOCAL = 1024;   // clouds 
 __host__ __device__ constexpr int p2p_threads(int max_points) { return max_points <= 256 ? 64 : max_points <= 512 ? 128 : 256; }
 
 // LDS of a launch whose largest cloud has `cap` points (a power of two, 64 .. P2P_TILE): the sorted first map, its
-// original indices, and - up to P2P_LOCAL points - the pairing tables.  Sized per launch: at 541 points a workgroup
+// original indices, and - up to P2P_LOCAL points - the pairing tables and the second map's points.  Sized per launch: at 541 points a workgroup
 // needs 14 KB instead of the 32 KB of the largest case, and eight of them share a CU instead of five.
 __host__ __device__ inline int p2p_local_cap(int cap) { return cap < P2P_LOCAL ? cap : P2P_LOCAL; }
-__host__ __device__ inline int p2p_lds_bytes(int cap) { return cap * (8 + 2) + p2p_local_cap(cap) * (8 + 4); }
+__host__ __device__ inline int p2p_lds_bytes(int cap) { return cap * (8 + 2) + p2p_local_cap(cap) * (8 + 4 + 8); }
 __host__ inline int p2p_cap_for(int n_max) { int c = 64; while (c < n_max && c < P2P_TILE) c <<= 1; return c; }
 
 // Deterministic sums of K values per element i in [0, n): the additions of a 256-thread workgroup, whatever the real width T.
@@ -98,7 +98,8 @@ __global__ __launch_bounds__(T) void p2p_icp_kernel(
     float2* tile = (float2*)p2p_smem;
     unsigned long long* lowner = (unsigned long long*)(tile + cap);          // small problems: owner / match tables here instead of in HBM
     int* lmatch = (int*)(lowner + p2p_local_cap(cap));
-    uint16_t* sid = (uint16_t*)(lmatch + p2p_local_cap(cap));                // original index of the sorted first-map points
+    float2* cpts = (float2*)(lmatch + p2p_local_cap(cap));                   // small problems: the second map's points (every iteration reads them twice)
+    uint16_t* sid = (uint16_t*)(cpts + p2p_local_cap(cap));                  // original index of the sorted first-map points
     __shared__ double sh[40];
     const int tid = threadIdx.x;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
@@ -131,6 +132,9 @@ __global__ __launch_bounds__(T) void p2p_icp_kernel(
         const bool local = n1 <= p2p_local_cap(cap) && n2 <= p2p_local_cap(cap);
         int* const match_b = local ? lmatch : match + (cur_off ? (size_t)c0 : (size_t)b * n_cur_shared);
         unsigned long long* const own_b = local ? lowner : owner + r0;
+        // sorted first map: partners are named by their SORTED position (owner table and match list alike), so that their
+        // coordinates come from the LDS tile; the original index only breaks ties, as before
+        if (local) for (int i = tid; i < n2; i += T) cpts[i] = make_float2(cur_x[c0 + i], cur_y[c0 + i]);
         double qx = init_pose[3 * b], qy = init_pose[3 * b + 1], qphi = init_pose[3 * b + 2];
         float thr_d = O.thr_dist, thr_a = O.thr_ang;
         int iter = 0, n_pairs = 0;
@@ -145,9 +149,10 @@ __global__ __launch_bounds__(T) void p2p_icp_kernel(
             for (int base = 0; base < n2; base += T) {
                 const int i = base + tid;
                 float gx = 0, gy = 0, best = 3.0e38f;
-                int bj = -1;
+                int bj = -1, bj_sorted = -1;                    // partner: original index (ties), sorted position (tables)
                 if (i < n2) {
-                    const float px = cur_x[c0 + i], py = cur_y[c0 + i];
+                    const float2 pq = local ? cpts[i] : make_float2(cur_x[c0 + i], cur_y[c0 + i]);
+                    const float px = pq.x, py = pq.y;
                     gx = (float)qx + cphi * px - sphi * py;
                     gy = (float)qy + sphi * px + cphi * py;
                 }
@@ -171,22 +176,41 @@ __global__ __launch_bounds__(T) void p2p_icp_kernel(
                         if (pk >= 0) lo = pk;
                         else { lo = 0; int hi = n1; while (lo < hi) { const int mid = (lo + hi) >> 1; if (tile[mid].x < gx) lo = mid + 1; else hi = mid; } }
                         int bk = -1;
-                        for (int k = lo; k < n1; ++k) {         // upwards
-                            const float ex = gx - tile[k].x, ex2 = ex * ex;
-                            if (ex2 > best && tile[k].x >= gx) break;
-                            const float ey = gy - tile[k].y;
-                            const float d = ex2 + ey * ey;
-                            const int oj = sid[k];
-                            if (d < best || (d == best && bj >= 0 && oj < bj)) { best = d; bj = oj; bk = k; }
+                        // four candidates per step, their loads issued together (a step's later candidates are looked at only
+                        // if the earlier ones did not end the scan: the order of evaluation is the one-by-one order)
+                        for (int k = lo; k < n1; k += 4) {      // upwards
+                            float2 tq[4]; int so[4];
+                            #pragma unroll
+                            for (int u = 0; u < 4; ++u) { const int kc = k + u < n1 ? k + u : n1 - 1; tq[u] = tile[kc]; so[u] = sid[kc]; }
+                            bool stop = false;
+                            #pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if (stop || k + u >= n1) { stop = true; continue; }
+                                const float ex = gx - tq[u].x, ex2 = ex * ex;
+                                if (ex2 > best && tq[u].x >= gx) { stop = true; continue; }
+                                const float ey = gy - tq[u].y;
+                                const float d = ex2 + ey * ey;
+                                if (d < best || (d == best && bj >= 0 && so[u] < bj)) { best = d; bj = so[u]; bk = k + u; }
+                            }
+                            if (stop) break;
                         }
-                        for (int k = lo - 1; k >= 0; --k) {     // downwards
-                            const float ex = gx - tile[k].x, ex2 = ex * ex;
-                            if (ex2 > best && tile[k].x <= gx) break;
-                            const float ey = gy - tile[k].y;
-                            const float d = ex2 + ey * ey;
-                            const int oj = sid[k];
-                            if (d < best || (d == best && bj >= 0 && oj < bj)) { best = d; bj = oj; bk = k; }
+                        for (int k = lo - 1; k >= 0; k -= 4) {  // downwards
+                            float2 tq[4]; int so[4];
+                            #pragma unroll
+                            for (int u = 0; u < 4; ++u) { const int kc = k - u > 0 ? k - u : 0; tq[u] = tile[kc]; so[u] = sid[kc]; }
+                            bool stop = false;
+                            #pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if (stop || k - u < 0) { stop = true; continue; }
+                                const float ex = gx - tq[u].x, ex2 = ex * ex;
+                                if (ex2 > best && tq[u].x <= gx) { stop = true; continue; }
+                                const float ey = gy - tq[u].y;
+                                const float d = ex2 + ey * ey;
+                                if (d < best || (d == best && bj >= 0 && so[u] < bj)) { best = d; bj = so[u]; bk = k - u; }
+                            }
+                            if (stop) break;
                         }
+                        if (bj >= 0) bj_sorted = bk;
                         const int nk = best < lim2 ? bk : -1;
                         if (trip == 0) pk0 = nk; else if (trip == 1) pk1 = nk; else if (trip == 2) pk2 = nk; else if (trip == 3) pk3 = nk;
                     }
@@ -206,9 +230,9 @@ __global__ __launch_bounds__(T) void p2p_icp_kernel(
                 int mj = -1;
                 if (i < n2 && bj >= 0) {
                     if (best < lim2) {
-                        mj = bj;
+                        mj = sorted ? bj_sorted : bj;
                         // the first-map point keeps its closest partner (ties: smaller index)
-                        atomicMin(&own_b[bj], ((unsigned long long)f2u(best) << 32) | (unsigned)i);
+                        atomicMin(&own_b[mj], ((unsigned long long)f2u(best) << 32) | (unsigned)i);
                     }
                 }
                 if (i < n2) match_b[i] = mj;
@@ -219,7 +243,9 @@ __global__ __launch_bounds__(T) void p2p_icp_kernel(
             p2p_sums<10, T>(n2, s, sh, [&](int i, double (&a)[10]) {
                 const int j = match_b[i];
                 if (j >= 0 && (unsigned)own_b[j] == (unsigned)i) {
-                    const double xa = ref_x[r0 + j], ya = ref_y[r0 + j], xb = cur_x[c0 + i], yb = cur_y[c0 + i];
+                    const float2 pa = sorted ? tile[j] : make_float2(ref_x[r0 + j], ref_y[r0 + j]);
+                    const float2 pb = local ? cpts[i] : make_float2(cur_x[c0 + i], cur_y[c0 + i]);
+                    const double xa = pa.x, ya = pa.y, xb = pb.x, yb = pb.y;
                     a[0] += 1; a[1] += xa; a[2] += ya; a[3] += xb; a[4] += yb;
                     a[5] += xa * xb; a[6] += ya * yb; a[7] += xa * yb; a[8] += ya * xb;
                     a[9] += (double)u2f((uint32_t)(own_b[j] >> 32));
@@ -252,7 +278,8 @@ __global__ __launch_bounds__(T) void p2p_icp_kernel(
             p2p_sums<3, T>(n2, h, sh, [&](int i, double (&a)[3]) {
                 const int j = match_b[i];
                 if (j >= 0 && (unsigned)own_b[j] == (unsigned)i) {
-                    const double xb = cur_x[c0 + i], yb = cur_y[c0 + i];
+                    const float2 pb = local ? cpts[i] : make_float2(cur_x[c0 + i], cur_y[c0 + i]);
+                    const double xb = pb.x, yb = pb.y;
                     const double jx = -(ss * xb + cc * yb), jy = cc * xb - ss * yb;
                     a[0] += jx; a[1] += jy; a[2] += jx * jx + jy * jy;
                 }

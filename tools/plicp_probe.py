@@ -8,10 +8,18 @@ from laser_slam_amd import capi, synth
 if len(sys.argv) > 1 and sys.argv[1] != "-":
     capi.LIB_PATH = os.path.abspath(sys.argv[1])
 import torch
-raw = np.concatenate([synth.make_scans(200, noise_seed=12345 + j)[0] for j in range(2)], 0)
-p = capi.param_make(**synth.SYN1081); ctx = capi.Context(p, 0)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-idx = np.arange(B) % (len(raw) - 1); idx = np.where(idx % 200 == 199, idx - 1, idx).astype(np.int32)
+if len(sys.argv) > 3:                                       # a log's head instead of the synthetic set: fr079 | intel | mit | indoor
+    preset, fname, tag = {"fr079": ("LMS511", "fr079_head.log", "ROBOTLASER1"), "intel": ("LMS211", "intel_head.log", "ROBOTLASER1"),
+                          "mit": ("LMS511", "mit_head.log", "ROBOTLASER1"), "indoor": ("LMS151", "indoor_head.txt", "LMS151")}[sys.argv[3]]
+    p = capi.param_preset(preset)
+    raw = capi.carmen_read(p, os.path.join(ROOT, "tests", "golden", fname), tag)[0]
+    ctx = capi.Context(p, 0)
+    idx = (np.arange(B) % (len(raw) - 1)).astype(np.int32)
+else:
+    raw = np.concatenate([synth.make_scans(200, noise_seed=12345 + j)[0] for j in range(2)], 0)
+    p = capi.param_make(**synth.SYN1081); ctx = capi.Context(p, 0)
+    idx = np.arange(B) % (len(raw) - 1); idx = np.where(idx % 200 == 199, idx - 1, idx).astype(np.int32)
 d_r = torch.from_numpy(raw).cuda(); ri = torch.from_numpy(idx).cuda(); ai = ri + 1
 out = torch.zeros(B, 8, dtype=torch.float64, device="cuda"); torch.cuda.synchronize()
 capi.plicp_batch(ctx, B, d_r, ri, ai, out); ctx.sync()
