@@ -26,11 +26,12 @@
 constexpr int ICP_THREADS = 256;     // the largest workgroup (1081 beams, the size-generic instance)
 // Threads per pair by sensor size: the order-free phases cover a scan 64 x waves beams at a time, the order-bound ones run
 // on one wave while the pair's other waves wait - so a workgroup should not be wider than the scan needs.  181 beams (LMS211)
-// get ONE wave (three trips, no workgroup barrier at all: 3.66 -> 5.93 M matches/s on intel-lab's head), 361 (LMS511) two
-// waves (2.02 -> 2.43 M on fr079's), everything larger four (541 beams on two waves measured 2 % slower than on four).
+// get ONE wave (three trips, no workgroup barrier at all: 3.66 -> 5.93 M matches/s on intel-lab's head), 361 and 541 (LMS511,
+// LMS151) two waves with the reference points in the workgroup's global slot, which is what lets 13 such workgroups share a CU
+// (fr079 2.02 -> 2.49 M, indoor 6.24 -> 6.85 M; 541 beams on two waves with the points in LDS: 2 % SLOWER than four), 1081 four.
 // Constraints: the dropped fifth of the matches must fit one thread each ((int)(0.2 n) <= T) and a thread keeps the last
 // matches of at most six beams in registers (n <= 6 T).
-__host__ __device__ constexpr int icp_threads(int nc) { return nc == 181 ? 64 : nc == 361 ? 128 : 256; }
+__host__ __device__ constexpr int icp_threads(int nc) { return nc == 181 ? 64 : (nc == 361 || nc == 541) ? 128 : 256; }
 
 // ---- diagnostics (the only conditional code in this file) ------------------------------------------------
 // -DLSA_PHASE_STAMPS: thread 0 of every workgroup adds the cycles it spent per phase to lsa_phase_cycles[]
@@ -83,8 +84,8 @@ __host__ __device__ inline int icp_mask_bytes(int n)
     int Np = (n + 63) & ~63;
     return (Np / 8 + 8 + 15) & ~15;            // one bit per ray + one spare word for two-word windows
 }
-// Where the reference scan's points live.  In LDS (8 Np bytes) as long as eight workgroups still fit a CU (up to 541
-// beams); beyond that in the workgroup's slot of a global scratch array - written once per pair, read through L1 / L2 by
+// Where the reference scan's points live.  In LDS (8 Np bytes) for the one-wave instance (181 beams); from 361 beams on in the
+// workgroup's slot of a global scratch array - written once per pair, read through L1 / L2 by
 // the nearest-neighbour search and the interpolation: at 1081 beams that costs 3.4 % at equal occupancy and buys seven
 // workgroups per CU instead of six (+6.6 %; 3 / 4 / 5 / 6 per CU run at 0.61 / 0.77 / 0.90 / 1.00 of six).  The
 // size-generic instance (NC = 0) always uses the slot, so that the address space is fixed at compile time.
@@ -93,7 +94,7 @@ __host__ __device__ inline int icp_lds_bytes(int n, bool ref_global, int T)
     int Np = (n + 63) & ~63;
     return (ref_global ? 12 : 20) * Np + icp_d_bytes(n, T) + (icp_lists_separate(n, T) ? 12 * Np : 0) + 256 + 2 * icp_mask_bytes(n);
 }
-__host__ __device__ constexpr bool icp_ref_global(int nc) { return nc == 0 || nc > 541; }
+__host__ __device__ constexpr bool icp_ref_global(int nc) { return nc == 0 || nc >= 361; }
 // bytes of one workgroup's slot in the global scratch
 __host__ __device__ inline size_t icp_ref_slot_bytes(int n, bool ref_global) { return ref_global ? (size_t)8 * ((n + 63) & ~63) : 0; }
 
@@ -658,10 +659,11 @@ __device__ __noinline__ void icp_error_tail(DevParam P, const float* g_ref_row, 
 #define LSA_ICP_WG_PER_CU_SMALL 8
 #endif
 // (__launch_bounds__' second argument is waves per SIMD in HIP.)  The narrow instances: the LDS admits 26 x 6.1 KB workgroups of
-// one wave at 181 beams and 13 x 11.8 KB of two at 361 - 6.5 waves per SIMD either way, i.e. a budget of 7 (72 registers)
+// one wave at 181 beams, 18 x 8.8 KB of two at 361 and 13 x 11.9 KB of two at 541 (reference points in the global slot) -
+// 6.5 waves per SIMD or more, i.e. a budget of 7 (72 registers)
 __host__ __device__ constexpr int icp_wg_per_cu(int nc)
 {
-    return nc == 181 || nc == 361 ? 7 : (nc > 0 && nc <= 541) ? (LSA_ICP_WG_PER_CU_SMALL) : (LSA_ICP_WG_PER_CU);
+    return nc == 181 || nc == 361 || nc == 541 ? 7 : (nc > 0 && nc <= 541) ? (LSA_ICP_WG_PER_CU_SMALL) : (LSA_ICP_WG_PER_CU);
 }
 // NC > 0: the beam count as a compile-time constant (the sensors' usual sizes), so that the LDS
 // layout and the trip counts are immediates instead of scalar registers; NC = 0: any size.
