@@ -102,6 +102,51 @@ def test_scores_argmax_weights_resample(world):
     assert np.array_equal(d_new.cpu().numpy(), poses[par_g])
 
 
+@pytest.mark.parametrize("geom", [(37, 11, -3.2, 1.7, 0.07, 150, 230), (0, 0, 0.0, 0.0, 0.05, 64, 64), (500, 3, 12.5, -40.0, 0.1, 700, 90)])
+def test_scorer_map_geometries_and_poses_off_the_map(geom):
+    """The scorer's fixed-point cell index, its tiled table with the four-cell apron and the clamp of far-away beams
+    against the oracle's plain arithmetic: map origins, offsets and resolutions that are not the fixture's, poses inside,
+    on the edges (cells -1, 0, size - 2, size - 1: the reference's `(int)` truncation and its `>= size - 1` test), far
+    outside (every beam clamped) and with huge coordinates; both frames; beam counts that leave a ragged last trip."""
+    import torch
+    from laser_slam_amd import capi
+    from oracle_lib import likelihood_field, score_poses
+    cx, cy, offx, offy, res, sx, sy = geom
+    rng = np.random.default_rng(sx * 7 + sy)
+    prob = np.full((sx, sy), 0.1, np.float32)
+    prob[:, :2] = 0.9; prob[:, -2:] = 0.9; prob[:2, :] = 0.9; prob[-2:, :] = 0.9
+    prob[sx // 3:sx // 3 + 3, sy // 4:3 * sy // 4] = 0.95
+    prob += rng.uniform(0, 0.02, prob.shape).astype(np.float32)
+    ctx = capi.Context(capi.param_preset("LMS151"))
+    fld = capi.Field(ctx, sx, sy, cx, cy, offx, offy, res)
+    d_prob = torch.from_numpy(prob).cuda(); torch.cuda.synchronize()
+    fld.build(d_prob, 1.0, 0.3, 0.5); ctx.sync()
+    lik_o = likelihood_field(prob, res)
+    # world coordinates of the map: x in [(0 - cx) res + offx, (sx - cx) res + offx)
+    x0, x1 = (0 - cx) * res + offx, (sx - cx) * res + offx
+    y0, y1 = (0 - cy) * res + offy, (sy - cy) * res + offy
+    P = 3000
+    poses = np.stack([rng.uniform(x0, x1, P), rng.uniform(y0, y1, P), rng.uniform(-7, 7, P)], 1)
+    poses[:200, 0] = rng.choice([x0 - res, x0, x0 + res * 0.999, x1 - 2 * res, x1 - res, x1], 200) + rng.uniform(-1e-4, 1e-4, 200)
+    poses[200:400, 1] = rng.choice([y0 - res, y0, y1 - 2 * res, y1 - res, y1], 200) + rng.uniform(-1e-4, 1e-4, 200)
+    poses[400:500, :2] += rng.choice([-1, 1], (100, 2)) * rng.uniform(50, 5000, (100, 2))          # far outside
+    poses[500:520, :2] = rng.choice([-1, 1], (20, 2)) * 1e7                                           # huge
+    poses = poses.astype(np.float32)
+    d_p = torch.from_numpy(poses).cuda(); d_s = torch.zeros(P, device="cuda")
+    for n, decim in ((541, 3), (97, 1), (1081, 3), (8, 1)):
+        ang = np.linspace(-0.75 * np.pi, 0.75 * np.pi, n)
+        rr = rng.uniform(0.05, 0.3 * max(x1 - x0, y1 - y0), n)
+        scan_x = (rr * np.cos(ang)).astype(np.float32); scan_y = (rr * np.sin(ang)).astype(np.float32)
+        d_x, d_y = torch.from_numpy(scan_x).cuda(), torch.from_numpy(scan_y).cuda()
+        for std in (False, True):
+            torch.cuda.synchronize()
+            fld.score_poses(d_x, d_y, n, decim, d_p, P, d_s, std_frame=std); ctx.sync()
+            want = score_poses(lik_o, cx, cy, offx, offy, res, scan_x, scan_y, decim, poses, std_frame=std)
+            got = d_s.cpu().numpy()
+            assert np.allclose(got, want, rtol=1e-5, atol=2e-3), (n, std, np.abs(got - want).max(), int(np.argmax(np.abs(got - want))))
+    fld.close(); ctx.close()
+
+
 def test_standard_resampler(world):
     """Standard_resampler (SIRFlt.cpp:39-115, what SIR_scheme::update_resample() uses): one uniform per offspring,
     parents ascending as copy_resamples leaves them; device against oracle (the device sums the weights pairwise,
@@ -321,7 +366,7 @@ def _fused_case(world, P, seed):
     return n, d_x, d_y, poses, nrm_p, nrm_r
 
 
-@pytest.mark.parametrize("P", [1, 777, 20000, 300000])
+@pytest.mark.parametrize("P", [1, 777, 20000, 300000, 2500000])
 def test_fused_step_equals_call_by_call_step(world, P):
     """The fused step (lsa_pf_filter_*: four launches, one read-back) against the call-by-call entry points it replaces in
     the loop - lsa_pf_predict, lsa_score_poses, lsa_pose_argmax, lsa_pf_weights, the fixed-point resampling pieces,
