@@ -757,22 +757,29 @@ __global__ __launch_bounds__(256) void grid_binned_kernel(
 #endif
 }
 
-// computeProbsOfMap: prob = hit / (double) sum clipped to 1, unseen cells 0.3.
-// Counts are converted to float first (the reference stores them as float).
+// computeProbsOfMap: prob = hit / (double) sum clipped to 1, unseen cells 0.3 (PMap.cpp:119-136).
+// Counts are converted to float first (the reference stores them as float).  The reference divides in double and rounds the
+// quotient to float; for counts below 2^24 that is the correctly rounded FLOAT quotient (the exact quotient of two 24-bit
+// integers is either a float or at least 2^-49 away, relatively, from every midpoint between two floats - too far for the
+// 53-bit intermediate to land on one), which the build's IEEE float division gives at a third of the instructions.  Counts
+// of 2^24 and more (the reference's float counters stop there) take the double path.  One cell per lane and trip: the pass is
+// a pure stream (8 B read, 4 B written per cell; 4.2 TB/s cold, 8.7 TB/s from the Infinity Cache) - four cells per lane with
+// 16-byte accesses measured 20 % SLOWER here, cold and cached alike, at every grid size tried.
+__device__ __forceinline__ float grid_prob_cell(uint32_t hit, uint32_t sum)
+{
+    const float s = (float)sum, h = (float)hit;
+    if (!(s > 0)) return (float)0.3;
+    float p;
+    if (__builtin_expect((hit | sum) >> 24, 0)) p = (float)((double)h / (double)s);
+    else p = h / s;
+    return (double)p > 1.0 ? 1.0f : p;
+}
+
 __global__ __launch_bounds__(256) void grid_prob_kernel(
     size_t cells, const uint32_t* __restrict__ hit, const uint32_t* __restrict__ sum, float* __restrict__ prob)
 {
-    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (size_t)gridDim.x * blockDim.x) {
-        const float s = (float)sum[c], h = (float)hit[c];
-        float p;
-        if (s > 0) {
-            p = (float)((double)h / (double)s);
-            if ((double)p > 1.0) p = 1.0f;
-        } else {
-            p = (float)0.3;
-        }
-        prob[c] = p;
-    }
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (size_t)gridDim.x * blockDim.x)
+        prob[c] = grid_prob_cell(hit[c], sum[c]);
 }
 
 // u32 count layer -> float layer (download in the reference's storage type)
