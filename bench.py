@@ -483,12 +483,11 @@ def secondary_matchers(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, which
                                               {"note": "double-precision point-to-line ICP (parity unpinned: CSM absent); "
                                                        "instruction-issue and latency bound, DESIGN.md 4.7"})}
     S = raw.shape[0]
-    Sp = 16384                                              # batched preprocessing (one lane per scan from 4096 scans on)
-    big = np.tile(raw, ((Sp + S - 1) // S, 1))[:Sp]
-    r2 = torch.from_numpy(big).cuda(); b2 = torch.zeros(Sp, n, dtype=torch.uint8, device="cuda"); s2 = torch.zeros(Sp, n, dtype=torch.int16, device="cuda")
+    Sp = 262144                                             # batched preprocessing (one lane per scan from 4096 scans on)
+    r2 = torch.from_numpy(raw).cuda().repeat((Sp + S - 1) // S, 1)[:Sp].contiguous(); b2 = torch.zeros(Sp, n, dtype=torch.uint8, device="cuda"); s2 = torch.zeros(Sp, n, dtype=torch.int16, device="cuda")
     ms = timed(torch, lambda: ctx.preprocess_batch(Sp, r2, b2, s2), reps=3)
     res["preprocess"] = {"value": Sp / (ms * 1e-3), "unit": "scans/s", "scans": Sp,
-                         "roofline": hbm_roofline("preprocess_lanes_kernel", Sp * n * 12.0, ms, Sp,
+                         "roofline": hbm_roofline("preprocess_tiles_kernel", Sp * n * 12.0, ms, Sp,
                                                   "12 B per beam: ranges read and written, flags read and written, segments written")}
     return res
 

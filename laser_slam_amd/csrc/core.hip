@@ -454,10 +454,13 @@ int lsa_preprocess_stages_batch(lsa_ctx* c, int S, float* d_r, uint8_t* d_bad, u
     if (S <= 0) return LSA_OK;
     HIP_TRY(hipSetDevice(c->device));
     const char* pre_env = getenv("LSA_PREPROCESS_PATH");
-    const bool lanes = pre_env ? !strcmp(pre_env, "lanes") : S >= 4096;      // (measured crossover: a small batch has too few waves that way)
-    if (stages == 7 && lanes && c->p.points >= 3) {
-        // batches: one lane per scan (the recurrences stay sequential, 64 scans share a wave)
-        hipLaunchKernelGGL(lsa::preprocess_lanes_kernel, dim3((S + 63) / 64), dim3(64), 0, c->stream, dev_param(c), S, d_r, d_bad, d_seg);
+    const bool lanes = pre_env ? (!strcmp(pre_env, "lanes") || !strcmp(pre_env, "tiles")) : S >= 4096;      // (measured crossover: a small batch has too few waves that way)
+    if (stages == 7 && lanes && c->p.points >= 8) {
+        // batches: one lane per scan (the recurrences stay sequential, 64 scans share a wave), rows moved through LDS tiles
+        if (pre_env && !strcmp(pre_env, "lanes"))
+            hipLaunchKernelGGL(lsa::preprocess_lanes_kernel, dim3((S + 63) / 64), dim3(64), 0, c->stream, dev_param(c), S, d_r, d_bad, d_seg);
+        else
+            hipLaunchKernelGGL(lsa::preprocess_tiles_kernel, dim3((S + 63) / 64), dim3(64), 0, c->stream, dev_param(c), S, d_r, d_bad, d_seg);
         HIP_TRY(hipGetLastError());
         return LSA_OK;
     }

@@ -485,4 +485,145 @@ __global__ __launch_bounds__(64) void preprocess_lanes_kernel(
     seg[N - 1] = (uint16_t)sg1;
 }
 
+// The same three stages with the global traffic coalesced (round 3).  preprocess_lanes_kernel lets every lane walk its own
+// row of the arrays: a wave touches 64 x 3 different lines per step, and from a few ten thousand scans on the caches no
+// longer hold them between a lane's consecutive accesses - 23 M scans/s at 16 384 scans, 12 M at 2^20 (2 % of the HBM
+// rate for 12 bytes per beam).  Here a wave still owns 64 scans, one per lane, with the recurrences' state in registers,
+// but it moves the rows through LDS in tiles of PRE_C beams: 64-byte row pieces loaded and stored by consecutive lanes, the
+// tile read and written by the lanes at conflict-free strides.  A beam is processed once the raw readings three beams
+// ahead of it are there (the median's look-ahead) and a segment id is final two beams behind (the break handling), so the
+// lanes work on beams [k C - 3, k C + C - 3) while tile k is the newest, and tile k - 1 goes back to memory afterwards:
+// two tiles in flight.  Identical arithmetic, order and results.
+#ifndef LSA_PRE_TILE
+#define LSA_PRE_TILE 16
+#endif
+constexpr int PRE_C = LSA_PRE_TILE;
+constexpr int PRE_RS = PRE_C + 1;            // floats per tile row (odd: lane l starts in bank 17 l mod 64)
+constexpr int PRE_BS = PRE_C + 4;            // bytes per tile row of the flags (5 words: 5 l mod 64)
+constexpr int PRE_SS = PRE_C + 2;            // u16 per tile row of the segment ids (9 words: 9 l mod 64)
+constexpr int PRE_TILE_BYTES = 64 * (PRE_RS * 4 + PRE_BS + PRE_SS * 2);
+
+__global__ __launch_bounds__(64) void preprocess_tiles_kernel(
+    DevParam P, int S, float* __restrict__ g_r, uint8_t* __restrict__ g_bad, uint16_t* __restrict__ g_seg)
+{
+    __shared__ __attribute__((aligned(16))) char tiles[2 * PRE_TILE_BYTES];
+    const int N = P.n, lane = (int)threadIdx.x;
+    const int s0 = blockIdx.x * 64;
+    const int rows = S - s0 < 64 ? S - s0 : 64;                 // scans of this wave
+    const bool mine = lane < rows;
+    // (this wave's 64 rows: a uniform base and 32-bit offsets below 64 N)
+    float* const w_r = g_r + (size_t)s0 * N;
+    uint8_t* const w_bad = g_bad + (size_t)s0 * N;
+    uint16_t* const w_seg = g_seg + (size_t)s0 * N;
+    auto tr = [&](int t) { return (float*)(tiles + t * PRE_TILE_BYTES); };
+    auto tb = [&](int t) { return (uint8_t*)(tiles + t * PRE_TILE_BYTES + 64 * PRE_RS * 4); };
+    auto ts = [&](int t) { return (uint16_t*)(tiles + t * PRE_TILE_BYTES + 64 * (PRE_RS * 4 + PRE_BS)); };
+    // beam i of this lane's scan inside the two tiles
+    auto R = [&](int i) -> float& { return tr((i / PRE_C) & 1)[lane * PRE_RS + (i % PRE_C)]; };
+    auto Bd = [&](int i) -> uint8_t& { return tb((i / PRE_C) & 1)[lane * PRE_BS + (i % PRE_C)]; };
+    auto Sg = [&](int i) -> uint16_t& { return ts((i / PRE_C) & 1)[lane * PRE_SS + (i % PRE_C)]; };
+    const float lim = LSA_SEG_MAX_DIST, far = (float)P.max_range;
+    float f2 = 0, f1 = 0, a0 = 0, a1 = 0, a2 = 0;
+    float r1 = 0, r2 = 0;
+    int b1 = 0, b2 = 0, sg1 = 0, sg2 = 0, id = 1, run = 0;
+    bool closed = false;
+    const int K = (N + PRE_C - 1) / PRE_C;
+    // a tile's 64 rows x PRE_C beams move as row pieces by consecutive lanes (piece j of a lane: element j 64 + lane of
+    // the tile); the loads are unconditional on clamped addresses, so that all 2 PRE_C of them are in flight together
+    float nr[PRE_C];
+    uint8_t nb[PRE_C];
+    auto fetch = [&](int k) {
+        const int c0 = k * PRE_C;
+        #pragma unroll
+        for (int j = 0; j < PRE_C; ++j) {
+            const int idx = j * 64 + lane;
+            int row = idx / PRE_C, col = c0 + idx % PRE_C;
+            row = row < rows ? row : rows - 1;
+            col = col < N ? col : N - 1;
+            const unsigned o = (unsigned)(row * N + col);
+            nr[j] = w_r[o];
+            nb[j] = w_bad[o];
+        }
+    };
+    auto stash = [&](int t) {
+        #pragma unroll
+        for (int j = 0; j < PRE_C; ++j) {
+            const int idx = j * 64 + lane, row = idx / PRE_C, col = idx % PRE_C;
+            tr(t)[row * PRE_RS + col] = nr[j];
+            tb(t)[row * PRE_BS + col] = nb[j];
+        }
+    };
+    fetch(0);
+    stash(0);
+    for (int k = 0; k <= K; ++k) {
+        if (k + 1 < K) fetch(k + 1);                             // tile k + 1 on its way while tile k is worked on
+        __builtin_amdgcn_wave_barrier();                         // (one wave: its LDS accesses execute in program order)
+        if (mine) {
+            if (k == 0) { a0 = R(0); a1 = R(1); a2 = R(2); }
+            const int i_lo = k * PRE_C - 3 < 0 ? 0 : k * PRE_C - 3;
+            const int i_hi = k < K ? (k * PRE_C + PRE_C - 3 < N ? k * PRE_C + PRE_C - 3 : N) : N;      // (the step behind the last tile finishes the scan)
+            for (int i = i_lo; i < i_hi; ++i) {
+                // --- median of the live window r[clamp(i-2 .. i+2)] (:1610-1639): left of i already filtered
+                float w[5];
+                w[0] = i >= 2 ? f2 : (i == 1 ? f1 : a0);
+                w[1] = i >= 1 ? f1 : a0;
+                w[2] = a0;
+                w[3] = i + 1 <= N - 1 ? a1 : a0;
+                w[4] = i + 2 <= N - 1 ? a2 : (i + 1 <= N - 1 ? a1 : a0);
+                #pragma unroll
+                for (int hi = 4; hi > 0; --hi)
+                    #pragma unroll
+                    for (int q = 0; q < hi; ++q)
+                        if (w[q] > w[q + 1]) { const float sw = w[q]; w[q] = w[q + 1]; w[q + 1] = sw; }
+                const float ri = w[2];
+                R(i) = ri;
+                f2 = f1; f1 = ri;
+                a0 = a1; a1 = a2; a2 = i + 3 < N ? R(i + 3) : 0.0f;
+                // --- far points (:1583-1590)
+                const int bi = (int)Bd(i) | (ri > far ? 1 : 0);
+                Bd(i) = (uint8_t)bi;
+                // --- segmentation (:1495-1576), finalising seg[i-2]
+                int sgi;
+                if (i == 0) { sgi = 0; }
+                else if (i == 1) {
+                    if (fabsf_(r1 - ri) < lim) { sg1 = id; sgi = id; run = 2; } else { sg1 = 0; sgi = id; run = 1; }
+                } else {
+                    bool brk = false;
+                    sgi = 0;
+                    const float ex = (float)((double)ri - (2.0 * (double)r1 - (double)r2));
+                    if (bi) brk = true;
+                    else if (fabsf_(ri - r1) < lim || (sg1 == sg2 && fabsf_(ex) < lim)) { run++; sgi = id; }
+                    else brk = true;
+                    if (brk) {
+                        if (run == 1) {
+                            if (sg2 == 0 && bi == 0 && b1 == 0 && b2 == 0 && fabsf_(ex) < lim) { sgi = id; sg1 = id; sg2 = id; run = 3; }
+                            else { sg1 = 0; sgi = id; run = 1; }
+                        } else { id++; sgi = id; run = 1; }
+                    }
+                    Sg(i - 2) = (uint16_t)sg2;
+                }
+                sg2 = sg1; sg1 = sgi;
+                r2 = r1; r1 = ri; b2 = b1; b1 = bi;
+            }
+            // the scan's end: both open ids (beam N - 2 lies in tile k - 1 or later, which is still here)
+            if (i_hi == N && !closed) { Sg(N - 2) = (uint16_t)sg2; Sg(N - 1) = (uint16_t)sg1; closed = true; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (k >= 1) {                                            // tile k - 1 out (complete: beams and segment ids up to its end are final)
+            const int c0 = (k - 1) * PRE_C, t = (k - 1) & 1;
+            #pragma unroll
+            for (int j = 0; j < PRE_C; ++j) {
+                const int idx = j * 64 + lane, row = idx / PRE_C, col = idx % PRE_C;
+                if (row < rows && c0 + col < N) {
+                    const unsigned o = (unsigned)(row * N + c0 + col);
+                    w_r[o] = tr(t)[row * PRE_RS + col];
+                    w_bad[o] = tb(t)[row * PRE_BS + col];
+                    w_seg[o] = ts(t)[row * PRE_SS + col];
+                }
+            }
+        }
+        if (k + 1 < K) stash((k + 1) & 1);                       // ... and into the slot tile k - 1 has just left
+    }
+}
+
 } // namespace lsa

@@ -74,11 +74,12 @@ def test_tables_match_reference(name, torch_mod):
     ctx.close()
 
 
-@pytest.mark.parametrize("path", ["wave", "lanes"])
+@pytest.mark.parametrize("path", ["wave", "lanes", "tiles"])
 @pytest.mark.parametrize("name", list(SETS))
 def test_preprocess(name, path, torch_mod, monkeypatch):
-    """pm_preprocessScan against the golden vectors through both kernels: one wave per scan (small batches, the host
-    entry point) and one lane per scan (batches of 4096 scans and more; forced here by LSA_PREPROCESS_PATH)."""
+    """pm_preprocessScan against the golden vectors through the three kernels: one wave per scan (small batches, the host
+    entry point), one lane per scan through LDS tiles (batches of 4096 scans and more; forced here by
+    LSA_PREPROCESS_PATH) and its untiled predecessor."""
     monkeypatch.setenv("LSA_PREPROCESS_PATH", path)
     torch = torch_mod
     g = load(name)
