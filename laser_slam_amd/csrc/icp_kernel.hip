@@ -43,7 +43,10 @@ __device__ unsigned long long lsa_phase_cycles[16];
 #define SUBSTAMP(slot, dep) do { if (tid == 0) { float d_ = (dep); asm volatile("" :: "v"(d_)); unsigned long long t_ = __builtin_readcyclecounter(); ph[slot] += t_ - t_sub; t_sub = t_; } } while (0)
 #define STAMP_ARGS , unsigned long long* ph, unsigned long long& t_sub
 #define STAMP_PASS , ph, t_sub
+// statistics next to the clocks: slot 11 = candidates, slot 12 = steps << 40 | entering records (tools/phase_shares.py)
+#define STAT(slot, v) do { if (tid == 0) ph[slot] += (unsigned long long)(v); } while (0)
 #else
+#define STAT(slot, v) do {} while (0)
 #define STAMP(slot) do {} while (0)
 #define SUBSTAMP(slot, dep) do {} while (0)
 #define STAMP_ARGS
@@ -547,6 +550,7 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt STAMP_ARGS)
         int q;
         const int cpos = block_rank<T>(cand, q, wcnt, phase);
         SUBSTAMP(14, (float)cpos);
+        STAT(11, q); STAT(12, 1ull << 40);
         if (q == 0) { if (valid) A[t - k] = rec; continue; }
         if (cand) cd[cpos] = d;
         if (tid < 4 && q + tid < ((q + 3) & ~3)) ((int*)cd)[q + tid] = -1;      // pad the row (bit pattern -1: see gt_bit)
@@ -568,6 +572,7 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt STAMP_ARGS)
         const int epos = block_rank<T>(ent, E, wcnt, phase);
         SUBSTAMP(8, (float)epos);
         if (valid && !ent) A[t - k] = rec;           // passes straight through
+        STAT(12, E);
         if (E == 0) continue;
         if (ent) ce[epos] = d;
         if (tid < 4 && E + tid < ((E + 3) & ~3)) ((int*)ce)[E + tid] = -1;

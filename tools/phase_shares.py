@@ -44,3 +44,6 @@ sub = np.array(list(buf)[8:16], np.float64) / B / mean_it
 print("trim sub-phases (per iteration): first-k sort=%.0f | rank cand=%.0f bsearch=%.0f count g2+rank ent=%.0f count h/push+writes=%.0f emit=%.0f"
       % (sub[5], sub[6], sub[7], sub[0], sub[1], sub[2]))
 print("per-iteration:", " ".join("%s=%.0f" % (nm.split()[0], x / B / mean_it) for nm, x in zip(names, v)))
+st = list(buf)
+steps = (st[12] >> 40) / B / mean_it
+print("trim steps per iteration %.2f, candidates per step %.1f, entering per step %.1f" % (steps, st[11] / max(st[12] >> 40, 1), (st[12] & ((1 << 40) - 1)) / max(st[12] >> 40, 1)))
