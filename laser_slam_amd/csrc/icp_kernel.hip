@@ -490,6 +490,37 @@ __device__ __forceinline__ int count_ge_from(const float* row, int cnt, float d,
     return c;
 }
 
+// #{from <= p < to : row[p] > d} for d >= 0 (rows are padded to a multiple of 4 with the bit pattern -1)
+__device__ __forceinline__ int count_gt_range(const float* row, int from, int to, float d)
+{
+    if (from >= to) return 0;
+    const int4* r4 = (const int4*)row;
+    const int t1 = (int)f2u(d);
+    int qd = from >> 2, c = 0;
+    const int qe = to >> 2;                              // quads [.., qe) lie entirely below `to`
+    if (from & 3) {                                      // the quad that straddles `from` (and maybe `to`)
+        const int4 v = r4[qd];
+        const int p = qd * 4;
+        c += (p + 1 >= from && p + 1 < to && v.y > t1) ? 1 : 0;
+        c += (p + 2 >= from && p + 2 < to && v.z > t1) ? 1 : 0;
+        c += (p + 3 >= from && p + 3 < to && v.w > t1) ? 1 : 0;
+        ++qd;
+    }
+    #pragma unroll 4
+    for (; qd < qe; ++qd) {
+        const int4 v = r4[qd];
+        c += gt_bit(v.x, t1) + gt_bit(v.y, t1) + gt_bit(v.z, t1) + gt_bit(v.w, t1);
+    }
+    if (qd == qe && (to & 3)) {                          // the quad that straddles `to`
+        const int4 v = r4[qd];
+        const int p = qd * 4;
+        c += (p     < to && v.x > t1) ? 1 : 0;
+        c += (p + 1 < to && v.y > t1) ? 1 : 0;
+        c += (p + 2 < to && v.z > t1) ? 1 : 0;
+    }
+    return c;
+}
+
 template <int T>
 __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt STAMP_ARGS)
 {
@@ -565,8 +596,26 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt STAMP_ARGS)
         }
         __syncthreads();
         SUBSTAMP(15, (float)g1);
-        // earlier records of this step that are strictly greater (later ones never count)
-        int g2 = cand ? count_split(cd, cpos, d, cpos) : 0;
+        // earlier records of this step that are strictly greater (later ones never count): row c of the candidates is
+        // [0, c).  Counted by thread c, not by the candidate's own thread (whose wave would run to the longest row
+        // among the few candidates it holds, the other lanes idle), and the T - q threads without a row take the second
+        // halves of the longest T - q rows: every wave is full and none runs further than q / 2.
+        int* part = (int*)ce;                            // [0, T): first parts  [T, 2 T): second halves (ce | se, both free)
+        {
+            const int spare = T - q, first_split = q - spare < 0 ? 0 : q - spare;      // rows >= first_split are halved
+            const int row = tid < q ? tid : first_split + (tid - q);
+            const bool second = tid >= q;
+            const int mid = row >= first_split ? row >> 1 : row;
+            const int from = second ? mid : 0, to = second ? row : mid;
+            const float dr = cd[row < q ? row : 0];
+            part[tid] = row < q ? count_gt_range(cd, from, to, dr) : 0;
+        }
+        __syncthreads();
+        int g2 = 0;
+        if (cand) {
+            const int spare = T - q, first_split = q - spare < 0 ? 0 : q - spare;
+            g2 = part[cpos] + (cpos >= first_split ? part[q + (cpos - first_split)] : 0);
+        }
         const bool ent = cand && (g1 + g2 < k);
         int E;
         const int epos = block_rank<T>(ent, E, wcnt, phase);
@@ -582,7 +631,14 @@ __device__ void trim_worst(const Lds& L, int n, int k, int* wcnt STAMP_ARGS)
         // Every earlier candidate that is strictly greater than an entering record has entered
         // itself (its count of greater predecessors is no larger), so the entering records ahead
         // of this one number g2 plus the later ones that are greater or equal.
-        int h = ent ? g2 + count_ge_from(ce, E, d, epos + 1) : 0;
+        // The later ones are counted by the first E threads, one entering record each in arrival order (the rows
+        // then fill whole waves: 34 quads of loads per step instead of 62 with every wave running to the longest
+        // row among the entering records it happens to hold), and handed back through the candidates' row, which
+        // is dead by now.
+        int* later = (int*)cd;
+        if (tid < E) later[tid] = count_ge_from(ce, E, ce[tid], tid + 1);
+        __syncthreads();
+        int h = ent ? g2 + later[epos] : 0;
         if (ent) se[h] = d;
         __syncthreads();
         const int top = k + E - 1;
