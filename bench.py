@@ -515,7 +515,7 @@ def p2p_entry(torch, capi, ctx, prob, count, what):
             "mean_iterations": float(out[:, 5].mean().item()), "mean_goodness": float(out[:, 3].mean().item()),
             "roofline": valu_roofline("p2p_icp_kernel<%d>" % (64 if pts / 2 <= 200 else 128 if pts / 2 <= 512 else 256), count / (ms * 1e-3), ms, count, pts * 8.0 + 24 + 128,
                                       {"note": "CICPWarpper's point-to-point ICP (MRPT icpClassic restated, parity unpinned): "
-                                               "sorted-slab nearest neighbour in LDS, closed-form 2D fit in double; instruction bound"})}
+                                               "nearest neighbour in a slab of the first map sorted along a per-problem oblique axis (LDS), closed-form 2D fit in double; instruction bound"})}
 
 
 def secondary_logs(torch, capi, pairs=1 << 17):
