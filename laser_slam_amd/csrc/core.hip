@@ -1334,13 +1334,16 @@ int lsa_pf_roughen(lsa_ctx* c, int n, double K, const float* d_normals, float* d
 }
 
 // point-to-point ICP launch: workgroup width and LDS by the largest cloud of the launch
-static void p2p_launch(lsa_ctx* c, int max_points, const lsa::P2PParam& P, int B, const float* rx, const float* ry, const int* roff,
+static void p2p_launch(lsa_ctx* c, int max_points, const lsa::P2PParam& P_, int B, const float* rx, const float* ry, const int* roff,
                        const float* cx, const float* cy, const int* coff, const double* init, unsigned long long* owner, int* match,
                        double* out, int n_cur_shared)
 {
     const int cap = lsa::p2p_cap_for(max_points);
     const int T = lsa::p2p_threads(max_points);
     const size_t lds = (size_t)lsa::p2p_lds_bytes(cap);
+    lsa::P2PParam P = P_;
+    const char* ax = getenv("LSA_P2P_AXIS");                 // test hook: the pairs must not depend on the sort axis
+    P.axis = ax && *ax ? atoi(ax) : -1;
 #define LSA_P2P_GO(TT) hipLaunchKernelGGL((lsa::p2p_icp_kernel<TT>), dim3(B), dim3(TT), lds, c->stream, P, B, rx, ry, roff, cx, cy, coff, init, \
                                           owner, match, out, n_cur_shared, cap)
     if (T == 64) LSA_P2P_GO(64); else if (T == 128) LSA_P2P_GO(128); else LSA_P2P_GO(256);

@@ -39,6 +39,7 @@ namespace lsa {
 struct P2PParam {
     int max_iter;
     float thr_dist, thr_ang, alfa, smallest_thr;
+    int axis;       // sort axis 0 .. P2P_AXES-1, or -1: chosen per problem (the launch sets it: LSA_P2P_AXIS, a test hook)
 };
 
 // the sort axes a problem chooses from (below)
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(T) void p2p_icp_kernel(
             int npad = 1;
             while (npad < n1) npad <<= 1;
             __syncthreads();
-            if (n1 >= 128) {
+            if (O.axis >= 0) { ac = P2P_AXIS[2 * (O.axis % P2P_AXES)]; as = P2P_AXIS[2 * (O.axis % P2P_AXES) + 1]; }
+            else if (n1 >= 128) {
                 // The axis: a search looks at the points of a slab, about (density along the axis) x (its bound) of them, and
                 // the queries lie where the points lie - the cost of an axis goes with the integral of its squared density.
                 // P2P_BINS bins over the extent of every direction's projections; the smallest sum of squared counts per

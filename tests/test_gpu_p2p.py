@@ -175,3 +175,35 @@ def test_batch_equals_single_problems(ctx):
         want = capi.p2p_icp_host(ctx, ref[:, 0].copy(), ref[:, 1].copy(), cur[:, 0].copy(), cur[:, 1].copy(), ini)
         assert np.array_equal(got[k, :13], want[:13]), (k, got[k, :7], want[:7])
     assert got[4, 3] == 0 and got[4, 6] == 0
+
+
+def test_pairs_do_not_depend_on_the_sort_axis(ctx, monkeypatch):
+    """The nearest-neighbour search scans the first map sorted along an axis the kernel picks per problem among eight
+    directions.  The search is exact on any of them: every forced axis (LSA_P2P_AXIS, a test hook read at launch) must give
+    the bits the automatic choice gives - node clouds of map cells (columns of equal x), scans, ragged synthetic clouds."""
+    from laser_slam_amd import capi
+    rng = np.random.default_rng(21)
+    probs = []
+    rows = np.loadtxt(os.path.join(GOLDEN, "zhicp", "matched_nodes.log"))
+    for n1, n2, _, px, py, pth in rows[:3]:
+        try:
+            probs.append((cloud(int(n1)), cloud(int(n2)), (px, py, pth)))
+        except OSError:
+            pass
+    for k in range(4):
+        n_ref, n_cur = int(rng.integers(130, 900)), int(rng.integers(130, 900))
+        t = np.sort(rng.uniform(0, 8, n_ref)); u = np.sort(rng.uniform(0, 8, n_cur))
+        wall = lambda v: np.stack([np.where(v < 4, v, 4.0), np.where(v < 4, 0.02 * np.sin(9 * v), v - 4.0)], 1)      # a corner: one wall along x, one along y
+        th, tx, ty = rng.uniform(-0.06, 0.06), rng.uniform(-0.15, 0.15), rng.uniform(-0.15, 0.15)
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        ref = wall(t).astype(np.float32); cur = ((wall(u) - [tx, ty]) @ R).astype(np.float32)
+        probs.append(((ref[:, 0].copy(), ref[:, 1].copy()), (cur[:, 0].copy(), cur[:, 1].copy()), (0.0, 0.0, 0.0)))
+    assert len(probs) >= 5
+    monkeypatch.delenv("LSA_P2P_AXIS", raising=False)
+    auto = [capi.p2p_icp_host(ctx, r[0], r[1], c[0], c[1], ini) for r, c, ini in probs]
+    assert any(a[6] > 50 for a in auto)
+    for axis in range(8):
+        monkeypatch.setenv("LSA_P2P_AXIS", str(axis))
+        for (r, c, ini), want in zip(probs, auto):
+            got = capi.p2p_icp_host(ctx, r[0], r[1], c[0], c[1], ini)
+            assert np.array_equal(got[:13], want[:13]), (axis, got[:7], want[:7])
