@@ -45,7 +45,21 @@ __device__ unsigned long long lsa_phase_cycles[16];
 #define STAMP_PASS , ph, t_sub
 // statistics next to the clocks: slot 11 = candidates, slot 12 = steps << 40 | entering records (tools/phase_shares.py)
 #define STAT(slot, v) do { if (tid == 0) ph[slot] += (unsigned long long)(v); } while (0)
+// -DLSA_NN_STATS on top: steps of the search's general path, by lanes and by waves (global slots 13 / 14), lanes on it (15)
+#ifdef LSA_NN_STATS
+#undef SUBSTAMP
+#undef STAT
+#define SUBSTAMP(slot, dep) do {} while (0)
+#define STAT(slot, v) do {} while (0)
+#define NN_STAT_LANE(slot) atomicAdd(&lsa_phase_cycles[slot], 1ull)
+#define NN_STAT_WAVE(slot) do { const unsigned long long m_ = __ballot(1); if (lane_id() == __builtin_ctzll(m_)) atomicAdd(&lsa_phase_cycles[slot], 1ull); } while (0)
 #else
+#define NN_STAT_LANE(slot) do {} while (0)
+#define NN_STAT_WAVE(slot) do {} while (0)
+#endif
+#else
+#define NN_STAT_LANE(slot) do {} while (0)
+#define NN_STAT_WAVE(slot) do {} while (0)
 #define STAT(slot, v) do {} while (0)
 #define STAMP(slot) do {} while (0)
 #define SUBSTAMP(slot, dep) do {} while (0)
@@ -370,8 +384,8 @@ __device__ __forceinline__ void nn_general(const Lds& L, float T, NnBeam& b)
             nn_range(b, T, im, done, s, e);
             int j = s;
             const int eq = e + 3 < b.hi - 1 ? e + 3 : b.hi - 1;         // quads may run past e inside the window
-            for (; j + 3 <= eq && j <= e; j += 4) nn_eval4(L, b.p, j, b.best, b.best_j);
-            for (; j <= e; ++j) nn_eval(L, b.p, j, b.best, b.best_j);
+            for (; j + 3 <= eq && j <= e; j += 4) { NN_STAT_LANE(13); NN_STAT_WAVE(14); nn_eval4(L, b.p, j, b.best, b.best_j); }
+            for (; j <= e; ++j) { NN_STAT_LANE(13); NN_STAT_WAVE(14); nn_eval(L, b.p, j, b.best, b.best_j); }
         }
     }
 }
@@ -830,7 +844,12 @@ __global__ __launch_bounds__(icp_threads(NC), icp_wg_per_cu(NC)) void icp_kernel
                     NnBeam b0;
                     nn_plan(P, L, i0, lv0, p0, jp0, T, inv_dfi, b0);
                     nn_flat(L, N, b0);
-                    if (__ballot(b0.live && !b0.flat)) nn_general(L, T, b0);
+                    if (__ballot(b0.live && !b0.flat)) {
+#if defined(LSA_PHASE_STAMPS) && defined(LSA_NN_STATS)
+                        { const unsigned long long m_ = __ballot(b0.live && !b0.flat); if (lane == 0) { atomicAdd(&lsa_phase_cycles[15], (unsigned long long)__popcll(m_)); atomicAdd(&lsa_phase_cycles[12], 1ull); } }
+#endif
+                        nn_general(L, T, b0);
+                    }
                     const int m0 = nn_store(L, N, i0, b0);
                     {
                         const uint32_t nv = (uint32_t)(m0 + 1) & 0xffffu;
