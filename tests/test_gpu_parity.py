@@ -99,6 +99,36 @@ def test_preprocess(name, path, torch_mod, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("points,scans", [(1081, 4999), (361, 777), (181, 64 * 9 + 1), (97, 130), (8, 70)])
+def test_preprocess_paths_agree_on_ragged_batches(points, scans, torch_mod, monkeypatch):
+    """The three preprocessing kernels on batches that are not a multiple of a wave's 64 scans, on five sensor sizes (the
+    tiled kernel moves 16-beam tiles: 97 and 8 beams end inside a tile), with spikes, far readings and flagged beams: the
+    lane-per-scan kernels must return the bits of the wave-per-scan kernel, which the golden vectors pin."""
+    torch = torch_mod
+    from laser_slam_amd import capi, synth
+    rng = np.random.default_rng(points)
+    par = dict(synth.SYN1081, points=points, window=min(synth.SYN1081["window"], (points - 1) // 2))
+    ctx = capi.Context(capi.param_make(**par), 0)
+    base = (300.0 + 200.0 * np.sin(np.arange(points) * 0.05)[None, :] + rng.normal(0, 2.0, (scans, points))).astype(np.float32)
+    base += rng.normal(0, 40.0, base.shape).astype(np.float32) * (rng.random(base.shape) < 0.05)
+    base[rng.random(base.shape) < 0.01] = 9000.0
+    flags = (rng.random(base.shape) < 0.03).astype(np.uint8)
+    outs = {}
+    for path in ("wave", "lanes", "tiles"):
+        monkeypatch.setenv("LSA_PREPROCESS_PATH", path)
+        d_r = dev(torch, base, np.float32); d_bad = dev(torch, flags, np.uint8)
+        d_seg = torch.zeros(base.shape, dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        ctx.preprocess_batch(scans, d_r, d_bad, d_seg)
+        ctx.sync()
+        outs[path] = (d_r.cpu().numpy().view(np.uint32), d_bad.cpu().numpy(), d_seg.cpu().numpy())
+    assert outs["wave"][2].max() > 1 and outs["wave"][1].sum() > flags.sum()
+    for path in ("lanes", "tiles"):
+        for a, b in zip(outs["wave"], outs[path]):
+            assert np.array_equal(a, b), path
+    ctx.close()
+
+
 @pytest.mark.parametrize("name", list(SETS))
 def test_scan_project(name, torch_mod):
     torch = torch_mod
