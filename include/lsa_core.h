@@ -329,6 +329,9 @@ int lsa_plicp_host(lsa_ctx* c, const float* h_ref_r, const float* h_cur_r, const
  * tcp_slam/clientFrontend.cpp:282): d_cov9 [B][9] = row-major 3x3 over (x [m], y [m], theta [rad]) =
  * sigma^2 H^-1 (A1 A1^T + A2 A2^T) H^-1 (A. Censi, "An accurate closed-form estimate of ICP's covariance", ICRA 2007)
  * over the final correspondences; sigma = sm_params.sigma (0.04 m in the reference, :104).  A failed pair gets zeros.
+ * This is the mathematically consistent form of the publication (the d2J/dtheta drho_j1 term carries the factor 2 on both
+ * of its parts; finite differences of an independent J confirm it, tests/test_oracle_plicp.py).  CSM is not in the
+ * reference tree: whether its released icp_covariance.c forms that term the same way is NOT pinned.
  * d_cov9 / h_cov9 NULL = lsa_plicp_batch / lsa_plicp_host. */
 int lsa_plicp_batch_cov(lsa_ctx* c, int n_pairs, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
                         const lsa_plicp_options* opt, double sigma, double* d_out8, double* d_cov9);
