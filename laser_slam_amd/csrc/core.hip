@@ -454,7 +454,10 @@ int lsa_preprocess_stages_batch(lsa_ctx* c, int S, float* d_r, uint8_t* d_bad, u
     if (S <= 0) return LSA_OK;
     HIP_TRY(hipSetDevice(c->device));
     const char* pre_env = getenv("LSA_PREPROCESS_PATH");
-    const bool lanes = pre_env ? (!strcmp(pre_env, "lanes") || !strcmp(pre_env, "tiles")) : S >= 4096;      // (measured crossover: a small batch has too few waves that way)
+    // (measured crossover: one lane per scan needs 1.4 k instructions per scan where one wave per scan needs 4 k, but below
+    //  some 65 536 scans it has too few waves: 6.6 / 26 / 94 / 130 M scans/s at 4 096 / 16 384 / 65 536 / 262 144 scans against
+    //  72 / 100 / 97 / 102 M)
+    const bool lanes = pre_env ? (!strcmp(pre_env, "lanes") || !strcmp(pre_env, "tiles")) : S >= 65536;
     if (stages == 7 && lanes && c->p.points >= 8) {
         // batches: one lane per scan (the recurrences stay sequential, 64 scans share a wave), rows moved through LDS tiles
         if (pre_env && !strcmp(pre_env, "lanes"))
@@ -464,8 +467,14 @@ int lsa_preprocess_stages_batch(lsa_ctx* c, int S, float* d_r, uint8_t* d_bad, u
         HIP_TRY(hipGetLastError());
         return LSA_OK;
     }
-    hipLaunchKernelGGL(lsa::preprocess_kernel, dim3(S), dim3(64), pre_lds(c->p.points), c->stream,
-                       dev_param(c), S, d_r, d_bad, d_seg, stages);
+    // one wave per scan: the whole wave on the scan (sweeps to the median filter's fixed point, a prefix scan of the
+    // segmentation's state maps), or - LSA_PREPROCESS_PATH=walk - lane 0 walking it the literal way
+    if (pre_env && !strcmp(pre_env, "walk"))
+        hipLaunchKernelGGL(lsa::preprocess_kernel, dim3(S), dim3(64), pre_lds(c->p.points), c->stream,
+                           dev_param(c), S, d_r, d_bad, d_seg, stages);
+    else
+        hipLaunchKernelGGL(lsa::preprocess_scan_kernel, dim3(S), dim3(64), pre_lds(c->p.points), c->stream,
+                           dev_param(c), S, d_r, d_bad, d_seg, stages);
     HIP_TRY(hipGetLastError());
     return LSA_OK;
 }

@@ -417,6 +417,146 @@ __global__ __launch_bounds__(64) void preprocess_kernel(
     }
 }
 
+// The same three stages with the whole wave at work on ONE scan (round 3): what a lone pm_preprocessScan costs is latency -
+// 350 us at 1081 beams with lane 0 walking the scan, a quarter of a CPolarMatch::FMatch call.  Every lane takes a block of
+// ceil(N / 64) consecutive beams and walks it; what a block needs from the blocks before it is settled as follows.
+//  * Median filter.  In place, a beam's window holds the FILTERED values of the two beams before it: f[i] = med5(f[i-2],
+//    f[i-1], r[i], r[i+1], r[i+2]) (edges clamped).  Those equations have exactly one solution (f[0] depends on raw values
+//    only, every later f[i] on earlier ones), so any fixed point of "recompute every f[i] from the current values" is the
+//    sequential result.  A sweep = every lane walks its block from the current values of the two beams in front of it;
+//    sweeps until one changes nothing.  Sweep k makes block k - 1 final at the latest (so 65 sweeps always suffice), but a
+//    wrong start dies out within a few beams: the blocks' ends are right after the first sweep, everything after the
+//    second, the third confirms.
+//  * Segmentation.  The state the reference carries from beam to beam reduces to three cases - A: a run of two or more
+//    (seg[i-1] == seg[i-2]); B: a single whose predecessor is 0; D: a single right after the id was advanced - because
+//    seg[i-1] always carries the current id when beam i is looked at, and `run` is only ever compared with 1.  A beam's
+//    data (its flag, the two range tests, the flags of the two beams before it) fix a map of {A, B, D} into itself; maps
+//    compose: a lane composes its block's, a prefix scan over the lanes gives every block's entry state, the lane walks
+//    its block again with it.  The id is 1 + the number of A -> D steps up to the beam, and seg[j] is that id unless step
+//    j + 1 zeroed it (a break out of a single without a merge) and step j + 2 did not merge it back.
+constexpr int PRE_SWEEPS = 66;
+__device__ __forceinline__ uint32_t seg_compose(uint32_t later, uint32_t earlier)      // maps of {0, 1, 2}, two bits per entry
+{
+    const uint32_t a = (later >> (2 * (earlier & 3))) & 3, b = (later >> (2 * ((earlier >> 2) & 3))) & 3, c = (later >> (2 * ((earlier >> 4) & 3))) & 3;
+    return a | (b << 2) | (c << 4);
+}
+
+__global__ __launch_bounds__(64) void preprocess_scan_kernel(
+    DevParam P, int S, float* __restrict__ g_r, uint8_t* __restrict__ g_bad, uint16_t* __restrict__ g_seg, int stages)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = P.n, Np = (N + 63) & ~63, lane = lane_id();
+    float* raw = (float*)smem;                       // readings as given; later the ids
+    float* f = (float*)(smem + 4 * Np);              // filtered
+    uint8_t* bad = (uint8_t*)(smem + 8 * Np);
+    uint8_t* fl = bad + Np;                          // per step: its map (+ 64: continues by the range test), later 1 = zeroes seg[i-1], 2 = merges
+    constexpr uint32_t SEG_ID = 0u | (1u << 2) | (2u << 4);
+    enum { SA = 0, SB = 1, SD = 2 };
+    const int per = (N + WAVE - 1) / WAVE;           // beams per lane
+    const int b0 = lane * per, b1 = b0 + per < N ? b0 + per : N;
+    for (int s = blockIdx.x; s < S; s += gridDim.x) {
+        const size_t so = (size_t)s * N;
+        for (int i = lane; i < Np; i += WAVE) {
+            const float v = i < N ? g_r[so + i] : 0.0f;
+            raw[i] = v; f[i] = v; bad[i] = i < N ? g_bad[so + i] : (uint8_t)0; fl[i] = 0;
+        }
+        __syncthreads();                                 // (one wave: orders the lanes' LDS traffic for the compiler)
+        if (stages & 1) {
+            bool changed = true;
+            for (int sweep = 0; changed && sweep < PRE_SWEEPS; ++sweep) {
+                bool ch = false;
+                float f2 = b0 >= 2 ? f[b0 - 2] : 0.0f, f1 = b0 >= 1 ? f[b0 - 1] : 0.0f;
+                float a0 = b0 < N ? raw[b0] : 0.0f, a1 = b0 + 1 < N ? raw[b0 + 1] : 0.0f, a2 = b0 + 2 < N ? raw[b0 + 2] : 0.0f;
+                __syncthreads();                         // (every lane has its start before any lane moves an end)
+                for (int i = b0; i < b1; ++i) {
+                    float w[5];
+                    w[0] = i >= 2 ? f2 : (i == 1 ? f1 : a0);
+                    w[1] = i >= 1 ? f1 : a0;
+                    w[2] = a0;
+                    w[3] = i + 1 <= N - 1 ? a1 : a0;
+                    w[4] = i + 2 <= N - 1 ? a2 : w[3];
+                    #pragma unroll
+                    for (int hi = 4; hi > 0; --hi)
+                        #pragma unroll
+                        for (int k = 0; k < hi; ++k)
+                            if (w[k] > w[k + 1]) { const float sw = w[k]; w[k] = w[k + 1]; w[k + 1] = sw; }
+                    if (f2u(w[2]) != f2u(f[i])) { f[i] = w[2]; ch = true; }      // (bit patterns: -0 to +0 is a change)
+                    f2 = f1; f1 = w[2];
+                    a0 = a1; a1 = a2; a2 = i + 3 < N ? raw[i + 3] : 0.0f;
+                }
+                changed = __ballot(ch) != 0;
+                __syncthreads();
+            }
+        }
+        if (stages & 2)
+            for (int i = lane; i < N; i += WAVE)
+                if (f[i] > (float)P.max_range) bad[i] |= 1;
+        __syncthreads();
+        if (stages & 4) {
+            const float lim = LSA_SEG_MAX_DIST;
+            const int state0 = fabsf_(f[0] - f[1]) < lim ? SA : SB;       // after beam 1 (:1500-1512)
+            uint32_t total = SEG_ID;                     // this block's steps composed
+            for (int i = b0 < 2 ? 2 : b0; i < b1; ++i) {
+                const float ri = f[i], r1 = f[i - 1], r2 = f[i - 2];
+                const bool bi = bad[i] != 0;
+                const bool c1 = fabsf_(ri - r1) < lim;
+                const float ex = (float)((double)ri - (2.0 * (double)r1 - (double)r2));
+                const bool c2 = fabsf_(ex) < lim;
+                const bool nb = !bi && bad[i - 1] == 0 && bad[i - 2] == 0;
+                const bool cont_c1 = !bi && c1;
+                const uint32_t fa = (!bi && (c1 || c2)) ? SA : SD;
+                const uint32_t fb = cont_c1 ? SA : ((nb && c2) ? SA : SB);
+                const uint32_t fd = cont_c1 ? SA : SB;
+                const uint32_t m = fa | (fb << 2) | (fd << 4);
+                fl[i] = (uint8_t)(m | (cont_c1 ? 64u : 0u));
+                total = seg_compose(m, total);
+            }
+            uint32_t inc = total;                        // inclusive prefix composition over the lanes
+            #pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                const uint32_t e = (uint32_t)__shfl_up((int)inc, off);
+                if (lane >= off) inc = seg_compose(inc, e);
+            }
+            uint32_t exc = (uint32_t)__shfl_up((int)inc, 1);
+            if (lane == 0) exc = SEG_ID;
+            int st = (int)((exc >> (2 * state0)) & 3);   // the state this block starts in
+            int adv = 0;                                 // id advances inside the block so far
+            for (int i = b0; i < b1; ++i) {
+                int flags = 0;
+                if (i >= 2) {
+                    const uint32_t m = fl[i];
+                    const int sa = (int)((m >> (2 * st)) & 3);
+                    if (st == SA && sa == SD) ++adv;
+                    if (st != SA && sa == SB) flags = 1;                         // seg[i-1] = 0
+                    if (st == SB && sa == SA && !(m & 64u)) flags = 2;           // seg[i-2 .. i] = id
+                    st = sa;
+                } else if (i == 1 && state0 == SB) flags = 1;                    // seg[0] = 0
+                fl[i] = (uint8_t)flags;
+                ((int*)raw)[i] = adv;                    // (the raw readings are not needed any more)
+            }
+            int before = adv;                            // advances in the blocks in front of this one
+            #pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                const int e = __shfl_up(before, off);
+                if (lane >= off) before += e;
+            }
+            before -= adv;
+            for (int i = b0; i < b1; ++i) ((int*)raw)[i] += 1 + before;
+        }
+        __syncthreads();
+        for (int i = lane; i < N; i += WAVE) {
+            if (stages & 1) g_r[so + i] = f[i];
+            g_bad[so + i] = bad[i];
+            if (stages & 4) {
+                const bool zeroed = i + 1 < N && (fl[i + 1] & 1);
+                const bool merged = i + 2 < N && (fl[i + 2] & 2);
+                g_seg[so + i] = (uint16_t)(zeroed && !merged ? 0 : ((const int*)raw)[i]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // The same three stages for batches: one LANE per scan.  Median filter and segmentation are recurrences along the
 // beam index, so a scan cannot be spread over lanes - but 64 scans can share a wave, each lane walking its own rows
 // of the global arrays (a lane reads and writes consecutive addresses, the caches merge them into lines) with the

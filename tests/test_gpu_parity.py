@@ -74,12 +74,12 @@ def test_tables_match_reference(name, torch_mod):
     ctx.close()
 
 
-@pytest.mark.parametrize("path", ["wave", "lanes", "tiles"])
+@pytest.mark.parametrize("path", ["wave", "walk", "lanes", "tiles"])
 @pytest.mark.parametrize("name", list(SETS))
 def test_preprocess(name, path, torch_mod, monkeypatch):
-    """pm_preprocessScan against the golden vectors through the three kernels: one wave per scan (small batches, the host
-    entry point), one lane per scan through LDS tiles (batches of 4096 scans and more; forced here by
-    LSA_PREPROCESS_PATH) and its untiled predecessor."""
+    """pm_preprocessScan against the golden vectors through the four kernels: one wave per scan with the whole wave at
+    work (small batches, the host entry point) or with lane 0 walking the scan the literal way ("walk"), one lane per scan
+    through LDS tiles (batches of 4096 scans and more; forced here by LSA_PREPROCESS_PATH) and its untiled predecessor."""
     monkeypatch.setenv("LSA_PREPROCESS_PATH", path)
     torch = torch_mod
     g = load(name)
@@ -103,7 +103,7 @@ def test_preprocess(name, path, torch_mod, monkeypatch):
 def test_preprocess_paths_agree_on_ragged_batches(points, scans, torch_mod, monkeypatch):
     """The three preprocessing kernels on batches that are not a multiple of a wave's 64 scans, on five sensor sizes (the
     tiled kernel moves 16-beam tiles: 97 and 8 beams end inside a tile), with spikes, far readings and flagged beams: the
-    lane-per-scan kernels must return the bits of the wave-per-scan kernel, which the golden vectors pin."""
+    other kernels must return the bits of the literal walk, which the golden vectors pin."""
     torch = torch_mod
     from laser_slam_amd import capi, synth
     rng = np.random.default_rng(points)
@@ -114,7 +114,7 @@ def test_preprocess_paths_agree_on_ragged_batches(points, scans, torch_mod, monk
     base[rng.random(base.shape) < 0.01] = 9000.0
     flags = (rng.random(base.shape) < 0.03).astype(np.uint8)
     outs = {}
-    for path in ("wave", "lanes", "tiles"):
+    for path in ("walk", "wave", "lanes", "tiles"):
         monkeypatch.setenv("LSA_PREPROCESS_PATH", path)
         d_r = dev(torch, base, np.float32); d_bad = dev(torch, flags, np.uint8)
         d_seg = torch.zeros(base.shape, dtype=torch.int16, device="cuda")
@@ -122,9 +122,9 @@ def test_preprocess_paths_agree_on_ragged_batches(points, scans, torch_mod, monk
         ctx.preprocess_batch(scans, d_r, d_bad, d_seg)
         ctx.sync()
         outs[path] = (d_r.cpu().numpy().view(np.uint32), d_bad.cpu().numpy(), d_seg.cpu().numpy())
-    assert outs["wave"][2].max() > 1 and outs["wave"][1].sum() > flags.sum()
-    for path in ("lanes", "tiles"):
-        for a, b in zip(outs["wave"], outs[path]):
+    assert outs["walk"][2].max() > 1 and outs["walk"][1].sum() > flags.sum()
+    for path in ("wave", "lanes", "tiles"):
+        for a, b in zip(outs["walk"], outs[path]):
             assert np.array_equal(a, b), path
     ctx.close()
 

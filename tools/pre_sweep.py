@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic (GPU box): batched preprocessing rate by batch size (one lane per scan from 4096 scans on)."""
+"""Diagnostic (GPU box): the four preprocessing kernels bit-compared on ragged batches, and their rates by batch size (fresh scans
+for every launch would change little here: the timed launches re-filter filtered scans, which the sweeps of the wave kernel settle
+faster - tools numbers for it are upper bounds; bench.py and the latency entry use fresh scans)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -19,15 +21,15 @@ for nn, Sp in ((1081, 4999), (361, 777), (181, 64 * 9 + 1), (97, 130)):
     base[rng.random(base.shape) < 0.01] = 9000.0
     flags = (rng.random(base.shape) < 0.03).astype(np.uint8)
     outs = {}
-    for path in ("scan", "lanes", "tiles"):
+    for path in ("walk", "wave", "lanes", "tiles"):
         os.environ["LSA_PREPROCESS_PATH"] = path
         r2 = torch.from_numpy(base).cuda(); b2 = torch.from_numpy(flags).cuda(); s2 = torch.zeros(Sp, nn, dtype=torch.int16, device="cuda")
         cx.preprocess_batch(Sp, r2, b2, s2); cx.sync()
         outs[path] = (r2.cpu().numpy().view(np.uint32), b2.cpu().numpy(), s2.cpu().numpy())
-    for path in ("lanes", "tiles"):
-        same = all(np.array_equal(a, b) for a, b in zip(outs["scan"], outs[path]))
-        print("n=%4d S=%5d  %s == scan: %s" % (nn, Sp, path, same), flush=True)
-for path, Sp in [(q, w) for q in ("lanes", "tiles") for w in (4096, 16384, 65536, 262144, 1048576)]:
+    for path in ("wave", "lanes", "tiles"):
+        same = all(np.array_equal(a, b) for a, b in zip(outs["walk"], outs[path]))
+        print("n=%4d S=%5d  %s == walk: %s" % (nn, Sp, path, same), flush=True)
+for path, Sp in [(q, w) for q in ("wave", "lanes", "tiles") for w in (1024, 4096, 16384, 65536, 262144, 1048576)]:
     os.environ["LSA_PREPROCESS_PATH"] = path
     big = np.tile(raw, ((Sp + S0 - 1) // S0, 1))[:Sp]
     r2 = torch.from_numpy(big).cuda(); b2 = torch.zeros(Sp, n, dtype=torch.uint8, device="cuda"); s2 = torch.zeros(Sp, n, dtype=torch.int16, device="cuda")
