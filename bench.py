@@ -483,9 +483,19 @@ def secondary_matchers(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, which
                                               {"note": "double-precision point-to-line ICP (parity unpinned: CSM absent); "
                                                        "instruction-issue and latency bound, DESIGN.md 4.7"})}
     S = raw.shape[0]
-    Sp = 262144                                             # batched preprocessing (one lane per scan from 4096 scans on)
+    Sp = 262144                                             # batched preprocessing (one lane per scan through LDS tiles from 65 536 scans on; one wave per scan below)
     r2 = torch.from_numpy(raw).cuda().repeat((Sp + S - 1) // S, 1)[:Sp].contiguous(); b2 = torch.zeros(Sp, n, dtype=torch.uint8, device="cuda"); s2 = torch.zeros(Sp, n, dtype=torch.int16, device="cuda")
     ms = timed(torch, lambda: ctx.preprocess_batch(Sp, r2, b2, s2), reps=3)
+    # one fresh scan per launch: what a lone pm_preprocessScan (the head of every FMatch call) costs on the device
+    one = [(torch.from_numpy(raw[k:k + 1].copy()).cuda(), torch.zeros(1, n, dtype=torch.uint8, device="cuda"), torch.zeros(1, n, dtype=torch.int16, device="cuda")) for k in range(21)]
+    ctx.preprocess_batch(1, *one[0]); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(1, 21):
+        ctx.preprocess_batch(1, *one[k])
+    e1.record(); torch.cuda.synchronize()
+    res["preprocess_one_scan"] = {"value": e0.elapsed_time(e1) * 1e3 / 20, "unit": "us per scan", "higher_is_better": False, "beams": int(n),
+                                  "note": "back-to-back launches of one fresh scan each (one wave per scan, the whole wave at work: DESIGN.md 4.3)"}
     res["preprocess"] = {"value": Sp / (ms * 1e-3), "unit": "scans/s", "scans": Sp,
                          "roofline": hbm_roofline("preprocess_tiles_kernel", Sp * n * 12.0, ms, Sp,
                                                   "12 B per beam: ranges read and written, flags read and written, segments written")}
