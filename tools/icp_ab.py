@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic (GPU box): pm_icp rate of several builds on the synthetic 1081-beam set, one process per build, interleaved.
+"""Diagnostic (GPU box): pm_icp (LSA_AB_MATCHER=0: pm_psm) rate of several builds on the synthetic 1081-beam set, one process per build, interleaved.
 usage: icp_ab.py [--pairs N] [--rounds R] build_ab/a.so build_ab/b.so ...  (a build named `-` is the product's library)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,7 +20,7 @@ if "--worker" in sys.argv:
     ri = torch.from_numpy(np.ascontiguousarray(base_pairs[sel, 0])).cuda(); ai = torch.from_numpy(np.ascontiguousarray(base_pairs[sel, 1])).cuda()
     pose = torch.zeros(B, 3, device="cuda")
     its = torch.zeros(B, dtype=torch.int32, device="cuda")
-    ms = bench.timed(torch, lambda: ctx.match_batch(1, B, d_r, d_bad, d_seg, ri, ai, pose, d_iters=its), reps=3)
+    ms = bench.timed(torch, lambda: ctx.match_batch(int(os.environ.get("LSA_AB_MATCHER", "1")), B, d_r, d_bad, d_seg, ri, ai, pose, d_iters=its), reps=3)
     print("%.4f %.3f" % (B / ms / 1e3, float(its.float().mean())), flush=True)
     sys.exit(0)
 args = sys.argv[1:]
