@@ -42,6 +42,13 @@ PROFILE_ROUND = "r03"
 N_BASE, SEEDS = 200, 8
 
 
+def kernel_name(matcher, beams):
+    """rocprofv3's name of the matcher's throughput instance (template arguments: beams[, threads of the workgroup])."""
+    if matcher == "icp":
+        return "icp_kernel<%d, %d>" % (beams, {181: 64, 361: 128, 541: 128}.get(beams, 256))
+    return "psm_kernel<%d>" % beams
+
+
 def build_scan_set():
     from laser_slam_amd import synth
     sets = [synth.make_scans(N_BASE, noise_seed=synth.WORLD_SEED + j)[0] for j in range(SEEDS)]
@@ -363,7 +370,7 @@ def main():
     value = total_pairs / elapsed
 
     out = None
-    kern = "%s_kernel<1081>" % args.matcher
+    kern = kernel_name(args.matcher, 1081)
     if rank == 0:
         W = p.window
         flops_pair = mean_iters * (n * 2 * W * 6 + 60 * n) if which == capi.MATCH_ICP else \
@@ -469,7 +476,7 @@ def secondary_matchers(torch, capi, ctx, d_r, d_bad, d_seg, d_ri, d_ai, B, which
     pose = torch.zeros(B, 3, device="cuda")
     ms = timed(torch, lambda: ctx.match_batch(other, B, d_r, d_bad, d_seg, d_ri, d_ai, pose), reps=3)
     res["pm_%s" % oname] = {"value": B / (ms * 1e-3), "unit": "scan-matches/s", "pairs": B,
-                            "roofline": valu_roofline("%s_kernel<1081>" % oname, B / (ms * 1e-3), ms, B, BYTES_PER_PAIR)}
+                            "roofline": valu_roofline(kernel_name(oname, 1081), B / (ms * 1e-3), ms, B, BYTES_PER_PAIR)}
     # point-to-line ICP (CCanonicalMatcher / zhcsm's matcher), raw scans, 2^17 pairs: a pair that restarts from six
     # perturbed poses runs seven loops, and a small batch waits for its slowest pair (8192 pairs took 17.9 ms in round 2,
     # 9 of them the tail of one such pair)
@@ -555,7 +562,7 @@ def secondary_logs(torch, capi, pairs=1 << 17):
         it = torch.zeros(pairs, dtype=torch.int32, device="cuda")
         entry = {"beams": n, "scans": S, "pairs": pairs}
         bytes_pair = 2 * n * 4 + 12 + 20
-        for which, nm, kn in ((capi.MATCH_ICP, "pm_icp", "icp_kernel<%d>" % n), (capi.MATCH_PSM, "pm_psm", "psm_kernel<%d>" % n)):
+        for which, nm, kn in ((capi.MATCH_ICP, "pm_icp", kernel_name("icp", n)), (capi.MATCH_PSM, "pm_psm", kernel_name("psm", n))):
             ms = timed(torch, lambda: ctx.match_batch(which, pairs, d_r, d_bad, d_seg, d_ri, d_ai, pose, d_status=st, d_iters=it), reps=3)
             mi = float(it.float().mean().item())
             entry[nm] = {"value": pairs / (ms * 1e-3), "unit": "scan-matches/s", "mean_iterations": mi,

@@ -68,7 +68,7 @@ struct lsa_ctx {
     size_t icp_ref_cap = 0;
     unsigned int* d_queue = nullptr;   // pair counter of the matchers' work queue (zeroed before each launch)
     int n_cu = 0;
-    int occ_icp = 0, occ_psm = 0;      // workgroups per CU of the matcher kernels for the current laser (0 = not asked yet)
+    int occ_icp = 0, occ_icp_wide = 0, occ_psm = 0;      // workgroups per CU of the matcher kernels for the current laser (0 = not asked yet)
     double* d_trig = nullptr;    // point-to-line ICP: cos | sin of the beam bearings in double, 2*N (host libm, as CSM's ld_compute_cartesian on the CPU)
 };
 
@@ -327,7 +327,7 @@ int lsa_ctx_set_param(lsa_ctx* c, const lsa_laser_param* p)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->p = *p;
-    c->occ_icp = c->occ_psm = 0;
+    c->occ_icp = c->occ_icp_wide = c->occ_psm = 0;
     if (c->d_trig) { hipFree(c->d_trig); c->d_trig = nullptr; }          // the point-to-line ICP's bearing table follows fi_min / dfi / points
     return upload_tables(c);
 }
@@ -515,11 +515,14 @@ int lsa_match_batch(lsa_ctx* c, int which, int B,
     // once per workgroup, not once per pair; pairs of different iteration counts still balance as they finish.
     HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned int), c->stream));
     if (which == LSA_MATCH_ICP) {
-#define LSA_LAUNCH_ICP(NC) do { \
+        // Width: the throughput instances (icp_threads) for batches; for a handful of pairs - a lone FMatch call - the wide ones,
+        // where a pair's latency is all that counts (LSA_ICP_WIDE=0 / 1 forces one or the other: tests, A/B runs)
+        const char* wide_env = getenv("LSA_ICP_WIDE");
+        const bool wide = wide_env && *wide_env ? atoi(wide_env) != 0 : B <= 2 * c->n_cu;
+#define LSA_LAUNCH_ICP_T(NC, TH, OCC) do { \
         const bool refg = lsa::icp_ref_global(NC); \
-        constexpr int TH = lsa::icp_threads(NC); \
-        if (!c->occ_icp) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_icp, lsa::icp_kernel<NC>, TH, icp_lds(P.n, refg, TH))); \
-        const long long resident = (long long)(c->occ_icp > 0 ? c->occ_icp : 1) * c->n_cu; \
+        if (!c->OCC) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->OCC, lsa::icp_kernel<NC, TH>, TH, icp_lds(P.n, refg, TH))); \
+        const long long resident = (long long)(c->OCC > 0 ? c->OCC : 1) * c->n_cu; \
         const unsigned grid = (unsigned)(B < resident ? B : resident); \
         const size_t need = lsa::icp_ref_slot_bytes(P.n, refg) * grid; \
         if (need > c->icp_ref_cap) { \
@@ -529,9 +532,12 @@ int lsa_match_batch(lsa_ctx* c, int which, int B,
             HIP_TRY(hipMalloc((void**)&c->d_icp_ref, lsa::icp_ref_slot_bytes(P.n, refg) * (size_t)resident)); \
             c->icp_ref_cap = lsa::icp_ref_slot_bytes(P.n, refg) * (size_t)resident; \
         } \
-        hipLaunchKernelGGL(lsa::icp_kernel<NC>, dim3(grid), dim3(TH), icp_lds(P.n, refg, TH), c->stream, P, B, d_r, \
+        hipLaunchKernelGGL((lsa::icp_kernel<NC, TH>), dim3(grid), dim3(TH), icp_lds(P.n, refg, TH), c->stream, P, B, d_r, \
                            d_bad, d_seg, d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters, c->d_queue, \
                            (float2*)c->d_icp_ref); } while (0)
+#define LSA_LAUNCH_ICP(NC) do { \
+        if (wide && lsa::icp_threads_wide(NC) != lsa::icp_threads(NC)) LSA_LAUNCH_ICP_T(NC, lsa::icp_threads_wide(NC), occ_icp_wide); \
+        else LSA_LAUNCH_ICP_T(NC, lsa::icp_threads(NC), occ_icp); } while (0)
         switch (P.n) {          // the reference's presets (PolarParameter.h:75-83) and the 1081-beam benchmark sensor
         case 181:  LSA_LAUNCH_ICP(181); break;
         case 361:  LSA_LAUNCH_ICP(361); break;
@@ -539,6 +545,7 @@ int lsa_match_batch(lsa_ctx* c, int which, int B,
         case 1081: LSA_LAUNCH_ICP(1081); break;
         default:   LSA_LAUNCH_ICP(0); break;
         }
+#undef LSA_LAUNCH_ICP_T
 #undef LSA_LAUNCH_ICP
     } else
     {

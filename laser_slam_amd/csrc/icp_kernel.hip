@@ -32,6 +32,10 @@ constexpr int ICP_THREADS = 256;     // the largest workgroup (1081 beams, the s
 // Constraints: the dropped fifth of the matches must fit one thread each ((int)(0.2 n) <= T) and a thread keeps the last
 // matches of at most six beams in registers (n <= 6 T).
 __host__ __device__ constexpr int icp_threads(int nc) { return nc == 181 ? 64 : (nc == 361 || nc == 541) ? 128 : 256; }
+// ... and for a handful of pairs (a lone FMatch call: one workgroup on an empty chip), where a pair's latency is all that
+// counts: four waves whatever the sensor, the order-free phases in a half or a quarter of the trips (fr079's FMatch 0.89 ->
+// 0.71 ms, intel-lab's 0.59 -> 0.40 - with two waves 0.44 -, indoor's 0.29 -> 0.26).  Same results at every width.
+__host__ __device__ constexpr int icp_threads_wide(int nc) { return 256; }
 
 // ---- diagnostics (the only conditional code in this file) ------------------------------------------------
 // -DLSA_PHASE_STAMPS: thread 0 of every workgroup adds the cycles it spent per phase to lsa_phase_cycles[]
@@ -707,14 +711,13 @@ __device__ __forceinline__ float ordered_sum(const float* arr, int cnt)
 // pm_error_index2 behind a successful match (FMatch, :105), once per pair and out of line: one more projection and the
 // two ordered sums.  Its own function so that the second inlined copy of scan_project (with its constants) does not
 // lengthen the live ranges of the matcher's main loop; the dynamic LDS block is the kernel's (same layout).
-template <int NC>
+template <int NC, int T>
 __device__ __noinline__ void icp_error_tail(DevParam P, const float* g_ref_row, const float* g_act_row, float ex, float ey, float eth,
                                             float* exy, int* n_assoc)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (NC > 0) P.n = NC;
     const int N = P.n;
-    constexpr int T = icp_threads(NC);
     Lds L = carve_icp(smem, N, icp_ref_global(NC), nullptr, T);
     L.g_act_r = g_act_row; L.g_ref_r = g_ref_row;
     if (L.ref_r) for (int i = threadIdx.x; i < N; i += T) L.ref_r[i] = g_ref_row[i];      // ref_xy is no longer needed
@@ -742,8 +745,8 @@ __host__ __device__ constexpr int icp_wg_per_cu(int nc)
 }
 // NC > 0: the beam count as a compile-time constant (the sensors' usual sizes), so that the LDS
 // layout and the trip counts are immediates instead of scalar registers; NC = 0: any size.
-template <int NC>
-__global__ __launch_bounds__(icp_threads(NC), icp_wg_per_cu(NC)) void icp_kernel(
+template <int NC, int NT>
+__global__ __launch_bounds__(NT, NT == icp_threads(NC) ? icp_wg_per_cu(NC) : (LSA_ICP_WG_PER_CU)) void icp_kernel(
     DevParam P_, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
     const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
     const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
@@ -754,7 +757,6 @@ __global__ __launch_bounds__(icp_threads(NC), icp_wg_per_cu(NC)) void icp_kernel
     DevParam P = P_;
     if (NC > 0) P.n = NC;
     const int N = P.n, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    constexpr int NT = icp_threads(NC);              // threads of this instance's workgroup
     Lds L = carve_icp(smem, N, icp_ref_global(NC), icp_ref_global(NC) ? ref_scratch + (size_t)blockIdx.x * ((N + 63) & ~63) : nullptr, NT);
     int* imisc = (int*)L.misc;              // [0] n
     float* fmisc = L.misc + 8;      // [0..3] means  [4..7] covariances
@@ -999,7 +1001,7 @@ __global__ __launch_bounds__(icp_threads(NC), icp_wg_per_cu(NC)) void icp_kernel
                     const float4 q = rel_pose_cold(init_pose[6 * (size_t)b], init_pose[6 * (size_t)b + 1], init_pose[6 * (size_t)b + 2], ax, ay, ath);
                     ex = q.x; ey = q.y; eth = q.z;
                 } else { ex = ax; ey = ay; eth = ath; }
-                icp_error_tail<NC>(P, g_r + ro, g_r + ao, ex, ey, eth, err_xy + 2 * (size_t)b, n_assoc ? n_assoc + b : nullptr);
+                icp_error_tail<NC, NT>(P, g_r + ro, g_r + ao, ex, ey, eth, err_xy + 2 * (size_t)b, n_assoc ? n_assoc + b : nullptr);
             } else if (tid < 2) {
                 err_xy[2 * (size_t)b + tid] = -1.0f;
                 if (tid == 0 && n_assoc) n_assoc[b] = 0;

@@ -2,7 +2,7 @@
 """Build container: turns the outputs of tools/profile_round.sh (gpurun_out/<round>/) into profiles/<round>_*.
 Usage: collect_profiles.py <round>
 
-Per kernel = per full name, template arguments kept (`lsa::icp_kernel<361>`, `lsa::plicp_kernel<3, false>`): the sensor
+Per kernel = per full name, template arguments kept (`lsa::icp_kernel<361, 128>`, `lsa::plicp_kernel<3, false>`): the sensor
 sizes run different instances.  Launches of fewer than 64 workgroups are left out of the counter averages (the single-pair
 calls of bench.py's latency entries would otherwise sit in the same rows as the batches).  `units_per_launch` is what one
 remaining launch of `bench.py --pairs 32768 --steps 1 --warmup 0 --no-cpu` processes (pairs, scans, poses); kernels launched
@@ -11,9 +11,9 @@ import collections, csv, glob, json, os, re, shutil, sys
 
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = "gpurun_out/%s" % rnd
-UNITS = {"lsa::icp_kernel<1081>": 32768, "lsa::psm_kernel<1081>": 32768, "lsa::plicp_kernel<256, 3, false>": 32768,
-         "lsa::icp_kernel<361>": 131072, "lsa::psm_kernel<361>": 131072, "lsa::icp_kernel<181>": 131072, "lsa::psm_kernel<181>": 131072,
-         "lsa::icp_kernel<541>": 131072, "lsa::psm_kernel<541>": 131072, "lsa::plicp_kernel<64, 4, false>": 131072, "lsa::plicp_kernel<64, 3, false>": 131072, "lsa::plicp_kernel<128, 4, false>": 131072, "lsa::plicp_kernel<128, 3, false>": 131072,
+UNITS = {"lsa::icp_kernel<1081, 256>": 32768, "lsa::psm_kernel<1081>": 32768, "lsa::plicp_kernel<256, 3, false>": 32768,
+         "lsa::icp_kernel<361, 128>": 131072, "lsa::psm_kernel<361>": 131072, "lsa::icp_kernel<181, 64>": 131072, "lsa::psm_kernel<181>": 131072,
+         "lsa::icp_kernel<541, 128>": 131072, "lsa::psm_kernel<541>": 131072, "lsa::plicp_kernel<64, 4, false>": 131072, "lsa::plicp_kernel<64, 3, false>": 131072, "lsa::plicp_kernel<128, 4, false>": 131072, "lsa::plicp_kernel<128, 3, false>": 131072,
          "lsa::preprocess_lanes_kernel": 16384, "lsa::grid_binned_kernel": 2048, "lsa::grid_prep_kernel": 2048, "lsa::grid_prob_kernel": 1}
 
 
@@ -116,6 +116,6 @@ for a, b in (("bench_profiled.json", "bench_profiled.json"), ("bench_default.jso
         shutil.copy("%s/%s" % (src, a), "profiles/%s_%s" % (rnd, b))
     except OSError:
         pass
-for k in ("lsa::icp_kernel<1081>", "lsa::psm_kernel<1081>", "lsa::plicp_kernel<256, 3, false>", "lsa::plicp_kernel<128, 4, false>", "lsa::p2p_icp_kernel<128>", "lsa::icp_kernel<361>", "lsa::psm_kernel<361>", "lsa::icp_kernel<181>"):
+for k in ("lsa::icp_kernel<1081, 256>", "lsa::psm_kernel<1081>", "lsa::plicp_kernel<256, 3, false>", "lsa::plicp_kernel<128, 4, false>", "lsa::p2p_icp_kernel<128>", "lsa::icp_kernel<361, 128>", "lsa::psm_kernel<361>", "lsa::icp_kernel<181, 64>"):
     print(k, {c: "%.4g" % v for c, v in hbm.get(k, {}).items()}, {c: "%.4g" % v for c, v in sq.get(k, {}).items()})
 print("score:", {c: ("%.4g" % v if isinstance(v, float) else v) for c, v in sc.items() if c != "_note"})
