@@ -1355,7 +1355,9 @@ static void p2p_launch(lsa_ctx* c, int max_points, const lsa::P2PParam& P_, int 
                        double* out, int n_cur_shared)
 {
     const int cap = lsa::p2p_cap_for(max_points);
-    const int T = lsa::p2p_threads(max_points);
+    // width by the largest cloud - or, for a handful of problems (a lone ICPMatch call: latency is all that counts), four waves
+    // whatever the clouds: the sums are formed the same way at every width (p2p_sums), so the result does not depend on it
+    const int T = B <= 2 * c->n_cu ? 256 : lsa::p2p_threads(max_points);
     const size_t lds = (size_t)lsa::p2p_lds_bytes(cap);
     lsa::P2PParam P = P_;
     const char* ax = getenv("LSA_P2P_AXIS");                 // test hook: the pairs must not depend on the sort axis
