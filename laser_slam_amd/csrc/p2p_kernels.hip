@@ -31,7 +31,12 @@ namespace lsa {
 #ifdef LSA_PHASE_STAMPS
 #define P2P_STAT(slot, v) atomicAdd(&lsa_phase_cycles[slot], (unsigned long long)(v))
 #define P2P_WAVE_STAT(slot) do { const unsigned long long m_ = __ballot(1); if (lane_id() == __builtin_ctzll(m_)) atomicAdd(&lsa_phase_cycles[slot], 1ull); } while (0)
+// thread 0's clock per phase of an iteration: slots 8 reset, 9 search, 10 sums, 11 closed form
+#define P2P_CLOCK(slot) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&lsa_phase_cycles[slot], t_ - p2p_t0); p2p_t0 = t_; } } while (0)
+#define P2P_CLOCK_START unsigned long long p2p_t0 = __builtin_readcyclecounter()
 #else
+#define P2P_CLOCK(slot) do {} while (0)
+#define P2P_CLOCK_START do {} while (0)
 #define P2P_STAT(slot, v) do {} while (0)
 #define P2P_WAVE_STAT(slot) do {} while (0)
 #endif
@@ -233,10 +238,12 @@ __global__ __launch_bounds__(T) void p2p_icp_kernel(
         double mse = 0.0, cov[6] = {0, 0, 0, 0, 0, 0};
         bool keep = n1 > 0 && n2 > 0;
         double cq = cos(qphi), sq = sin(qphi);                 // of the pose in hand (an iteration ends with those of its new pose)
+        P2P_CLOCK_START;
         while (keep && iter < O.max_iter) {
             const float cphi = (float)cq, sphi = (float)sq;
             for (int j = tid; j < n1; j += T) own_b[j] = ~0ull;
             __syncthreads();
+            P2P_CLOCK(8);
             // nearest first-map point of every second-map point
             // second-map point i in the first map's frame and its pairing threshold
             auto query = [&](int i, float& gx, float& gy, float& lim) {
@@ -363,6 +370,7 @@ __global__ __launch_bounds__(T) void p2p_icp_kernel(
                 }
             }
             __syncthreads();
+            P2P_CLOCK(9);
             // sums over the surviving pairs (a = first map, b = second map in its own frame)
             double s[10];                                    // n, xa, ya, xb, yb, xaxb, yayb, xayb, yaxb, squared residuals
             p2p_sums<10, T>(n2, s, sh, [&](int i, double (&a)[10]) {
@@ -376,6 +384,7 @@ __global__ __launch_bounds__(T) void p2p_icp_kernel(
                     a[9] += (double)u2f((uint32_t)(own_b[j] >> 32));
                 }
             });
+            P2P_CLOCK(10);
             n_pairs = (int)s[0];
             if (n_pairs == 0) { keep = false; break; }
             mse = s[9] / s[0];
@@ -394,6 +403,7 @@ __global__ __launch_bounds__(T) void p2p_icp_kernel(
                 if (thr_d < O.smallest_thr) keep = false;
             }
             ++iter;
+            P2P_CLOCK(11);
         }
         // covariance: sigma^2 (J^T J)^-1 of the pair residuals at the solution,
         // J_i = [1 0 -(s xb + c yb); 0 1 (c xb - s yb)]
