@@ -207,3 +207,31 @@ def test_pairs_do_not_depend_on_the_sort_axis(ctx, monkeypatch):
         for (r, c, ini), want in zip(probs, auto):
             got = capi.p2p_icp_host(ctx, r[0], r[1], c[0], c[1], ini)
             assert np.array_equal(got[:13], want[:13]), (axis, got[:7], want[:7])
+
+
+def test_degenerate_clouds_against_oracle(ctx):
+    """Clouds the axis choice and the strips of the sort could trip over: all points on one vertical or horizontal line (the
+    projections' extent vanishes on some axes), every point the same, exactly 128 points (the threshold of the choice), a
+    first map of 2048 points (the largest that is sorted) and one of 2049 (streamed in tiles, unsorted)."""
+    from laser_slam_amd import capi
+    from oracle_lib import p2p_icp
+    rng = np.random.default_rng(33)
+    def moved(p, th, tx, ty):
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        return ((p - [tx, ty]) @ R).astype(np.float32)
+    t = np.linspace(0, 5, 300)
+    cases = {
+        "vertical": np.stack([np.full(300, 1.5), t], 1),
+        "horizontal": np.stack([t, np.full(300, -0.7)], 1),
+        "same point": np.tile([[0.4, 0.9]], (200, 1)),
+        "128 points": np.stack([t[:128], 0.2 * np.sin(3 * t[:128])], 1),
+        "2048 points": np.stack([np.linspace(0, 20, 2048), np.sin(np.linspace(0, 20, 2048))], 1),
+        "2049 points": np.stack([np.linspace(0, 20, 2049), np.sin(np.linspace(0, 20, 2049))], 1),
+    }
+    for name, ref in cases.items():
+        ref = ref.astype(np.float32)
+        cur = moved(ref[:: 2 if len(ref) > 1000 else 1].astype(np.float64) + rng.normal(0, 0.002, (len(ref[:: 2 if len(ref) > 1000 else 1]), 2)), 0.02, 0.05, -0.03)
+        got = capi.p2p_icp_host(ctx, ref[:, 0].copy(), ref[:, 1].copy(), cur[:, 0].copy(), cur[:, 1].copy(), (0.0, 0.0, 0.0))
+        want = p2p_icp(ref[:, 0].copy(), ref[:, 1].copy(), cur[:, 0].copy(), cur[:, 1].copy(), (0.0, 0.0, 0.0))
+        assert got[5] == want[5] and got[6] == want[6], (name, got[:7], want[:7])
+        assert np.allclose(got[:5], want[:5], rtol=1e-9, atol=1e-9), (name, got[:5], want[:5])
