@@ -959,18 +959,30 @@ int lsa_grid_update_host(lsa_grid* g, const float* gx, const float* gy, int n, f
     if (n < 0) return lsa_grid_compute_prob(g);          // updateMap(n<0) == finish, PMap.cpp:54-60
     if (n == 0) return LSA_OK;
     HIP_TRY(hipSetDevice(g->c->device));
+    // One scan alone would be one workgroup walking all its rays (131 us at 1081 beams on an otherwise empty chip): it goes in
+    // as ceil(n / GRID_LONE_BEAMS) scans of GRID_LONE_BEAMS beams from the same robot cell - the counts are additive, the
+    // arrays are the same memory read with another row length - and a workgroup has a ray per thread at most.
+    constexpr int GRID_LONE_BEAMS = 128;
+    const int parts = (n + GRID_LONE_BEAMS - 1) / GRID_LONE_BEAMS;
     if (g->pts_cap < n) {
         if (g->d_pts) hipFree(g->d_pts);
-        HIP_TRY(hipMalloc((void**)&g->d_pts, sizeof(float) * (2 * (size_t)n + 2)));
+        const int cap_parts = (n + GRID_LONE_BEAMS - 1) / GRID_LONE_BEAMS;
+        HIP_TRY(hipMalloc((void**)&g->d_pts, sizeof(float) * (2 * (size_t)n + 3 * (size_t)cap_parts)));
         g->pts_cap = n;
     }
     hipStream_t st = g->c->stream;
-    const float rxy[2] = {rx, ry};
+    std::vector<float> tail(3 * (size_t)parts);          // robot position of every part, then the parts' beam counts
+    for (int k = 0; k < parts; ++k) {
+        tail[2 * k] = rx; tail[2 * k + 1] = ry;
+        const int nb = k + 1 < parts ? GRID_LONE_BEAMS : n - k * GRID_LONE_BEAMS;
+        memcpy(&tail[2 * (size_t)parts + k], &nb, sizeof nb);
+    }
+    float* d_tail = g->d_pts + 2 * (size_t)g->pts_cap;
     HIP_TRY(hipMemcpyAsync(g->d_pts, gx, sizeof(float) * n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(g->d_pts + g->pts_cap, gy, sizeof(float) * n, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(g->d_pts + 2 * (size_t)g->pts_cap, rxy, sizeof rxy, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));      // rxy is a stack temporary
-    return lsa_grid_update_batch(g, 1, n, g->d_pts, g->d_pts + g->pts_cap, g->d_pts + 2 * (size_t)g->pts_cap, nullptr);
+    HIP_TRY(hipMemcpyAsync(d_tail, tail.data(), sizeof(float) * tail.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));      // (the tail is a temporary)
+    return lsa_grid_update_batch(g, parts, GRID_LONE_BEAMS, g->d_pts, g->d_pts + g->pts_cap, d_tail, (const int*)(d_tail + 2 * (size_t)parts));
 }
 
 int lsa_grid_compute_prob(lsa_grid* g)
