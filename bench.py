@@ -636,6 +636,38 @@ def secondary_latency(torch, capi, raw1081):
         ctx.close()
         q = lambda v: {"median_us": float(np.median(v)) * 1e6, "p95_us": float(np.percentile(v, 95)) * 1e6, "max_us": float(np.max(v)) * 1e6}
         res[name] = {"beams": n, "calls": len(tf), "CPolarMatch_FMatch": q(tf), "CCanonicalMatcher_FMatch": dict(q(tp), mean_iterations=float(np.mean(its)))}
+    q = lambda v: {"median_us": float(np.median(v)) * 1e6, "p95_us": float(np.percentile(v, 95)) * 1e6, "max_us": float(np.max(v)) * 1e6}
+    # a lone CPMap::updateMap (drawmap / mapGraph insert a scan at a time): one 1081-beam scan into 4096^2 at 5 cm
+    p = capi.param_make(**synth.SYN1081); ctx = capi.Context(p)
+    fi = capi.param_tables(p)[0]
+    g = capi.Grid(ctx, 4096, 4096, 2048, 2048, 0.0, 0.0, 0.05)
+    tu = []
+    for k in range(60):
+        rr = raw1081[k] * 0.01
+        x = (rr * np.cos(fi) + 1.0).astype(np.float32); y = (rr * np.sin(fi) + 2.0).astype(np.float32)
+        t0 = time.perf_counter(); g.update_host(x, y, 1.0, 2.0); ctx.sync(); tu.append(time.perf_counter() - t0)
+    g.close()
+    res["CPMap_updateMap"] = dict(q(tu[10:]), beams=int(raw1081.shape[1]), grid="4096x4096 at 5 cm")
+    # a lone CICPWarpper::ICPMatch on the reference's map-node clouds with their recorded priors (MapNode.cpp:625-656)
+    zd = os.path.join(ROOT, "tests", "golden", "zhicp")
+    try:
+        rows = np.loadtxt(os.path.join(zd, "matched_nodes.log"))
+        tc, itc, npts = [], [], []
+        for rep in range(4):
+            for a, b, _, px, py, pth in rows:
+                fa, fb = os.path.join(zd, "%d.log" % int(a)), os.path.join(zd, "%d.log" % int(b))
+                if not (os.path.exists(fa) and os.path.exists(fb)):
+                    continue
+                ca, cb = np.loadtxt(fa, dtype=np.float32), np.loadtxt(fb, dtype=np.float32)
+                t0 = time.perf_counter()
+                o = capi.p2p_icp_host(ctx, ca[:, 0].copy(), ca[:, 1].copy(), cb[:, 0].copy(), cb[:, 1].copy(), (px, py, pth))
+                if rep:
+                    tc.append(time.perf_counter() - t0); itc.append(o[5]); npts.append(len(ca) + len(cb))
+        if tc:
+            res["CICPWarpper_ICPMatch"] = dict(q(tc), mean_iterations=float(np.mean(itc)), points_per_problem=float(np.mean(npts)))
+    except OSError:
+        pass
+    ctx.close()
     return {"fmatch_latency": res}
 
 

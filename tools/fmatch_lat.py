@@ -12,5 +12,6 @@ stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
 raw = bench.build_scan_set()
 res = bench.secondary_latency(torch, capi, raw)["fmatch_latency"]
 for k, v in res.items():
-    if not isinstance(v, dict) or "beams" not in v: continue
+    if not isinstance(v, dict) or "CPolarMatch_FMatch" not in v:
+        print(k, v); continue
     print(sys.argv[1] if len(sys.argv) > 1 else "-", k, v["beams"], "CPolarMatch::FMatch median %.0f us p95 %.0f" % (v["CPolarMatch_FMatch"]["median_us"], v["CPolarMatch_FMatch"]["p95_us"]), flush=True)
