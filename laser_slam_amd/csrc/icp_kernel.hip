@@ -33,9 +33,16 @@ constexpr int ICP_THREADS = 256;     // the largest workgroup (1081 beams, the s
 // matches of at most six beams in registers (n <= 6 T).
 __host__ __device__ constexpr int icp_threads(int nc) { return nc == 181 ? 64 : (nc == 361 || nc == 541) ? 128 : 256; }
 // ... and for a handful of pairs (a lone FMatch call: one workgroup on an empty chip), where a pair's latency is all that
-// counts: four waves whatever the sensor, the order-free phases in a half or a quarter of the trips (fr079's FMatch 0.89 ->
-// 0.71 ms, intel-lab's 0.59 -> 0.40 - with two waves 0.44 -, indoor's 0.29 -> 0.26).  Same results at every width.
-__host__ __device__ constexpr int icp_threads_wide(int nc) { return 256; }
+// counts: four waves at 181 beams, eight at 361 / 541, sixteen at 1081 - the order-free phases in one trip or two (fr079's
+// FMatch 0.89 ms with two waves, 0.70 with four, 0.63 with eight; intel-lab's 0.59 -> 0.41; indoor's 0.29 -> 0.24; 1081 beams
+// 1.04 ms with four, 0.93 with eight, 0.86 with sixteen).  Same results at every width.
+#ifndef LSA_ICP_LONE_T
+#define LSA_ICP_LONE_T 1024
+#endif
+#ifndef LSA_ICP_LONE_T_MID
+#define LSA_ICP_LONE_T_MID 512
+#endif
+__host__ __device__ constexpr int icp_threads_wide(int nc) { return nc == 1081 ? LSA_ICP_LONE_T : (nc == 361 || nc == 541) ? LSA_ICP_LONE_T_MID : 256; }
 
 // ---- diagnostics (the only conditional code in this file) ------------------------------------------------
 // -DLSA_PHASE_STAMPS: thread 0 of every workgroup adds the cycles it spent per phase to lsa_phase_cycles[]
@@ -434,10 +441,17 @@ __device__ __forceinline__ int block_rank(bool flag, int& total, int* wcnt, int&
     const unsigned long long mask = __ballot(flag);
     if (T == 64) { total = __popcll(mask); return prefix_popc(mask); }      // one wave: the ballot is the whole answer
     const int wave = threadIdx.x >> 6;
-    int* slot = wcnt + 4 * (phase & 1);
+    int* slot = wcnt + (T > 256 ? T / 64 : 4) * (phase & 1);
     phase++;
     if (lane_id() == 0) slot[wave] = __popcll(mask);
     __syncthreads();
+    if (T > 256) {                                       // eight or sixteen waves (lone-pair instances)
+        int off = 0, all = 0;
+        #pragma unroll
+        for (int w = 0; w < T / 64; ++w) { const int c = slot[w]; off += w < wave ? c : 0; all += c; }
+        total = all;
+        return off + prefix_popc(mask);
+    }
     if (T == 128) {
         const int c0 = slot[0], c1 = slot[1];
         total = c0 + c1;
@@ -885,7 +899,7 @@ __global__ __launch_bounds__(NT, NT == icp_threads(NC) ? icp_wg_per_cu(NC) : (LS
 #ifdef LSA_PHASE_STAMPS
             t_sub = __builtin_readcyclecounter();
 #endif
-            trim_worst<NT>(L, n, drop, imisc + 40 STAMP_PASS);                               // :1839-1857
+            trim_worst<NT>(L, n, drop, imisc + 32 STAMP_PASS);                               // :1839-1857
             __syncthreads();
             STAMP(3);
 
