@@ -402,15 +402,16 @@ __device__ __forceinline__ void nn_general(const Lds& L, float T, NnBeam& b)
 }
 
 // record of beam i into L.key[i] (:1811-1816), returns the match for next iteration's seed
-__device__ __forceinline__ int nn_store(const Lds& L, int N, int i, const NnBeam& b)
+__device__ __forceinline__ int nn_store(const Lds& L, int N, int i, const NnBeam& b, bool& kept)
 {
     const bool found = b.live && b.best_j != 0x7fffffff;
+    kept = false;
     if (i < N) {
         float rd = -1.0f;
         int bj = 0;
         if (found) {
             const float sd = sqrtf(b.best);
-            if (sd < LSA_MAX_ERROR) { rd = sd; bj = b.best_j; }
+            if (sd < LSA_MAX_ERROR) { rd = sd; bj = b.best_j; kept = true; }
         }
         L.key[i] = pack_rec(rd, (uint32_t)i | ((uint32_t)bj << 16));
     }
@@ -722,6 +723,51 @@ __device__ __forceinline__ float ordered_sum(const float* arr, int cnt)
     return acc;
 }
 
+// The same sum for the lone-pair instances, where nothing else covers an LDS latency and the registers are there: the chain
+// of dependent additions is the whole cost, so the loads must never be waited for - a ring of eight 128-bit registers, each
+// refilled (seven quads ahead of the chain) as soon as its four values are added.  The loads and their waits are written
+// out, because the compiler turns a source-level prefetch back into "load four quads, wait, add" per trip (it reloads
+// instead of carrying the values round the loop).  LDS returns in order, so "at most seven outstanding" means the oldest
+// quad has arrived; the wait names its register, which keeps the additions behind it.  (In the throughput instances the
+// 32 registers cost more than the latency they hide: -2.5 % / -4 % at 361 / 541 beams.)
+typedef float lsa_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float ordered_sum_ahead(const float* arr, int cnt)
+{
+    const int nq = cnt >> 2;
+    float acc = 0.0f;
+    int qd = 0;
+    if (nq >= 16) {
+        uint32_t ad = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)arr;
+        lsa_f4 r0, r1, r2, r3, r4, r5, r6, r7;
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
+                     "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\tds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112"
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7) : "v"(ad) : "memory");
+        // quads [qd, qd + 8) are in flight or here; every step adds one and asks for the one eight behind it (reads that run past
+        // the list stay inside the workgroup's LDS - at most 15 quads behind a list's end - and are never added)
+#define LSA_SUM_STEP(R, OFF) \
+        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(R)); \
+        acc += R.x; acc += R.y; acc += R.z; acc += R.w; \
+        asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(R) : "v"(ad), "v"(acc) : "memory");
+        for (; qd + 16 <= nq; qd += 8) {
+            LSA_SUM_STEP(r0, 128) LSA_SUM_STEP(r1, 144) LSA_SUM_STEP(r2, 160) LSA_SUM_STEP(r3, 176)
+            LSA_SUM_STEP(r4, 192) LSA_SUM_STEP(r5, 208) LSA_SUM_STEP(r6, 224) LSA_SUM_STEP(r7, 240)
+            ad += 128;
+        }
+#undef LSA_SUM_STEP
+        // the ring holds quads [qd, qd + 8): all inside the list (qd + 8 <= nq)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7));
+        acc += r0.x; acc += r0.y; acc += r0.z; acc += r0.w;  acc += r1.x; acc += r1.y; acc += r1.z; acc += r1.w;
+        acc += r2.x; acc += r2.y; acc += r2.z; acc += r2.w;  acc += r3.x; acc += r3.y; acc += r3.z; acc += r3.w;
+        acc += r4.x; acc += r4.y; acc += r4.z; acc += r4.w;  acc += r5.x; acc += r5.y; acc += r5.z; acc += r5.w;
+        acc += r6.x; acc += r6.y; acc += r6.z; acc += r6.w;  acc += r7.x; acc += r7.y; acc += r7.z; acc += r7.w;
+        qd += 8;
+    }
+    const float4* v = (const float4*)arr;            // arrays are 16-byte aligned
+    for (; qd < nq; ++qd) { const float4 q = v[qd]; acc += q.x; acc += q.y; acc += q.z; acc += q.w; }
+    for (int k2 = qd * 4; k2 < cnt; ++k2) acc += arr[k2];
+    return acc;
+}
+
 // pm_error_index2 behind a successful match (FMatch, :105), once per pair and out of line: one more projection and the
 // two ordered sums.  Its own function so that the second inlined copy of scan_project (with its constants) does not
 // lengthen the live ranges of the matcher's main loop; the dynamic LDS block is the kernel's (same layout).
@@ -760,7 +806,7 @@ __host__ __device__ constexpr int icp_wg_per_cu(int nc)
 // NC > 0: the beam count as a compile-time constant (the sensors' usual sizes), so that the LDS
 // layout and the trip counts are immediates instead of scalar registers; NC = 0: any size.
 template <int NC, int NT>
-__global__ __launch_bounds__(NT, NT == icp_threads(NC) ? icp_wg_per_cu(NC) : (LSA_ICP_WG_PER_CU)) void icp_kernel(
+__global__ __launch_bounds__(NT, NT == icp_threads(NC) ? icp_wg_per_cu(NC) : (NT >= 256 ? NT / 256 : 1)) void icp_kernel(
     DevParam P_, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
     const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
     const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,
@@ -866,7 +912,12 @@ __global__ __launch_bounds__(NT, NT == icp_threads(NC) ? icp_wg_per_cu(NC) : (LS
 #endif
                         nn_general(L, T, b0);
                     }
-                    const int m0 = nn_store(L, N, i0, b0);
+                    bool ok0;
+                    const int m0 = nn_store(L, N, i0, b0, ok0);
+                    if (NT != icp_threads(NC)) {                                           // (lone-pair instances: the compaction below)
+                        const unsigned long long okm = __ballot(ok0);
+                        if (lane == 0) ((uint8_t*)(imisc + 2))[base >> 6] = (uint8_t)__popcll(okm);
+                    }
                     {
                         const uint32_t nv = (uint32_t)(m0 + 1) & 0xffffu;
                         const uint32_t nw = (trip & 1) ? (jpw & 0xffffu) | (nv << 16) : (jpw & 0xffff0000u) | nv;
@@ -877,6 +928,45 @@ __global__ __launch_bounds__(NT, NT == icp_threads(NC) ? icp_wg_per_cu(NC) : (LS
             __syncthreads();
             STAMP(1);
 
+            if (NT != icp_threads(NC)) {
+                // ---- compaction in beam order, all waves (lone-pair instances: latency is what counts) -----------------
+                // The search left every 64-beam chunk's count of matches in the slots (a byte per chunk); a chunk's records
+                // go to the running total of the chunks in front of it.  A thread takes the records of its own beams to
+                // registers, and once every wave has (the destinations overlap other threads' sources) writes them down:
+                // two short intervals for all waves in place of one wave walking the scan (8.7 k -> 2.4 k cycles at 1081
+                // beams; in the throughput instances the extra instructions of four waves cost what the latency gains).
+                constexpr int WPT = NT / WAVE;                                   // chunks between a wave's consecutive trips
+                constexpr int TRIPS = NC > 0 ? (NC + NT - 1) / NT : 6;
+                constexpr int CHUNKS = NC > 0 ? (NC + WAVE - 1) / WAVE : 6 * WPT;
+                static_assert(CHUNKS <= 24, "six words of chunk counts");
+                const int uw = __builtin_amdgcn_readfirstlane(wave);
+                const int nchunk = (N + WAVE - 1) / WAVE;
+                uint32_t cw[(CHUNKS + 3) / 4];
+                #pragma unroll
+                for (int u = 0; u < (CHUNKS + 3) / 4; ++u) cw[u] = (uint32_t)__builtin_amdgcn_readfirstlane(imisc[2 + u]);
+                unsigned long long v[TRIPS];
+                #pragma unroll
+                for (int trip = 0; trip < TRIPS; ++trip) {
+                    const int i = uw * WAVE + trip * NT + lane;
+                    v[trip] = i < N ? L.key[i] : pack_rec(-1.0f, 0);
+                }
+                __syncthreads();
+                int run = 0, off[TRIPS];
+                #pragma unroll
+                for (int trip = 0; trip < TRIPS; ++trip) off[trip] = 0;
+                #pragma unroll
+                for (int c = 0; c < CHUNKS; ++c) {
+                    if (c % WPT == uw) off[c / WPT] = run;
+                    if (NC > 0 || c < nchunk) run += (int)((cw[c >> 2] >> (8 * (c & 3))) & 0xffu);
+                }
+                #pragma unroll
+                for (int trip = 0; trip < TRIPS; ++trip) {
+                    const bool ok = rec_d(v[trip]) >= 0.0f;
+                    const unsigned long long mask = __ballot(ok);
+                    if (ok) L.key[off[trip] + prefix_popc(mask)] = v[trip];
+                }
+                if (tid == 0) imisc[0] = run;
+            } else
             // ---- wave 0: compaction in beam order ------------------------------------
             if (wave == sw) {
                 int m = 0;
@@ -945,7 +1035,7 @@ __global__ __launch_bounds__(NT, NT == icp_threads(NC) ? icp_wg_per_cu(NC) : (LS
             STAMP(4);
 
             // ---- closed-form rigid fit, :1936-1986: ordered sums, one lane per sum -------
-            if (wave == sw && lane < 4) fmisc[lane] = ordered_sum(my_list, keep) / (float)keep;
+            if (wave == sw && lane < 4) fmisc[lane] = (NT != icp_threads(NC) ? ordered_sum_ahead(my_list, keep) : ordered_sum(my_list, keep)) / (float)keep;
             __syncthreads();
             STAMP(5);
             const float mpx = fmisc[0], mpy = fmisc[1], mqx = fmisc[2], mqy = fmisc[3];
@@ -957,7 +1047,7 @@ __global__ __launch_bounds__(NT, NT == icp_threads(NC) ? icp_wg_per_cu(NC) : (LS
             // the covariance sums, then the pose update (:1984-1999) and next iteration's cos/sin
             // (:1753-1754), by the one wave that holds the sums: the other waves only read the result
             if (wave == sw) {
-                const float sum = lane < 4 ? ordered_sum(my_list, keep) : 0.0f;
+                const float sum = lane < 4 ? (NT != icp_threads(NC) ? ordered_sum_ahead(my_list, keep) : ordered_sum(my_list, keep)) : 0.0f;
                 const float sxx = bcast_f(sum, 0), sxy = bcast_f(sum, 1), syx = bcast_f(sum, 2), syy = bcast_f(sum, 3);
                 const float ax = fmisc[PS_AX], ay = fmisc[PS_AY], ath = fmisc[PS_ATH];
                 const float ndth = atan2f_(sxy - syx, sxx + syy);                // :1984
