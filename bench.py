@@ -46,7 +46,7 @@ def kernel_name(matcher, beams):
     """rocprofv3's name of the matcher's throughput instance (template arguments: beams[, threads of the workgroup])."""
     if matcher == "icp":
         return "icp_kernel<%d, %d>" % (beams, {181: 64, 361: 128, 541: 128}.get(beams, 256))
-    return "psm_kernel<%d>" % beams
+    return "psm_kernel<%d, %d>" % (beams, {181: 64, 361: 64, 541: 128}.get(beams, 256))
 
 
 def build_scan_set():

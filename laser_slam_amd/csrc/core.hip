@@ -68,7 +68,7 @@ struct lsa_ctx {
     size_t icp_ref_cap = 0;
     unsigned int* d_queue = nullptr;   // pair counter of the matchers' work queue (zeroed before each launch)
     int n_cu = 0;
-    int occ_icp = 0, occ_icp_wide = 0, occ_psm = 0;      // workgroups per CU of the matcher kernels for the current laser (0 = not asked yet)
+    int occ_icp = 0, occ_icp_wide = 0, occ_psm = 0, occ_psm_wide = 0;      // workgroups per CU of the matcher kernels for the current laser (0 = not asked yet)
     double* d_trig = nullptr;    // point-to-line ICP: cos | sin of the beam bearings in double, 2*N (host libm, as CSM's ld_compute_cartesian on the CPU)
 };
 
@@ -327,7 +327,7 @@ int lsa_ctx_set_param(lsa_ctx* c, const lsa_laser_param* p)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->p = *p;
-    c->occ_icp = c->occ_icp_wide = c->occ_psm = 0;
+    c->occ_icp = c->occ_icp_wide = c->occ_psm = c->occ_psm_wide = 0;
     if (c->d_trig) { hipFree(c->d_trig); c->d_trig = nullptr; }          // the point-to-line ICP's bearing table follows fi_min / dfi / points
     return upload_tables(c);
 }
@@ -549,13 +549,17 @@ int lsa_match_batch(lsa_ctx* c, int which, int B,
 #undef LSA_LAUNCH_ICP
     } else
     {
-#define LSA_LAUNCH_PSM(NC) do { \
+        const char* pwide_env = getenv("LSA_PSM_WIDE");          // (as LSA_ICP_WIDE)
+        const bool pwide = pwide_env && *pwide_env ? atoi(pwide_env) != 0 : B <= 2 * c->n_cu;
+#define LSA_LAUNCH_PSM_T(NC, TH, OCC) do { \
         const int lds = lsa::psm_compact_lds_bytes(P.n, P.window); \
-        constexpr int TH = lsa::psm_threads(NC); \
-        if (!c->occ_psm) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->occ_psm, lsa::psm_kernel<NC>, TH, lds)); \
-        const long long resident = (long long)(c->occ_psm > 0 ? c->occ_psm : 1) * c->n_cu; \
-        hipLaunchKernelGGL(lsa::psm_kernel<NC>, dim3((unsigned)(B < resident ? B : resident)), dim3(TH), lds, c->stream, P, B, \
+        if (!c->OCC) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->OCC, lsa::psm_kernel<NC, TH>, TH, lds)); \
+        const long long resident = (long long)(c->OCC > 0 ? c->OCC : 1) * c->n_cu; \
+        hipLaunchKernelGGL((lsa::psm_kernel<NC, TH>), dim3((unsigned)(B < resident ? B : resident)), dim3(TH), lds, c->stream, P, B, \
                            d_r, d_bad, d_seg, d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters, c->d_queue); } while (0)
+#define LSA_LAUNCH_PSM(NC) do { \
+        if (pwide && lsa::psm_threads(NC) != 256) LSA_LAUNCH_PSM_T(NC, 256, occ_psm_wide); \
+        else LSA_LAUNCH_PSM_T(NC, lsa::psm_threads(NC), occ_psm); } while (0)
         switch (P.n) {
         case 181:  LSA_LAUNCH_PSM(181); break;
         case 361:  LSA_LAUNCH_PSM(361); break;
@@ -563,6 +567,7 @@ int lsa_match_batch(lsa_ctx* c, int which, int B,
         case 1081: LSA_LAUNCH_PSM(1081); break;
         default:   LSA_LAUNCH_PSM(0); break;
         }
+#undef LSA_LAUNCH_PSM_T
 #undef LSA_LAUNCH_PSM
     }
     HIP_TRY(hipGetLastError());

@@ -377,8 +377,10 @@ __device__ __forceinline__ void load_pair_psm(const DevParam& P, Lds& L, const f
 // eight waves per SIMD (64 registers; 17.9 KiB of LDS at 1081 beams).  What does not fit is parked in scratch memory in the
 // prologue, once per persistent workgroup: tests/test_isa_invariants.py holds every instance to "no scratch store behind the
 // first loop header" (round 2's 361-beam instance wrote 27-41 KB of scratch per pair from inside the iteration loop).
-template <int NC>
-__global__ __launch_bounds__(psm_threads(NC), LSA_PSM_WG_PER_CU) void psm_kernel(
+// NT: threads of the workgroup - psm_threads(NC) for batches, 256 for a handful of pairs (a lone pm_psm call: latency is all
+// that counts; one workgroup per CU's worth of registers there)
+template <int NC, int NT>
+__global__ __launch_bounds__(NT, NT == psm_threads(NC) ? (LSA_PSM_WG_PER_CU) : 1) void psm_kernel(
     DevParam P_, int B, const float* __restrict__ g_r, const uint8_t* __restrict__ g_bad,
     const uint16_t* __restrict__ g_seg, const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
     const float* __restrict__ init_pose, float* __restrict__ pose_out, float* __restrict__ ret_out,

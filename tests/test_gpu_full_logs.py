@@ -35,9 +35,10 @@ def _context(capi, name, g):
 @pytest.mark.parametrize("width", ["batch", "wide"])
 @pytest.mark.parametrize("name", ["fr079", "intel", "mit"])
 def test_whole_log_every_pair_bit_identical(name, width, monkeypatch):
-    """(width: pm_icp's throughput instances - one wave per pair at 181 beams, two at 361 - and the wide ones a handful of
-    pairs gets, i.e. every lone FMatch call; forced here for the whole log by LSA_ICP_WIDE)"""
+    """(width: the matchers' throughput instances - one wave per pair at 181 beams, one or two at 361 - and the wide ones a handful
+    of pairs gets, i.e. every lone FMatch / pm_psm call; forced here for the whole log by LSA_ICP_WIDE / LSA_PSM_WIDE)"""
     monkeypatch.setenv("LSA_ICP_WIDE", "1" if width == "wide" else "0")
+    monkeypatch.setenv("LSA_PSM_WIDE", "1" if width == "wide" else "0")
     import torch
     from laser_slam_amd import capi
     g = _load(name)

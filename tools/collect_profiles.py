@@ -11,9 +11,9 @@ import collections, csv, glob, json, os, re, shutil, sys
 
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = "gpurun_out/%s" % rnd
-UNITS = {"lsa::icp_kernel<1081, 256>": 32768, "lsa::psm_kernel<1081>": 32768, "lsa::plicp_kernel<256, 3, false>": 32768,
-         "lsa::icp_kernel<361, 128>": 131072, "lsa::psm_kernel<361>": 131072, "lsa::icp_kernel<181, 64>": 131072, "lsa::psm_kernel<181>": 131072,
-         "lsa::icp_kernel<541, 128>": 131072, "lsa::psm_kernel<541>": 131072, "lsa::plicp_kernel<64, 4, false>": 131072, "lsa::plicp_kernel<64, 3, false>": 131072, "lsa::plicp_kernel<128, 4, false>": 131072, "lsa::plicp_kernel<128, 3, false>": 131072,
+UNITS = {"lsa::icp_kernel<1081, 256>": 32768, "lsa::psm_kernel<1081, 256>": 32768, "lsa::plicp_kernel<256, 3, false>": 32768,
+         "lsa::icp_kernel<361, 128>": 131072, "lsa::psm_kernel<361, 64>": 131072, "lsa::icp_kernel<181, 64>": 131072, "lsa::psm_kernel<181, 64>": 131072,
+         "lsa::icp_kernel<541, 128>": 131072, "lsa::psm_kernel<541, 128>": 131072, "lsa::plicp_kernel<64, 4, false>": 131072, "lsa::plicp_kernel<64, 3, false>": 131072, "lsa::plicp_kernel<128, 4, false>": 131072, "lsa::plicp_kernel<128, 3, false>": 131072,
          "lsa::preprocess_lanes_kernel": 16384, "lsa::grid_binned_kernel": 2048, "lsa::grid_prep_kernel": 2048, "lsa::grid_prob_kernel": 1}
 
 
@@ -116,6 +116,6 @@ for a, b in (("bench_profiled.json", "bench_profiled.json"), ("bench_default.jso
         shutil.copy("%s/%s" % (src, a), "profiles/%s_%s" % (rnd, b))
     except OSError:
         pass
-for k in ("lsa::icp_kernel<1081, 256>", "lsa::psm_kernel<1081>", "lsa::plicp_kernel<256, 3, false>", "lsa::plicp_kernel<128, 4, false>", "lsa::p2p_icp_kernel<128>", "lsa::icp_kernel<361, 128>", "lsa::psm_kernel<361>", "lsa::icp_kernel<181, 64>"):
+for k in ("lsa::icp_kernel<1081, 256>", "lsa::psm_kernel<1081, 256>", "lsa::plicp_kernel<256, 3, false>", "lsa::plicp_kernel<128, 4, false>", "lsa::p2p_icp_kernel<128>", "lsa::icp_kernel<361, 128>", "lsa::psm_kernel<361, 64>", "lsa::icp_kernel<181, 64>"):
     print(k, {c: "%.4g" % v for c, v in hbm.get(k, {}).items()}, {c: "%.4g" % v for c, v in sq.get(k, {}).items()})
 print("score:", {c: ("%.4g" % v if isinstance(v, float) else v) for c, v in sc.items() if c != "_note"})
