@@ -1372,16 +1372,16 @@ static void p2p_launch(lsa_ctx* c, int max_points, const lsa::P2PParam& P_, int 
                        double* out, int n_cur_shared)
 {
     const int cap = lsa::p2p_cap_for(max_points);
-    // width by the largest cloud - or, for a handful of problems (a lone ICPMatch call: latency is all that counts), four waves
-    // whatever the clouds: the sums are formed the same way at every width (p2p_sums), so the result does not depend on it
-    const int T = B <= 2 * c->n_cu ? 256 : lsa::p2p_threads(max_points);
+    // width by the largest cloud - or, for a handful of problems (a lone ICPMatch call: latency is all that counts), four to
+    // sixteen waves whatever the clouds: the sums are formed the same way at every width (p2p_sums), so the result does not depend on it
+    const int T = B <= 2 * c->n_cu ? (max_points > 512 ? 1024 : max_points > 256 ? 512 : 256) : lsa::p2p_threads(max_points);      // (a lone problem's points in one trip up to 1024)
     const size_t lds = (size_t)lsa::p2p_lds_bytes(cap);
     lsa::P2PParam P = P_;
     const char* ax = getenv("LSA_P2P_AXIS");                 // test hook: the pairs must not depend on the sort axis
     P.axis = ax && *ax ? atoi(ax) : -1;
 #define LSA_P2P_GO(TT) hipLaunchKernelGGL((lsa::p2p_icp_kernel<TT>), dim3(B), dim3(TT), lds, c->stream, P, B, rx, ry, roff, cx, cy, coff, init, \
                                           owner, match, out, n_cur_shared, cap)
-    if (T == 64) LSA_P2P_GO(64); else if (T == 128) LSA_P2P_GO(128); else LSA_P2P_GO(256);
+    if (T == 64) LSA_P2P_GO(64); else if (T == 128) LSA_P2P_GO(128); else if (T == 256) LSA_P2P_GO(256); else if (T == 512) LSA_P2P_GO(512); else LSA_P2P_GO(1024);
 #undef LSA_P2P_GO
 }
 

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(T) void p2p_icp_kernel(
     int* lmatch = (int*)(lowner + p2p_local_cap(cap));
     float2* cpts = (float2*)(lmatch + p2p_local_cap(cap));                   // small problems: the second map's points (every iteration reads them twice)
     uint2* ku = (uint2*)(cpts + p2p_local_cap(cap));                         // projection (float bits) and original index of the sorted first-map points
-    __shared__ double sh[40];
+    __shared__ double sh[136];                                                // sums of four virtual waves; the axis choice's per-wave extents (T / 64 x 16 floats)
     const int tid = threadIdx.x;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const int r0 = ref_off[b], n1 = ref_off[b + 1] - r0;
