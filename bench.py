@@ -608,7 +608,7 @@ def secondary_latency(torch, capi, raw1081):
     from laser_slam_amd import synth
     res = {}
     cases = [("fr079", "LMS511", "fr079_head.log", "ROBOTLASER1"), ("intel", "LMS211", "intel_head.log", "ROBOTLASER1"),
-             ("indoor", "LMS151", "indoor_head.txt", "LMS151"), ("syn1081", None, None, None)]
+             ("mit", "LMS511", "mit_head.log", "ROBOTLASER1"), ("indoor", "LMS151", "indoor_head.txt", "LMS151"), ("syn1081", None, None, None)]
     for name, preset, fname, tag in cases:
         if preset is None:
             p = capi.param_make(**synth.SYN1081); r = raw1081[:60]; bad = np.zeros(r.shape, np.int32)
@@ -635,7 +635,8 @@ def secondary_latency(torch, capi, raw1081):
             tp.append(time.perf_counter() - t0); its.append(o[5])
         ctx.close()
         q = lambda v: {"median_us": float(np.median(v)) * 1e6, "p95_us": float(np.percentile(v, 95)) * 1e6, "max_us": float(np.max(v)) * 1e6}
-        res[name] = {"beams": n, "calls": len(tf), "CPolarMatch_FMatch": q(tf), "CCanonicalMatcher_FMatch": dict(q(tp), mean_iterations=float(np.mean(its)))}
+        res[name] = {"beams": n, "calls": len(tf), "CPolarMatch_FMatch": q(tf),
+                     "CCanonicalMatcher_FMatch": dict(q(tp), mean_iterations=float(np.mean(its)), restarting_calls_frac=float(np.mean(np.array(its) > 10)))}
     q = lambda v: {"median_us": float(np.median(v)) * 1e6, "p95_us": float(np.percentile(v, 95)) * 1e6, "max_us": float(np.max(v)) * 1e6}
     # a lone CPMap::updateMap (drawmap / mapGraph insert a scan at a time): one 1081-beam scan into 4096^2 at 5 cm
     p = capi.param_make(**synth.SYN1081); ctx = capi.Context(p)

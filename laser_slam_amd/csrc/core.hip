@@ -239,7 +239,7 @@ static int ensure_staging(lsa_ctx* c)
     c->off_seg = sizeof(float) * 2 * (size_t)n;
     c->off_bad = c->off_seg + sizeof(uint16_t) * 2 * (size_t)n;
     c->off_small = (c->off_bad + 2 * (size_t)n + 15) & ~(size_t)15;
-    c->off_ismall = c->off_small + sizeof(float) * 48;                  // small[16..21]: min/max slots of lsa_pf_roughen; the point-to-line ICP's 17 doubles
+    c->off_ismall = c->off_small + sizeof(float) * 176;                  // small[16..21]: min/max slots of lsa_pf_roughen; the point-to-line ICP's 17 doubles + 6 x 8 of a lone call's restarts
     c->off_idx = c->off_ismall + sizeof(int) * 4;
     c->stage_bytes = c->off_idx + sizeof(int) * 2;
     HIP_TRY(hipMalloc((void**)&c->d_stage, c->stage_bytes));
@@ -1656,8 +1656,9 @@ static int plicp_dispatch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const flo
 }
 }   // extern "C++"
 
-int lsa_plicp_batch_cov(lsa_ctx* c, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
-                        const lsa_plicp_options* opt, double sigma, double* d_out8, double* d_cov9)
+// phase: lsa::PlicpParam::phase (0 = the whole matcher per pair; 1 / 2: first run / one restart per item - the lone-call path)
+static int plicp_run(lsa_ctx* c, int phase, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
+                     const lsa_plicp_options* opt, double sigma, double* d_out8, double* d_cov9)
 {
     if (!c || !d_r || !d_ref_idx || !d_act_idx || !d_out8) return fail(LSA_E_ARG, "null argument");
     if (B <= 0) return LSA_OK;
@@ -1673,6 +1674,7 @@ int lsa_plicp_batch_cov(lsa_ctx* c, int B, const float* d_r, const int32_t* d_re
     P.restart_threshold_mean_error = o.restart_threshold_mean_error; P.restart_dt = o.restart_dt; P.restart_dtheta = o.restart_dtheta;
     P.outliers_maxPerc = o.outliers_maxPerc; P.outliers_adaptive_order = o.outliers_adaptive_order;
     P.outliers_adaptive_mult = o.outliers_adaptive_mult; P.outliers_remove_doubles = o.outliers_remove_doubles;
+    P.phase = phase;
     if (!c->d_trig) {
         // The bearings' cosines and sines come from the host's libm once per context: CSM computes the scans' Cartesian
         // points on the CPU, and range-quantised scans hold many exactly symmetric neighbour pairs whose nearer-of-two
@@ -1684,6 +1686,16 @@ int lsa_plicp_batch_cov(lsa_ctx* c, int B, const float* d_r, const int32_t* d_re
     }
     if (d_cov9) return plicp_dispatch<true>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9);
     return plicp_dispatch<false>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, 0.0, nullptr);
+}
+int lsa_plicp_batch_cov(lsa_ctx* c, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
+                        const lsa_plicp_options* opt, double sigma, double* d_out8, double* d_cov9)
+{
+    return plicp_run(c, 0, B, d_r, d_ref_idx, d_act_idx, opt, sigma, d_out8, d_cov9);
+}
+static int plicp_phase(lsa_ctx* c, int phase, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
+                       const lsa_plicp_options* opt, double* d_out8)
+{
+    return plicp_run(c, phase, B, d_r, d_ref_idx, d_act_idx, opt, 0.0, d_out8, nullptr);
 }
 
 int lsa_plicp_batch(lsa_ctx* c, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
@@ -1704,6 +1716,31 @@ int lsa_plicp_host_cov(lsa_ctx* c, const float* ref_r, const float* cur_r, const
     memcpy(c->h_stage + sizeof(float) * (size_t)n, cur_r, sizeof(float) * n);
     HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
     double* d_out = (double*)c->d_small;
+    if (!cov9) {
+        // A lone call: a pair that restarts (mean error above the threshold: six more loops from perturbed poses) would walk
+        // seven loops in one workgroup - 2 ms where the first takes 0.3.  The first run alone, then, if it asks for them, the
+        // six restarts on six workgroups at once (they are independent: a run depends on its start alone), and the winner
+        // picked here in the kernel's order.  Same bits as the one-workgroup form (tests/test_gpu_plicp.py).
+        rc = plicp_phase(c, 1, 1, c->d_r, c->d_idx, c->d_idx + 1, opt, d_out); if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(c->h_stage + c->off_small, c->d_small, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        double first[8];
+        memcpy(first, c->h_stage + c->off_small, sizeof first);
+        if (first[3] == 1 && first[7] == 1) {
+            rc = plicp_phase(c, 2, 6, c->d_r, c->d_idx, c->d_idx + 1, opt, d_out); if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(c->h_stage + c->off_small, d_out + 8, sizeof(double) * 48, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const double* r = (const double*)(c->h_stage + c->off_small);
+            for (int a = 0; a < 6; ++a) {
+                if (r[8 * a + 3] != 1) continue;
+                first[5] += r[8 * a + 5];
+                if (r[8 * a + 4] < first[4]) { first[0] = r[8 * a]; first[1] = r[8 * a + 1]; first[2] = r[8 * a + 2]; first[4] = r[8 * a + 4]; }
+            }
+        }
+        first[7] = 0;
+        memcpy(out8, first, sizeof first);
+        return LSA_OK;
+    }
     rc = lsa_plicp_batch_cov(c, 1, c->d_r, c->d_idx, c->d_idx + 1, opt, sigma, d_out, cov9 ? d_out + 8 : nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(c->h_stage + c->off_small, c->d_small, sizeof(double) * 17, hipMemcpyDeviceToHost, c->stream));

@@ -24,6 +24,8 @@ struct PlicpParam {
     double restart_threshold_mean_error, restart_dt, restart_dtheta;
     double outliers_maxPerc, outliers_adaptive_order, outliers_adaptive_mult;
     int outliers_remove_doubles;
+    int phase;      // 0: a pair's first run and, if need be, its six restarts in one workgroup; 1: the first run only (out8[7] = 1: wants
+                    // the restarts); 2: item b = restart b % 6 of pair b / 6 from the first run's result in out8 (the host's lone-call path)
 };
 
 constexpr int PLICP_THREADS = 256;     // the widest workgroup
@@ -692,8 +694,9 @@ __global__ __launch_bounds__(T, WG) void plicp_kernel(PlicpParam P, int B, const
         __syncthreads();
         if (tid == 0) *claim = (int)atomicAdd(queue, 1u);
         __syncthreads();
-        const int b = *claim;
-        if (b >= B) break;
+        const int item = *claim;
+        if (item >= B) break;
+        const int b = P.phase == 2 ? item / 6 : item;    // the pair
         for (int i = tid; i < n; i += T) {                   // fromPMScan2LDP (:191-227) + ld_compute_cartesian
             const double cth = trig[i], sth = trig[n + i];             // cos | sin of float(fi_min + dfi i), from the host's libm
             for (int w = 0; w < 2; ++w) {
@@ -722,6 +725,22 @@ __global__ __launch_bounds__(T, WG) void plicp_kernel(PlicpParam P, int B, const
         double x[3] = {0, 0, 0}, best[3] = {0, 0, 0}, best_error = 0, res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int nvalid = 0, iters = 0, runs = 1;
         bool ok_first = false, restarted = false;
+        if (P.phase == 2) {
+            // one restart of a pair whose first run is on record: out8[8 pair ..] holds it, out8[8 (B0 + item) ..] takes this run's
+            // x, y, theta, ok, error, iterations (B0 = pairs of the call; the host picks the winner in the order a = 0 .. 5)
+            const int a = item % 6;
+            const double* first = out8 + 8 * (size_t)b;
+            const double dt = P.restart_dt, dth = P.restart_dtheta;
+            const double start[3] = {first[0] + (a == 0 ? dt : a == 1 ? -dt : 0.0), first[1] + (a == 2 ? dt : a == 3 ? -dt : 0.0),
+                                     first[2] + (a == 4 ? dth : a == 5 ? -dth : 0.0)};
+            double xa[3] = {0, 0, 0}, my_error = 0;
+            int my_valid = 0, my_iters = 0;
+            __syncthreads();
+            const bool ok = plicp_loop<T>(P, L, start, xa, my_error, my_valid, my_iters);
+            double* o = out8 + 8 * (size_t)(B / 6 + item);
+            if (tid == 0) { o[0] = xa[0]; o[1] = xa[1]; o[2] = xa[2]; o[3] = ok ? 1 : 0; o[4] = my_error; o[5] = my_iters; o[6] = my_valid; o[7] = 0; }
+            continue;
+        }
         for (int a = -1; a < runs - 1; ++a) {
             const double dt = P.restart_dt, dth = P.restart_dtheta;
             const double start[3] = {x[0] + (a == 0 ? dt : a == 1 ? -dt : 0.0), x[1] + (a == 2 ? dt : a == 3 ? -dt : 0.0),
@@ -736,7 +755,10 @@ __global__ __launch_bounds__(T, WG) void plicp_kernel(PlicpParam P, int B, const
                 ok_first = true;
                 x[0] = plicp_uniform(xa[0]); x[1] = plicp_uniform(xa[1]); x[2] = plicp_uniform(xa[2]);
                 best[0] = x[0]; best[1] = x[1]; best[2] = x[2]; best_error = plicp_uniform(my_error); nvalid = my_valid;
-                if (P.restart && my_error / my_valid > P.restart_threshold_mean_error) { restarted = true; runs = 7; }
+                if (P.restart && my_error / my_valid > P.restart_threshold_mean_error) {
+                    if (P.phase == 1) res[7] = 1;       // (the caller runs the restarts, six workgroups at once)
+                    else { restarted = true; runs = 7; }
+                }
             } else if (ok) {
                 iters += my_iters;
                 if (my_error < best_error) { best_error = plicp_uniform(my_error); best[0] = plicp_uniform(xa[0]); best[1] = plicp_uniform(xa[1]); best[2] = plicp_uniform(xa[2]); }

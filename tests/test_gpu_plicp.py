@@ -74,6 +74,11 @@ def test_plicp_restart_path():
         assert np.allclose(got[b, :3], want[:3], atol=5e-6) and abs(got[b, 4] - want[4]) <= 1e-6 * want[4]
         restarted += want[5] > 10
     assert restarted >= B // 2
+    # the host entry point runs a restarting pair's six restarts on six workgroups at once and picks the winner itself:
+    # the same bits as the one-workgroup form of the batch
+    for b in range(B):
+        one = capi.plicp_host(ctx, raw[b], raw[b + 1])
+        assert np.array_equal(one, got[b]), (b, one, got[b])
     ctx.close()
 
 
