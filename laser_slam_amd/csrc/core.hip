@@ -1604,7 +1604,7 @@ int lsa_plicp_options_default(lsa_plicp_options* o)                  // ZHCanoni
 }
 
 extern "C++" {
-template <int T, int WG, bool COV>
+template <int T, int WG, bool COV, int PHASE>
 static int plicp_launch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
                         double* d_out8, double sigma, double* d_cov9)
 {
@@ -1612,7 +1612,8 @@ static int plicp_launch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const float
         static std::atomic<unsigned long long> done{0};
         const unsigned long long bit = 1ull << (c->device & 63);
         if (!(done.load(std::memory_order_acquire) & bit)) {
-            HIP_TRY(hipFuncSetAttribute((const void*)lsa::plicp_kernel<T, WG, COV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (PHASE == 0) HIP_TRY(hipFuncSetAttribute((const void*)lsa::plicp_kernel<T, WG, COV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            else HIP_TRY(hipFuncSetAttribute((const void*)lsa::plicp_lone_kernel<T, WG, (PHASE ? PHASE : 1)>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             done.fetch_or(bit, std::memory_order_release);
         }
     }
@@ -1624,20 +1625,25 @@ static int plicp_launch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const float
     static std::atomic<int> occ_lds[64];
     int occ = occ_cache[c->device & 63].load();
     if (!occ || occ_lds[c->device & 63].load() != lds) {
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lsa::plicp_kernel<T, WG, COV>, T, lds));
+        if (PHASE == 0) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lsa::plicp_kernel<T, WG, COV>, T, lds));
+        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lsa::plicp_lone_kernel<T, WG, (PHASE ? PHASE : 1)>, T, lds));
         if (occ < 1) occ = 1;
         occ_cache[c->device & 63].store(occ); occ_lds[c->device & 63].store(lds);
     }
     const long long resident = (long long)occ * c->n_cu;
     HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL((lsa::plicp_kernel<T, WG, COV>), dim3((unsigned)(B < resident ? B : resident)), dim3(T), lds, c->stream, P, B, d_r,
-                       d_ref_idx, d_act_idx, c->d_trig, d_out8, sigma, d_cov9, c->d_queue);
+    if (PHASE == 0)
+        hipLaunchKernelGGL((lsa::plicp_kernel<T, WG, COV>), dim3((unsigned)(B < resident ? B : resident)), dim3(T), lds, c->stream, P, B, d_r,
+                           d_ref_idx, d_act_idx, c->d_trig, d_out8, sigma, d_cov9, c->d_queue);
+    else
+        hipLaunchKernelGGL((lsa::plicp_lone_kernel<T, WG, (PHASE ? PHASE : 1)>), dim3((unsigned)(B < resident ? B : resident)), dim3(T), lds, c->stream, P, B, d_r,
+                           d_ref_idx, d_act_idx, c->d_trig, d_out8, c->d_queue);
     HIP_TRY(hipGetLastError());
     return LSA_OK;
 }
 // workgroup width by scan size (plicp_threads), register budget by what the LDS lets a CU hold: four waves per SIMD (128
 // registers) when at least sixteen waves fit, three (168) otherwise
-template <bool COV>
+template <bool COV, int PHASE>
 static int plicp_dispatch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
                           double* d_out8, double sigma, double* d_cov9)
 {
@@ -1647,7 +1653,7 @@ static int plicp_dispatch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const flo
 #define LSA_PLICP_FOUR_MIN 16
 #endif
     const bool four = wgs * (T / 64) >= LSA_PLICP_FOUR_MIN;
-#define LSA_PLICP_GO(TT, WW) return plicp_launch<TT, WW, COV>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9)
+#define LSA_PLICP_GO(TT, WW) return plicp_launch<TT, WW, COV, PHASE>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9)
     if (T == 64) { if (four) LSA_PLICP_GO(64, 4); LSA_PLICP_GO(64, 3); }
     if (T == 128) { if (four) LSA_PLICP_GO(128, 4); LSA_PLICP_GO(128, 3); }
     if (four) LSA_PLICP_GO(256, 4);
@@ -1656,7 +1662,7 @@ static int plicp_dispatch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const flo
 }
 }   // extern "C++"
 
-// phase: lsa::PlicpParam::phase (0 = the whole matcher per pair; 1 / 2: first run / one restart per item - the lone-call path)
+// phase: plicp_pairs' PHASE (0 = the whole matcher per pair; 1 / 2: first run / one restart per item - the lone-call path)
 static int plicp_run(lsa_ctx* c, int phase, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
                      const lsa_plicp_options* opt, double sigma, double* d_out8, double* d_cov9)
 {
@@ -1674,7 +1680,6 @@ static int plicp_run(lsa_ctx* c, int phase, int B, const float* d_r, const int32
     P.restart_threshold_mean_error = o.restart_threshold_mean_error; P.restart_dt = o.restart_dt; P.restart_dtheta = o.restart_dtheta;
     P.outliers_maxPerc = o.outliers_maxPerc; P.outliers_adaptive_order = o.outliers_adaptive_order;
     P.outliers_adaptive_mult = o.outliers_adaptive_mult; P.outliers_remove_doubles = o.outliers_remove_doubles;
-    P.phase = phase;
     if (!c->d_trig) {
         // The bearings' cosines and sines come from the host's libm once per context: CSM computes the scans' Cartesian
         // points on the CPU, and range-quantised scans hold many exactly symmetric neighbour pairs whose nearer-of-two
@@ -1684,8 +1689,10 @@ static int plicp_run(lsa_ctx* c, int phase, int B, const float* d_r, const int32
         HIP_TRY(hipMalloc((void**)&c->d_trig, sizeof(double) * t.size()));
         HIP_TRY(hipMemcpy(c->d_trig, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
     }
-    if (d_cov9) return plicp_dispatch<true>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9);
-    return plicp_dispatch<false>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, 0.0, nullptr);
+    if (d_cov9) return plicp_dispatch<true, 0>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9);
+    if (phase == 1) return plicp_dispatch<false, 1>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, 0.0, nullptr);
+    if (phase == 2) return plicp_dispatch<false, 2>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, 0.0, nullptr);
+    return plicp_dispatch<false, 0>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, 0.0, nullptr);
 }
 int lsa_plicp_batch_cov(lsa_ctx* c, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
                         const lsa_plicp_options* opt, double sigma, double* d_out8, double* d_cov9)

@@ -24,8 +24,6 @@ struct PlicpParam {
     double restart_threshold_mean_error, restart_dt, restart_dtheta;
     double outliers_maxPerc, outliers_adaptive_order, outliers_adaptive_mult;
     int outliers_remove_doubles;
-    int phase;      // 0: a pair's first run and, if need be, its six restarts in one workgroup; 1: the first run only (out8[7] = 1: wants
-                    // the restarts); 2: item b = restart b % 6 of pair b / 6 from the first run's result in out8 (the host's lone-call path)
 };
 
 constexpr int PLICP_THREADS = 256;     // the widest workgroup
@@ -668,11 +666,14 @@ __device__ void plicp_covariance(const PlicpParam& P, const PlicpLds& L, const f
 // WG = workgroups per CU the registers are budgeted for: 4 wherever the LDS allows four (up to 541 beams); beyond that the
 // LDS holds three at most, and the instance budgeted for three (168 registers instead of 128) keeps in registers what the
 // four-per-CU budget spills to scratch (540 B per lane there).  COV: also sm_icp's covariance of the result (d_cov9).
-template <int T, int WG, bool COV>
-__global__ __launch_bounds__(T, WG) void plicp_kernel(PlicpParam P, int B, const float* __restrict__ g_r,
-                                                              const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
-                                                              const double* __restrict__ trig, double* __restrict__ out8,
-                                                              double sigma, double* __restrict__ cov9, unsigned int* __restrict__ queue)
+// PHASE (the lone-call path of lsa_plicp_host, kernels of their own so that the batch's instance is what it was): 0 = a pair's
+// first run and, if need be, its six restarts; 1 = the first run only (out8[7] = 1: wants the restarts); 2 = item b is restart
+// b % 6 of pair b / 6 from the first run's record in out8.
+template <int T, int WG, bool COV, int PHASE>
+__device__ __forceinline__ void plicp_pairs(const PlicpParam& P, int B, const float* __restrict__ g_r,
+                                            const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
+                                            const double* __restrict__ trig, double* out8,
+                                            double sigma, double* __restrict__ cov9, unsigned int* __restrict__ queue)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = P.n, Np = (n + 63) & ~63, tid = threadIdx.x;
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(T, WG) void plicp_kernel(PlicpParam P, int B, const
         __syncthreads();
         const int item = *claim;
         if (item >= B) break;
-        const int b = P.phase == 2 ? item / 6 : item;    // the pair
+        const int b = PHASE == 2 ? item / 6 : item;      // the pair
         for (int i = tid; i < n; i += T) {                   // fromPMScan2LDP (:191-227) + ld_compute_cartesian
             const double cth = trig[i], sth = trig[n + i];             // cos | sin of float(fi_min + dfi i), from the host's libm
             for (int w = 0; w < 2; ++w) {
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(T, WG) void plicp_kernel(PlicpParam P, int B, const
         double x[3] = {0, 0, 0}, best[3] = {0, 0, 0}, best_error = 0, res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int nvalid = 0, iters = 0, runs = 1;
         bool ok_first = false, restarted = false;
-        if (P.phase == 2) {
+        if (PHASE == 2) {
             // one restart of a pair whose first run is on record: out8[8 pair ..] holds it, out8[8 (B0 + item) ..] takes this run's
             // x, y, theta, ok, error, iterations (B0 = pairs of the call; the host picks the winner in the order a = 0 .. 5)
             const int a = item % 6;
@@ -756,7 +757,7 @@ __global__ __launch_bounds__(T, WG) void plicp_kernel(PlicpParam P, int B, const
                 x[0] = plicp_uniform(xa[0]); x[1] = plicp_uniform(xa[1]); x[2] = plicp_uniform(xa[2]);
                 best[0] = x[0]; best[1] = x[1]; best[2] = x[2]; best_error = plicp_uniform(my_error); nvalid = my_valid;
                 if (P.restart && my_error / my_valid > P.restart_threshold_mean_error) {
-                    if (P.phase == 1) res[7] = 1;       // (the caller runs the restarts, six workgroups at once)
+                    if (PHASE == 1) res[7] = 1;         // (the caller runs the restarts, six workgroups at once)
                     else { restarted = true; runs = 7; }
                 }
             } else if (ok) {
@@ -779,6 +780,22 @@ __global__ __launch_bounds__(T, WG) void plicp_kernel(PlicpParam P, int B, const
         } else res[5] = iters;
         if (tid < 8) out8[8 * (size_t)b + tid] = res[tid];
     }
+}
+
+template <int T, int WG, bool COV>
+__global__ __launch_bounds__(T, WG) void plicp_kernel(PlicpParam P, int B, const float* __restrict__ g_r,
+                                                              const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
+                                                              const double* __restrict__ trig, double* __restrict__ out8,
+                                                              double sigma, double* __restrict__ cov9, unsigned int* __restrict__ queue)
+{
+    plicp_pairs<T, WG, COV, 0>(P, B, g_r, ref_idx, act_idx, trig, out8, sigma, cov9, queue);
+}
+template <int T, int WG, int PHASE>
+__global__ __launch_bounds__(T, WG) void plicp_lone_kernel(PlicpParam P, int B, const float* __restrict__ g_r,
+                                                                   const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
+                                                                   const double* __restrict__ trig, double* out8, unsigned int* __restrict__ queue)
+{
+    plicp_pairs<T, WG, false, PHASE>(P, B, g_r, ref_idx, act_idx, trig, out8, 0.0, nullptr, queue);
 }
 
 } // namespace lsa
