@@ -1,9 +1,10 @@
 // pm_icp (src/zhpsm/ZHPolar_Match.cpp:1653-2021) on gfx950, included from
 // match_kernels.hip inside namespace lsa.
 //
-// One 256-thread workgroup (4 waves) per scan pair, 7 workgroups per CU at 1081 beams (8 up to 541):
+// One workgroup per scan pair - for batches one wave at 181 beams, two at 361 / 541, four at 1081 (7 workgroups per CU there);
+// for a handful of pairs four to sixteen (icp_threads_wide: a lone FMatch call, where latency is all that counts):
 //  - order-free phases (projection, scatter-min, nearest neighbour, interpolation,
-//    products) use all 256 lanes;
+//    products) use all lanes;
 //  - order-bound phases (list compaction, the ordered FP32 sums of the rigid fit) run in wave 0 while
 //    the other waves of the pair wait at a barrier and the CU's other pairs fill the SIMDs.
 //
@@ -23,7 +24,7 @@
 // Last iteration's match per beam (the NN seed) lives in registers: a thread always handles the
 // same beams.
 
-constexpr int ICP_THREADS = 256;     // the largest workgroup (1081 beams, the size-generic instance)
+constexpr int ICP_THREADS = 256;     // the largest workgroup of the batch instances (1081 beams, the size-generic instance)
 // Threads per pair by sensor size: the order-free phases cover a scan 64 x waves beams at a time, the order-bound ones run
 // on one wave while the pair's other waves wait - so a workgroup should not be wider than the scan needs.  181 beams (LMS211)
 // get ONE wave (three trips, no workgroup barrier at all: 3.66 -> 5.93 M matches/s on intel-lab's head), 361 and 541 (LMS511,
