@@ -22,7 +22,7 @@ def device_asm():
     return os.path.join(ROOT, "build_ab", "core.s")
 
 
-@pytest.mark.parametrize("prefix", ["_ZN3lsa10icp_kernelILi", "_ZN3lsa10psm_kernelILi", "_ZN3lsa12plicp_kernelILi", "_ZN3lsa15pf_score_kernelILb",
+@pytest.mark.parametrize("prefix", ["_ZN3lsa10icp_kernelILi", "_ZN3lsa10psm_kernelILi", "_ZN3lsa12plicp_kernelILi", "_ZN3lsa17plicp_lone_kernelILi", "_ZN3lsa15pf_score_kernelILb",
                                     "_ZN3lsa14p2p_icp_kernel"])
 def test_parked_scalars_are_handled_soundly(device_asm, prefix):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sgpr_spill_check.py"), device_asm, prefix], capture_output=True, text=True)
