@@ -627,6 +627,11 @@ def secondary_latency(torch, capi, raw1081):
             t0 = time.perf_counter()
             _, _, _, cur = ctx.fmatch_host(cur, [r[k].copy(), bad[k].astype(np.int32), z.copy()], False)
             tf.append(time.perf_counter() - t0)
+        # a lone CPolarMatch::pm_psm (the public method, e.g. src/zhpsm/test.cpp) on preprocessed scans
+        pre = [ctx.preprocess_host(r[k], bad[k].astype(np.int32)) for k in range(min(S, 30))]
+        tq = []
+        for k in range(1, len(pre)):
+            t0 = time.perf_counter(); ctx.match_host(0, pre[k - 1], pre[k]); tq.append(time.perf_counter() - t0)
         capi.plicp_host(ctx, r[0], r[1])
         its = []
         for k in range(2, min(S, 60)):
@@ -635,7 +640,7 @@ def secondary_latency(torch, capi, raw1081):
             tp.append(time.perf_counter() - t0); its.append(o[5])
         ctx.close()
         q = lambda v: {"median_us": float(np.median(v)) * 1e6, "p95_us": float(np.percentile(v, 95)) * 1e6, "max_us": float(np.max(v)) * 1e6}
-        res[name] = {"beams": n, "calls": len(tf), "CPolarMatch_FMatch": q(tf),
+        res[name] = {"beams": n, "calls": len(tf), "CPolarMatch_FMatch": q(tf), "CPolarMatch_pm_psm": q(tq[3:]),
                      "CCanonicalMatcher_FMatch": dict(q(tp), mean_iterations=float(np.mean(its)), restarting_calls_frac=float(np.mean(np.array(its) > 10)))}
     q = lambda v: {"median_us": float(np.median(v)) * 1e6, "p95_us": float(np.percentile(v, 95)) * 1e6, "max_us": float(np.max(v)) * 1e6}
     # a lone CPMap::updateMap (drawmap / mapGraph insert a scan at a time): one 1081-beam scan into 4096^2 at 5 cm
