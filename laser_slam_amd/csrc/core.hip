@@ -1613,7 +1613,7 @@ static int plicp_launch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const float
         const unsigned long long bit = 1ull << (c->device & 63);
         if (!(done.load(std::memory_order_acquire) & bit)) {
             if (PHASE == 0) HIP_TRY(hipFuncSetAttribute((const void*)lsa::plicp_kernel<T, WG, COV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            else HIP_TRY(hipFuncSetAttribute((const void*)lsa::plicp_lone_kernel<T, WG, (PHASE ? PHASE : 1)>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            else HIP_TRY(hipFuncSetAttribute((const void*)lsa::plicp_lone_kernel<T, WG, COV, (PHASE ? PHASE : 1)>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             done.fetch_or(bit, std::memory_order_release);
         }
     }
@@ -1626,7 +1626,7 @@ static int plicp_launch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const float
     int occ = occ_cache[c->device & 63].load();
     if (!occ || occ_lds[c->device & 63].load() != lds) {
         if (PHASE == 0) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lsa::plicp_kernel<T, WG, COV>, T, lds));
-        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lsa::plicp_lone_kernel<T, WG, (PHASE ? PHASE : 1)>, T, lds));
+        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lsa::plicp_lone_kernel<T, WG, COV, (PHASE ? PHASE : 1)>, T, lds));
         if (occ < 1) occ = 1;
         occ_cache[c->device & 63].store(occ); occ_lds[c->device & 63].store(lds);
     }
@@ -1636,8 +1636,8 @@ static int plicp_launch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const float
         hipLaunchKernelGGL((lsa::plicp_kernel<T, WG, COV>), dim3((unsigned)(B < resident ? B : resident)), dim3(T), lds, c->stream, P, B, d_r,
                            d_ref_idx, d_act_idx, c->d_trig, d_out8, sigma, d_cov9, c->d_queue);
     else
-        hipLaunchKernelGGL((lsa::plicp_lone_kernel<T, WG, (PHASE ? PHASE : 1)>), dim3((unsigned)(B < resident ? B : resident)), dim3(T), lds, c->stream, P, B, d_r,
-                           d_ref_idx, d_act_idx, c->d_trig, d_out8, c->d_queue);
+        hipLaunchKernelGGL((lsa::plicp_lone_kernel<T, WG, COV, (PHASE ? PHASE : 1)>), dim3((unsigned)(B < resident ? B : resident)), dim3(T), lds, c->stream, P, B, d_r,
+                           d_ref_idx, d_act_idx, c->d_trig, d_out8, sigma, d_cov9, c->d_queue);
     HIP_TRY(hipGetLastError());
     return LSA_OK;
 }
@@ -1689,6 +1689,8 @@ static int plicp_run(lsa_ctx* c, int phase, int B, const float* d_r, const int32
         HIP_TRY(hipMalloc((void**)&c->d_trig, sizeof(double) * t.size()));
         HIP_TRY(hipMemcpy(c->d_trig, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
     }
+    if (d_cov9 && phase == 1) return plicp_dispatch<true, 1>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9);
+    if (d_cov9 && phase == 3) return plicp_dispatch<true, 3>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9);
     if (d_cov9) return plicp_dispatch<true, 0>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, sigma, d_cov9);
     if (phase == 1) return plicp_dispatch<false, 1>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, 0.0, nullptr);
     if (phase == 2) return plicp_dispatch<false, 2>(c, P, B, d_r, d_ref_idx, d_act_idx, d_out8, 0.0, nullptr);
@@ -1698,11 +1700,6 @@ int lsa_plicp_batch_cov(lsa_ctx* c, int B, const float* d_r, const int32_t* d_re
                         const lsa_plicp_options* opt, double sigma, double* d_out8, double* d_cov9)
 {
     return plicp_run(c, 0, B, d_r, d_ref_idx, d_act_idx, opt, sigma, d_out8, d_cov9);
-}
-static int plicp_phase(lsa_ctx* c, int phase, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
-                       const lsa_plicp_options* opt, double* d_out8)
-{
-    return plicp_run(c, phase, B, d_r, d_ref_idx, d_act_idx, opt, 0.0, d_out8, nullptr);
 }
 
 int lsa_plicp_batch(lsa_ctx* c, int B, const float* d_r, const int32_t* d_ref_idx, const int32_t* d_act_idx,
@@ -1723,36 +1720,39 @@ int lsa_plicp_host_cov(lsa_ctx* c, const float* ref_r, const float* cur_r, const
     memcpy(c->h_stage + sizeof(float) * (size_t)n, cur_r, sizeof(float) * n);
     HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
     double* d_out = (double*)c->d_small;
-    if (!cov9) {
-        // A lone call: a pair that restarts (mean error above the threshold: six more loops from perturbed poses) would walk
-        // seven loops in one workgroup - 2 ms where the first takes 0.3.  The first run alone, then, if it asks for them, the
-        // six restarts on six workgroups at once (they are independent: a run depends on its start alone), and the winner
-        // picked here in the kernel's order.  Same bits as the one-workgroup form (tests/test_gpu_plicp.py).
-        rc = plicp_phase(c, 1, 1, c->d_r, c->d_idx, c->d_idx + 1, opt, d_out); if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(c->h_stage + c->off_small, c->d_small, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        double first[8];
-        memcpy(first, c->h_stage + c->off_small, sizeof first);
-        if (first[3] == 1 && first[7] == 1) {
-            rc = plicp_phase(c, 2, 6, c->d_r, c->d_idx, c->d_idx + 1, opt, d_out); if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(c->h_stage + c->off_small, d_out + 8, sizeof(double) * 48, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            const double* r = (const double*)(c->h_stage + c->off_small);
-            for (int a = 0; a < 6; ++a) {
-                if (r[8 * a + 3] != 1) continue;
-                first[5] += r[8 * a + 5];
-                if (r[8 * a + 4] < first[4]) { first[0] = r[8 * a]; first[1] = r[8 * a + 1]; first[2] = r[8 * a + 2]; first[4] = r[8 * a + 4]; }
-            }
-        }
-        first[7] = 0;
-        memcpy(out8, first, sizeof first);
-        return LSA_OK;
-    }
-    rc = lsa_plicp_batch_cov(c, 1, c->d_r, c->d_idx, c->d_idx + 1, opt, sigma, d_out, cov9 ? d_out + 8 : nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(c->h_stage + c->off_small, c->d_small, sizeof(double) * 17, hipMemcpyDeviceToHost, c->stream));
+    double* d_cov = d_out + 8 + 48;                      // (behind the record and the six restarts' records)
+    // A lone call: a pair that restarts (mean error above the threshold: six more loops from perturbed poses) would walk
+    // seven loops in one workgroup - 2 ms where the first takes 0.3.  The first run alone, then, if it asks for them, the
+    // six restarts on six workgroups at once (they are independent: a run depends on its start alone), the winner picked
+    // here in the kernel's order, and - if asked for - the covariance at the winner (sm_icp recomputes the correspondences
+    // there).  Same bits as the one-workgroup form (tests/test_gpu_plicp.py).
+    rc = plicp_run(c, 1, 1, c->d_r, c->d_idx, c->d_idx + 1, opt, sigma, d_out, cov9 ? d_cov : nullptr); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->h_stage + c->off_small, d_out, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (cov9) HIP_TRY(hipMemcpyAsync(c->h_stage + c->off_small + sizeof(double) * 8, d_cov, sizeof(double) * 9, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    memcpy(out8, c->h_stage + c->off_small, sizeof(double) * 8);
+    double first[8];
+    memcpy(first, c->h_stage + c->off_small, sizeof first);
+    const bool restarts = first[3] == 1 && first[7] == 1;
+    if (restarts) {
+        rc = plicp_run(c, 2, 6, c->d_r, c->d_idx, c->d_idx + 1, opt, 0.0, d_out, nullptr); if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(c->h_stage + c->off_small, d_out + 8, sizeof(double) * 48, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const double* r = (const double*)(c->h_stage + c->off_small);
+        for (int a = 0; a < 6; ++a) {
+            if (r[8 * a + 3] != 1) continue;
+            first[5] += r[8 * a + 5];
+            if (r[8 * a + 4] < first[4]) { first[0] = r[8 * a]; first[1] = r[8 * a + 1]; first[2] = r[8 * a + 2]; first[4] = r[8 * a + 4]; }
+        }
+        if (cov9) {
+            memcpy(c->h_stage + c->off_small, first, sizeof(double) * 3);                 // the winner's pose, for phase 3
+            HIP_TRY(hipMemcpyAsync(d_out, c->h_stage + c->off_small, sizeof(double) * 3, hipMemcpyHostToDevice, c->stream));
+            rc = plicp_run(c, 3, 1, c->d_r, c->d_idx, c->d_idx + 1, opt, sigma, d_out, d_cov); if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(c->h_stage + c->off_small + sizeof(double) * 8, d_cov, sizeof(double) * 9, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+    }
+    first[7] = 0;
+    memcpy(out8, first, sizeof first);
     if (cov9) memcpy(cov9, c->h_stage + c->off_small + sizeof(double) * 8, sizeof(double) * 9);
     return LSA_OK;
 }

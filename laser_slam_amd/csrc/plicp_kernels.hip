@@ -667,8 +667,8 @@ __device__ void plicp_covariance(const PlicpParam& P, const PlicpLds& L, const f
 // LDS holds three at most, and the instance budgeted for three (168 registers instead of 128) keeps in registers what the
 // four-per-CU budget spills to scratch (540 B per lane there).  COV: also sm_icp's covariance of the result (d_cov9).
 // PHASE (the lone-call path of lsa_plicp_host, kernels of their own so that the batch's instance is what it was): 0 = a pair's
-// first run and, if need be, its six restarts; 1 = the first run only (out8[7] = 1: wants the restarts); 2 = item b is restart
-// b % 6 of pair b / 6 from the first run's record in out8.
+// first run and, if need be, its six restarts; 1 = the first run only (out8[7] = 1: wants the restarts - and no covariance
+// yet); 2 = item b is restart b % 6 of pair b / 6 from the first run's record in out8; 3 = the covariance at the pose in out8.
 template <int T, int WG, bool COV, int PHASE>
 __device__ __forceinline__ void plicp_pairs(const PlicpParam& P, int B, const float* __restrict__ g_r,
                                             const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
@@ -742,6 +742,16 @@ __device__ __forceinline__ void plicp_pairs(const PlicpParam& P, int B, const fl
             if (tid == 0) { o[0] = xa[0]; o[1] = xa[1]; o[2] = xa[2]; o[3] = ok ? 1 : 0; o[4] = my_error; o[5] = my_iters; o[6] = my_valid; o[7] = 0; }
             continue;
         }
+        if (PHASE == 3) {
+            // the covariance of a restarted pair at the pose the caller picked (out8[8 pair ..]): sm_icp recomputes the
+            // correspondences there, without outlier rejection
+            const double* at = out8 + 8 * (size_t)b;
+            const double pose[3] = {at[0], at[1], at[2]};
+            __syncthreads();
+            plicp_correspondences<T>(P, L, pose, cos(pose[2]), sin(pose[2]));
+            plicp_covariance<T>(P, L, g_r + (size_t)ref_idx[b] * n, pose, sigma, cov9 + 9 * (size_t)b);
+            continue;
+        }
         for (int a = -1; a < runs - 1; ++a) {
             const double dt = P.restart_dt, dth = P.restart_dtheta;
             const double start[3] = {x[0] + (a == 0 ? dt : a == 1 ? -dt : 0.0), x[1] + (a == 2 ? dt : a == 3 ? -dt : 0.0),
@@ -767,7 +777,7 @@ __device__ __forceinline__ void plicp_pairs(const PlicpParam& P, int B, const fl
         }
         if (ok_first) {
             res[0] = best[0]; res[1] = best[1]; res[2] = best[2]; res[3] = 1; res[4] = best_error; res[5] = iters; res[6] = nvalid;
-            if (COV) {
+            if (COV && !(PHASE == 1 && res[7] == 1)) {      // (a lone call's restarting pair gets its covariance in phase 3)
                 if (restarted) {                  // sm_icp recomputes the correspondences at the result after restarts (no outlier rejection)
                     __syncthreads();
                     plicp_correspondences<T>(P, L, best, cos(best[2]), sin(best[2]));
@@ -790,12 +800,13 @@ __global__ __launch_bounds__(T, WG) void plicp_kernel(PlicpParam P, int B, const
 {
     plicp_pairs<T, WG, COV, 0>(P, B, g_r, ref_idx, act_idx, trig, out8, sigma, cov9, queue);
 }
-template <int T, int WG, int PHASE>
+template <int T, int WG, bool COV, int PHASE>
 __global__ __launch_bounds__(T, WG) void plicp_lone_kernel(PlicpParam P, int B, const float* __restrict__ g_r,
                                                                    const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
-                                                                   const double* __restrict__ trig, double* out8, unsigned int* __restrict__ queue)
+                                                                   const double* __restrict__ trig, double* out8,
+                                                                   double sigma, double* __restrict__ cov9, unsigned int* __restrict__ queue)
 {
-    plicp_pairs<T, WG, false, PHASE>(P, B, g_r, ref_idx, act_idx, trig, out8, 0.0, nullptr, queue);
+    plicp_pairs<T, WG, COV, PHASE>(P, B, g_r, ref_idx, act_idx, trig, out8, sigma, cov9, queue);
 }
 
 } // namespace lsa

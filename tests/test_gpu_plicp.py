@@ -79,6 +79,16 @@ def test_plicp_restart_path():
     for b in range(B):
         one = capi.plicp_host(ctx, raw[b], raw[b + 1])
         assert np.array_equal(one, got[b]), (b, one, got[b])
+    # ... and with the covariance (FMatchKeyFrame2): the restarting pair's is formed at the winner by a phase of its own
+    d_out2 = torch.zeros(B, 8, dtype=torch.float64, device="cuda"); d_cov = torch.zeros(B, 9, dtype=torch.float64, device="cuda")
+    capi.plicp_batch_cov(ctx, B, d_r, torch.from_numpy(ri).cuda(), torch.from_numpy(ai).cuda(), 0.04, d_out2, d_cov)
+    ctx.sync()
+    got2, cov = d_out2.cpu().numpy(), d_cov.cpu().numpy()
+    assert np.array_equal(got2, got)
+    for b in range(B):
+        one, c1 = capi.plicp_host_cov(ctx, raw[b], raw[b + 1], 0.04)
+        assert np.array_equal(one, got[b]), (b, one, got[b])
+        assert np.allclose(c1.reshape(9), cov[b], rtol=1e-9, atol=0), (b, c1, cov[b])
     ctx.close()
 
 
