@@ -1626,7 +1626,7 @@ static int plicp_launch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const float
     int occ = occ_cache[c->device & 63].load();
     if (!occ || occ_lds[c->device & 63].load() != lds) {
         if (PHASE == 0) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lsa::plicp_kernel<T, WG, COV>, T, lds));
-        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lsa::plicp_lone_kernel<T, WG, COV, (PHASE ? PHASE : 1)>, T, lds));
+        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lsa::plicp_lone_kernel<T, WG, COV, (PHASE ? PHASE : 1)>, lsa::PLICP_THREADS, lds));
         if (occ < 1) occ = 1;
         occ_cache[c->device & 63].store(occ); occ_lds[c->device & 63].store(lds);
     }
@@ -1636,7 +1636,7 @@ static int plicp_launch(lsa_ctx* c, const lsa::PlicpParam& P, int B, const float
         hipLaunchKernelGGL((lsa::plicp_kernel<T, WG, COV>), dim3((unsigned)(B < resident ? B : resident)), dim3(T), lds, c->stream, P, B, d_r,
                            d_ref_idx, d_act_idx, c->d_trig, d_out8, sigma, d_cov9, c->d_queue);
     else
-        hipLaunchKernelGGL((lsa::plicp_lone_kernel<T, WG, COV, (PHASE ? PHASE : 1)>), dim3((unsigned)(B < resident ? B : resident)), dim3(T), lds, c->stream, P, B, d_r,
+        hipLaunchKernelGGL((lsa::plicp_lone_kernel<T, WG, COV, (PHASE ? PHASE : 1)>), dim3((unsigned)(B < resident ? B : resident)), dim3(lsa::PLICP_THREADS), lds, c->stream, P, B, d_r,
                            d_ref_idx, d_act_idx, c->d_trig, d_out8, sigma, d_cov9, c->d_queue);
     HIP_TRY(hipGetLastError());
     return LSA_OK;

@@ -62,15 +62,18 @@ struct PlicpLds {
     int* hist;                                             // 2 x 264 ints of the radix select
 };
 
-template <int T>
+// TS <= T: the sum as a workgroup of TS threads forms it - the first TS threads' values only, their waves' trees, the waves in
+// order - whatever the real width T (the lone-call instances run 256 threads and must return what the batch's width returns)
+template <int T, int TS = T>
 __device__ __forceinline__ double plicp_block_sum(double v, double* red)
 {
     for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
     if (T == 64) return v;
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0 && (int)threadIdx.x < TS) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (T == 128) return red[0] + red[1];
+    if (TS == 64) return red[0];
+    if (TS == 128) return red[0] + red[1];
     return red[0] + red[1] + red[2] + red[3];
 }
 
@@ -86,21 +89,22 @@ __device__ __forceinline__ double plicp_uniform(double v)
 __device__ __forceinline__ double plicp_dist2(double ax, double ay, double bx, double by) { return (ax - bx) * (ax - bx) + (ay - by) * (ay - by); }
 
 // the same fixed-order tree for K values at once (two barriers instead of 2 K)
-template <int K, int T>
+template <int K, int T, int TS = T>
 __device__ __forceinline__ void plicp_block_sums(double (&v)[K], double* red)
 {
     #pragma unroll
     for (int q = 0; q < K; ++q) for (int o = 32; o; o >>= 1) v[q] += __shfl_xor(v[q], o);
     if (T == 64) return;
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0 && (int)threadIdx.x < TS) {
         #pragma unroll
         for (int q = 0; q < K; ++q) red[24 + (threadIdx.x >> 6) * K + q] = v[q];
     }
     __syncthreads();
     #pragma unroll
     for (int q = 0; q < K; ++q) {
-        if (T == 128) v[q] = red[24 + q] + red[24 + K + q];
+        if (TS == 64) v[q] = red[24 + q];
+        else if (TS == 128) v[q] = red[24 + q] + red[24 + K + q];
         else v[q] = red[24 + q] + red[24 + K + q] + red[24 + 2 * K + q] + red[24 + 3 * K + q];
     }
 }
@@ -397,7 +401,7 @@ __device__ __forceinline__ int plicp_correspondences(const PlicpParam& P, const 
 }
 
 // one icp_loop from q0; returns ok, x_new, total error, kept correspondences, iterations (all uniform)
-template <int T>
+template <int T, int TS>
 __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double q0[3], double x_new[3], double& total_error,
                            int& nvalid, int& iterations)
 {
@@ -458,16 +462,22 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
             for (int i = tid; i < n; i += T) {
                 const double d = L.dist[i];
                 if (d < 0) continue;
-                if (d > limit) L.corr[i] = -1; else { mine++; err += d; }
+                if (d > limit) L.corr[i] = -1; else { mine++; if (TS == T) err += d; }
             }
+            if (TS != T && tid < TS)                        // (the error as TS threads add it up: every TS-th point in turn)
+                for (int i = tid; i < n; i += TS) {
+                    const double d = L.dist[i];
+                    if (d < 0) continue;
+                    if (!(d > limit)) err += d;
+                }
             nvalid = (int)plicp_block_sum<T>((double)mine, L.red);
-            total_error = plicp_block_sum<T>(err, L.red);
+            total_error = plicp_block_sum<T, TS>(err, L.red);
         }
         PSTAMP(2);
         if (nvalid < fail_perc * n) { ok = false; break; }
         // closed-form point-to-line step
         double s[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // M upper triangle (10), g (4)
-        for (int i = tid; i < n; i += T) {
+        for (int i = tid < TS ? tid : n; i < n; i += TS) {          // (TS < T: the first TS threads, as the batch's width sums)
             if (L.corr[i] < 0) continue;
             const int j1 = L.corr[i] & 0xffff, j2 = L.corr[i] >> 16;
             double px, py;
@@ -482,7 +492,7 @@ __device__ bool plicp_loop(const PlicpParam& P, const PlicpLds& L, const double 
             for (int r = 0; r < 4; ++r) for (int c = r; c < 4; ++c) s[q++] += a[r] * a[c];
             for (int r = 0; r < 4; ++r) s[10 + r] += a[r] * b;
         }
-        plicp_block_sums<14, T>(s, L.red);
+        plicp_block_sums<14, T, TS>(s, L.red);
         PSTAMP(3);
         // (every lane works the same step out; letting one wave do it and publish the result was measured: no gain)
         bool solved = nvalid >= 2;
@@ -669,7 +679,7 @@ __device__ void plicp_covariance(const PlicpParam& P, const PlicpLds& L, const f
 // PHASE (the lone-call path of lsa_plicp_host, kernels of their own so that the batch's instance is what it was): 0 = a pair's
 // first run and, if need be, its six restarts; 1 = the first run only (out8[7] = 1: wants the restarts - and no covariance
 // yet); 2 = item b is restart b % 6 of pair b / 6 from the first run's record in out8; 3 = the covariance at the pose in out8.
-template <int T, int WG, bool COV, int PHASE>
+template <int T, int TS, int WG, bool COV, int PHASE>
 __device__ __forceinline__ void plicp_pairs(const PlicpParam& P, int B, const float* __restrict__ g_r,
                                             const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
                                             const double* __restrict__ trig, double* out8,
@@ -737,7 +747,7 @@ __device__ __forceinline__ void plicp_pairs(const PlicpParam& P, int B, const fl
             double xa[3] = {0, 0, 0}, my_error = 0;
             int my_valid = 0, my_iters = 0;
             __syncthreads();
-            const bool ok = plicp_loop<T>(P, L, start, xa, my_error, my_valid, my_iters);
+            const bool ok = plicp_loop<T, TS>(P, L, start, xa, my_error, my_valid, my_iters);
             double* o = out8 + 8 * (size_t)(B / 6 + item);
             if (tid == 0) { o[0] = xa[0]; o[1] = xa[1]; o[2] = xa[2]; o[3] = ok ? 1 : 0; o[4] = my_error; o[5] = my_iters; o[6] = my_valid; o[7] = 0; }
             continue;
@@ -759,7 +769,7 @@ __device__ __forceinline__ void plicp_pairs(const PlicpParam& P, int B, const fl
             double xa[3] = {0, 0, 0}, my_error = 0;
             int my_valid = 0, my_iters = 0;
             __syncthreads();
-            const bool ok = plicp_loop<T>(P, L, start, xa, my_error, my_valid, my_iters);
+            const bool ok = plicp_loop<T, TS>(P, L, start, xa, my_error, my_valid, my_iters);
             if (a < 0) {
                 iters = my_iters;
                 if (!ok) break;
@@ -798,15 +808,16 @@ __global__ __launch_bounds__(T, WG) void plicp_kernel(PlicpParam P, int B, const
                                                               const double* __restrict__ trig, double* __restrict__ out8,
                                                               double sigma, double* __restrict__ cov9, unsigned int* __restrict__ queue)
 {
-    plicp_pairs<T, WG, COV, 0>(P, B, g_r, ref_idx, act_idx, trig, out8, sigma, cov9, queue);
+    plicp_pairs<T, T, WG, COV, 0>(P, B, g_r, ref_idx, act_idx, trig, out8, sigma, cov9, queue);
 }
-template <int T, int WG, bool COV, int PHASE>
-__global__ __launch_bounds__(T, WG) void plicp_lone_kernel(PlicpParam P, int B, const float* __restrict__ g_r,
+// (TS: the batch's width for this scan size - the sums are formed as it forms them; the kernel itself runs 256 threads)
+template <int TS, int WG, bool COV, int PHASE>
+__global__ __launch_bounds__(PLICP_THREADS, WG) void plicp_lone_kernel(PlicpParam P, int B, const float* __restrict__ g_r,
                                                                    const int* __restrict__ ref_idx, const int* __restrict__ act_idx,
                                                                    const double* __restrict__ trig, double* out8,
                                                                    double sigma, double* __restrict__ cov9, unsigned int* __restrict__ queue)
 {
-    plicp_pairs<T, WG, COV, PHASE>(P, B, g_r, ref_idx, act_idx, trig, out8, sigma, cov9, queue);
+    plicp_pairs<PLICP_THREADS, TS, WG, COV, PHASE>(P, B, g_r, ref_idx, act_idx, trig, out8, sigma, cov9, queue);
 }
 
 } // namespace lsa
