@@ -558,7 +558,7 @@ int lsa_match_batch(lsa_ctx* c, int which, int B,
         hipLaunchKernelGGL((lsa::psm_kernel<NC, TH>), dim3((unsigned)(B < resident ? B : resident)), dim3(TH), lds, c->stream, P, B, \
                            d_r, d_bad, d_seg, d_ref_idx, d_act_idx, d_init_pose, d_pose_out, d_ret, d_err_xy, d_n_assoc, d_status, d_iters, c->d_queue); } while (0)
 #define LSA_LAUNCH_PSM(NC) do { \
-        constexpr int TW = NC == 1081 ? 512 : 256;           /* (eight per-wave slots beside the pose slots: no more than 512) */ \
+        constexpr int TW = NC == 181 ? 256 : 512;            /* (eight per-wave slots beside the pose slots: no more than 512) */ \
         if (pwide && lsa::psm_threads(NC) != TW) LSA_LAUNCH_PSM_T(NC, TW, occ_psm_wide); \
         else LSA_LAUNCH_PSM_T(NC, lsa::psm_threads(NC), occ_psm); } while (0)
         switch (P.n) {
